@@ -1,0 +1,222 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference MCTS tree path.
+ *
+ * This file is the checker for the HIP tree kernels.  It is compiled by
+ * oracle/Makefile into oracle/_build/libmz_oracle.so and may be loaded only by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing in the
+ * product package (muzero_amd/) links, imports or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py replays the streams captured
+ * from the imported reference (tools/make_goldens.py) through these functions and
+ * demands bit-identical per-node visit counts / value sums / priors, selected leaf
+ * and chosen child per simulation, and the reference's own known-answer tests
+ * (tests/search/test_selection.py:29-41, tests/search/test_backpropagation.py:15-81).
+ *
+ * The tree is a flat pool: node 0 is the root, every expansion appends A children in
+ * action order, so children of a node are `first_child .. first_child+A-1`.
+ * Network outputs are *inputs* here (recorded streams): the prior vector written by
+ * an expansion is the value the reference stores with `.item()` after its extra
+ * softmax (src/search/expansion.py:26-32).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define MZ_C1 1.25
+#define MZ_C2 19652.0
+
+typedef struct {
+    int32_t A;            /* actions per expansion                                  */
+    int32_t cap;          /* node capacity                                          */
+    int32_t n_nodes;      /* nodes in use                                           */
+    int32_t *visit;       /* Node.visit_count   src/search/nodes.py:16              */
+    double *value_sum;    /* Node.value_sum     src/search/nodes.py:17              */
+    double *prior;        /* Node.policy_priority (fp32 value widened)  nodes.py:19 */
+    float *reward;        /* Node.reward        src/search/nodes.py:18              */
+    int32_t *parent;      /* -1 for the root                                        */
+    int32_t *first_child; /* -1 while the node has no children                      */
+    int8_t *to_play;      /* Node.to_play       src/search/nodes.py:15              */
+} mzo_tree;
+
+void mzo_init(mzo_tree *t, int32_t root_to_play) {
+    t->n_nodes = 1;
+    t->visit[0] = 0;
+    t->value_sum[0] = 0.0;
+    t->prior[0] = 0.0;
+    t->reward[0] = 0.0f;
+    t->parent[0] = -1;
+    t->first_child[0] = -1;
+    t->to_play[0] = (int8_t)root_to_play;
+}
+
+/* src/search/expansion.py:30-35 + src/search/nodes.py:24-30.
+ * Returns the index of the child random.choice picked (first_child + rand_child). */
+int32_t mzo_expand(mzo_tree *t, int32_t leaf, const float *prior32, const float *reward32,
+                   int32_t rand_child) {
+    int32_t base = t->n_nodes;
+    for (int a = 0; a < t->A; ++a) {
+        int32_t c = base + a;
+        t->visit[c] = 0;
+        t->value_sum[c] = 0.0;
+        t->prior[c] = (double)prior32[a];
+        t->reward[c] = reward32[a];
+        t->parent[c] = leaf;
+        t->first_child[c] = -1;
+        t->to_play[c] = (int8_t)(-t->to_play[leaf]);
+    }
+    t->first_child[leaf] = base;
+    t->n_nodes = base + t->A;
+    return base + rand_child;
+}
+
+/* src/search/mcts.py:91-94.  After the update the root children hold 0-dim float32
+ * tensors: P' = f32( P + f32( f32((1-eps)*P as f64) + f32(eps)*eta ) ).            */
+void mzo_root_noise(mzo_tree *t, const float *eta, double noise_frac) {
+    int32_t base = t->first_child[0];
+    volatile float e32 = (float)noise_frac;
+    for (int a = 0; a < t->A; ++a) {
+        double p = t->prior[base + a];
+        volatile float keep = (float)((1.0 - noise_frac) * p);
+        volatile float mix = e32 * eta[a];
+        volatile float add = keep + mix;
+        volatile float out = (float)p + add;
+        t->prior[base + a] = (double)out;
+    }
+}
+
+/* src/search/selection.py:43-59.  Children of the root are scored in float32 (their
+ * prior is a float32 tensor after mcts.py:94), all other children in float64.
+ * max(..., key=) keeps the first maximal element.                                   */
+int32_t mzo_select(const mzo_tree *t, int32_t *out_depth) {
+    int32_t node = 0, depth = 0;
+    while (t->first_child[node] >= 0) {
+        int32_t base = t->first_child[node];
+        double sqrt_np = sqrt((double)t->visit[node]);
+        int32_t best = base;
+        double best64 = 0.0;
+        float best32 = 0.0f;
+        for (int a = 0; a < t->A; ++a) {
+            int32_t c = base + a;
+            int32_t n = t->visit[c];
+            volatile double pb = sqrt_np / (double)(n + 1);
+            volatile double lg = log(((double)n + MZ_C2 + 1.0) / MZ_C2) + MZ_C1;
+            pb = pb * lg;
+            if (node == 0) {
+                volatile float ps = (float)pb * (float)t->prior[c];
+                volatile float sc = ps;
+                if (n > 0) {
+                    volatile double q = t->value_sum[c] / (double)n;
+                    sc = (float)q + ps;
+                }
+                if (a == 0 || sc > best32) { best32 = sc; best = c; }
+            } else {
+                volatile double ps = pb * t->prior[c];
+                volatile double sc = ps;
+                if (n > 0) {
+                    volatile double q = t->value_sum[c] / (double)n;
+                    sc = q + ps;
+                } else {
+                    sc = 0.0 + ps; /* `ts = 0` (int) + float */
+                }
+                if (a == 0 || sc > best64) { best64 = sc; best = c; }
+            }
+        }
+        node = best;
+        ++depth;
+    }
+    if (out_depth) *out_depth = depth;
+    return node;
+}
+
+/* src/search/backpropagation.py:9-18.  `rewards` = [r_1 .. r_depth, v] as produced by
+ * src/search/simulation.py:44 (float32 values widened to Python floats).            */
+double mzo_backup(mzo_tree *t, int32_t child, const float *rewards, int32_t n_rewards,
+                  int32_t leaf_to_play, double discount) {
+    volatile double g = 0.0;
+    for (int i = n_rewards - 1; i >= 0; --i) {
+        volatile double m = discount * g;
+        g = (double)rewards[i] + m;
+    }
+    int32_t node = child;
+    while (node >= 0) {
+        t->visit[node] += 1;
+        volatile double add = (t->to_play[node] == leaf_to_play) ? g : -g;
+        t->value_sum[node] = t->value_sum[node] + add;
+        node = t->parent[node];
+    }
+    return g;
+}
+
+/* src/search/mcts.py:71-72,97-103: root mean value and softmax over the root
+ * children's value sums (no max shift, Python sum() order).                         */
+void mzo_result(const mzo_tree *t, double *policy, double *utility) {
+    int32_t base = t->first_child[0];
+    double s = 0.0;
+    for (int a = 0; a < t->A; ++a) {
+        policy[a] = exp(t->value_sum[base + a]);
+        s = s + policy[a];
+    }
+    for (int a = 0; a < t->A; ++a) policy[a] = policy[a] / s;
+    *utility = t->value_sum[0] / (double)t->visit[0];
+}
+
+/*
+ * Whole MCTS.run (src/search/mcts.py:44-74) driven by recorded streams:
+ *   prior_stream  [S+1][A]   priors written by expansion e (e = 0 is the root expansion)
+ *   reward_stream [S+1][A]   dynamics rewards of expansion e
+ *   rand_stream   [S+1]      random.choice index of expansion e (index 0 is discarded
+ *                            by the reference, mcts.py:89)
+ *   sim_stream    [S][depth+1]  the list MuZeroSimulation returns for simulation s
+ * Optional per-simulation traces: leaf[S], child[S], ret[S].
+ */
+void mzo_run(mzo_tree *t, int32_t root_to_play, int32_t S, int32_t depth,
+             const float *prior_stream, const float *reward_stream,
+             const int32_t *rand_stream, const float *sim_stream, const float *eta,
+             double noise_frac, double discount, int32_t *leaf_trace, int32_t *child_trace,
+             double *ret_trace, double *policy, double *utility) {
+    int A = t->A;
+    mzo_init(t, root_to_play);
+    (void)mzo_expand(t, 0, prior_stream, reward_stream, rand_stream[0]);
+    mzo_root_noise(t, eta, noise_frac);
+    for (int s = 0; s < S; ++s) {
+        int32_t leaf = mzo_select(t, 0);
+        int32_t child = mzo_expand(t, leaf, prior_stream + (size_t)(s + 1) * A,
+                                   reward_stream + (size_t)(s + 1) * A, rand_stream[s + 1]);
+        double g = mzo_backup(t, child, sim_stream + (size_t)s * (depth + 1), depth + 1,
+                              t->to_play[leaf], discount);
+        if (leaf_trace) leaf_trace[s] = leaf;
+        if (child_trace) child_trace[s] = child;
+        if (ret_trace) ret_trace[s] = g;
+    }
+    mzo_result(t, policy, utility);
+}
+
+/*
+ * Batched driver over G independent trees with [G]-major streams; used to check the
+ * HIP kernels at full size and as a scalar CPU timing leg for the tree-only path.
+ * Pool arrays are [G][cap]; `to_play` is [G].
+ */
+void mzo_run_batch(int32_t G, int32_t A, int32_t S, int32_t depth, int32_t cap,
+                   int32_t *visit, double *value_sum, double *prior, float *reward,
+                   int32_t *parent, int32_t *first_child, int8_t *to_play_nodes,
+                   const int8_t *root_to_play, const float *prior_stream,
+                   const float *reward_stream, const int32_t *rand_stream,
+                   const float *sim_stream, const float *eta, double noise_frac,
+                   double discount, int32_t *leaf_trace, int32_t *child_trace,
+                   double *policy, double *utility) {
+    for (int32_t g = 0; g < G; ++g) {
+        mzo_tree t;
+        size_t o = (size_t)g * cap;
+        t.A = A; t.cap = cap; t.n_nodes = 0;
+        t.visit = visit + o; t.value_sum = value_sum + o; t.prior = prior + o;
+        t.reward = reward + o; t.parent = parent + o; t.first_child = first_child + o;
+        t.to_play = to_play_nodes + o;
+        mzo_run(&t, root_to_play[g], S, depth,
+                prior_stream + (size_t)g * (S + 1) * A, reward_stream + (size_t)g * (S + 1) * A,
+                rand_stream + (size_t)g * (S + 1), sim_stream + (size_t)g * S * (depth + 1),
+                eta + (size_t)g * A, noise_frac, discount,
+                leaf_trace ? leaf_trace + (size_t)g * S : 0,
+                child_trace ? child_trace + (size_t)g * S : 0, 0,
+                policy + (size_t)g * A, utility + g);
+    }
+}

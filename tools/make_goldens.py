@@ -1,0 +1,336 @@
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+
+The reference checkout (/root/reference) is imported through tools/_ref_shim.py, driven on
+seeded inputs, and its inputs/outputs are written as plain arrays.  Nothing from the
+reference's source travels: fixtures are data only.  Every fixture stores the inputs needed
+to replay it (weights of the small networks, root latents, Dirichlet samples, child-choice
+streams, recorded network-output streams) next to the reference's outputs.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import _ref_shim  # noqa: E402
+
+_ref_shim.install()
+torch.set_num_threads(1)
+
+from src.config import config_loader as rcfg  # noqa: E402
+from src.neural_networks.neural_network import (  # noqa: E402
+    DynamicsNetwork as RefG,
+    PredictionNetwork as RefF,
+    RepresentationNetwork as RefH,
+)
+from src.search import mcts as ref_mcts_mod  # noqa: E402
+from src.search.factory import create_mcts as ref_create_mcts  # noqa: E402
+from src.search.nodes import Node as RefNode  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def dense(n, act="relu"):
+    return rcfg.DenseLayerConfig(out_features=n, activation=act)
+
+
+def build_ref_nets(obs_space, latent_shape, A, K, reward, value, policy, seed):
+    torch.manual_seed(seed)
+    h = RefH(obs_space, latent_shape,
+             rcfg.RepresentationNetworkConfig(history_length=K, downsample=[], res_net=[]))
+    g = RefG(latent_shape, A, rcfg.DynamicsNetworkConfig(res_net=[], reward_net=[dense(n) for n in reward]))
+    f = RefF(latent_shape, A, rcfg.PredictionNetworkConfig(
+        res_net=[], value_net=[dense(n) for n in value], policy_net=[dense(n) for n in policy]))
+    return h, g, f
+
+
+def sd_arrays(prefix, module):
+    return {f"{prefix}{k}": v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def sd_hash(*modules):
+    m = hashlib.sha256()
+    for mod in modules:
+        for k, v in mod.state_dict().items():
+            m.update(k.encode())
+            m.update(v.detach().numpy().tobytes())
+    return m.hexdigest()
+
+
+# ----------------------------------------------------------------------------------------
+# MCTS trees
+# ----------------------------------------------------------------------------------------
+def capture_tree(g, f, A, S, depth, to_play, noise_frac, discount, root_latent, seed):
+    """Run the reference MCTS.run once and record streams + the whole tree."""
+    cfg = rcfg.MCTSConfig(selection_strategy="puct", max_iterations=S, max_time=0, model_look_ahead=depth,
+                          discount_factor=discount, dirichlet_alpha=0.3, noise_frac=noise_frac)
+    actions = torch.arange(A).long()
+    mcts = ref_create_mcts(g, f, actions, cfg)
+    index_of = {}
+    order = []
+    rec = {"prior": [], "reward": [], "rand": [], "sim": [], "leaf": [], "child": []}
+
+    def reg(node):
+        index_of[id(node)] = len(order)
+        order.append(node)
+
+    orig_expand = ref_mcts_mod.expand_node
+
+    def expand_rec(node, acts, dyn, pred):
+        chosen = orig_expand(node, acts, dyn, pred)
+        kids = list(node.children.values())
+        for k in kids:
+            reg(k)
+        rec["prior"].append([float(k.policy_priority) for k in kids])
+        rec["reward"].append([k.reward.item() for k in kids])
+        rec["rand"].append([i for i, k in enumerate(kids) if k is chosen][0])
+        rec["child"].append(index_of[id(chosen)])
+        return chosen
+
+    orig_sel, orig_sim = mcts.selection, mcts.simulation
+
+    def sel_rec(root):
+        leaf = orig_sel(root)
+        rec["leaf"].append(index_of[id(leaf)])
+        return leaf
+
+    def sim_rec(node):
+        out = orig_sim(node)
+        rec["sim"].append(list(out))
+        return out
+
+    mcts.selection, mcts.simulation = sel_rec, sim_rec
+    ref_mcts_mod.expand_node = expand_rec
+    try:
+        random.seed(seed)
+        torch.manual_seed(seed)
+        py_state, t_state = random.getstate(), torch.get_rng_state()
+        root = RefNode(latent_state=root_latent.clone(), to_play=to_play)
+        reg(root)
+        with torch.no_grad():
+            policy, utility = mcts.run(root)
+        # replay the RNG draws the run consumed (expansion.py:35, mcts.py:91)
+        random.setstate(py_state)
+        torch.set_rng_state(t_state)
+        rand_replay = [random.randrange(A) for _ in range(S + 1)]
+        eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample().numpy()
+    finally:
+        ref_mcts_mod.expand_node = orig_expand
+    assert rand_replay == rec["rand"], "child-choice replay mismatch"
+    n = len(order)
+    assert n == 1 + A + S * A
+    first_child = np.full(n, -1, np.int32)
+    for nd in order:
+        kids = list(nd.children.values())
+        if kids:
+            first_child[index_of[id(nd)]] = index_of[id(kids[0])]
+            assert [index_of[id(k)] for k in kids] == list(range(index_of[id(kids[0])], index_of[id(kids[0])] + A))
+    return {
+        "A": A, "S": S, "depth": depth, "to_play": to_play, "noise_frac": noise_frac, "discount": discount,
+        "seed": seed,
+        "root_latent": root_latent.numpy().copy(),
+        "eta": eta.astype(np.float32),
+        "rand": np.array(rec["rand"], np.int32),
+        "prior_stream": np.array(rec["prior"][0:1] + rec["prior"][1:], np.float32),
+        "prior_stream_f64": np.array(rec["prior"], np.float64),
+        "reward_stream": np.array(rec["reward"], np.float32),
+        "sim_stream": np.array(rec["sim"], np.float64),
+        "leaf": np.array(rec["leaf"], np.int32),
+        "child": np.array(rec["child"][1:], np.int32),
+        "visit": np.array([nd.visit_count for nd in order], np.int32),
+        "value_sum": np.array([float(nd.value_sum) for nd in order], np.float64),
+        "prior": np.array([float(nd.policy_priority) for nd in order], np.float64),
+        "parent": np.array([-1 if nd.parent is None else index_of[id(nd.parent)] for nd in order], np.int32),
+        "first_child": first_child,
+        "node_to_play": np.array([nd.to_play for nd in order], np.int8),
+        "policy": np.array(policy, np.float64),
+        "utility": np.float64(utility),
+    }
+
+
+def make_trees():
+    out = {}
+    cases = []
+    # (A, S, depth, to_play, noise_frac, discount, scale, uniform_policy)
+    seed = 1000
+    for A in (2, 5, 7):
+        for depth in (1, 2, 3):
+            for nf in (0.0, 0.25):
+                tp = {2: 0, 5: 1, 7: -1}[A] if depth != 2 else 1
+                cases.append((A, 50, depth, tp, nf, 0.998 if depth != 3 else 1.0, 1.0, False))
+    # value-dominated trees (large |Q|), exact prior ties, short searches, to_play 0
+    cases += [
+        (7, 50, 1, 1, 0.25, 0.998, 25.0, False),
+        (7, 50, 1, -1, 0.0, 0.998, 25.0, False),
+        (7, 50, 1, 1, 0.0, 0.998, 1.0, True),
+        (7, 50, 1, 1, 0.25, 0.998, 1.0, True),
+        (7, 1, 1, 1, 0.25, 0.998, 1.0, False),
+        (7, 3, 1, 0, 0.25, 0.9, 8.0, False),
+        (3, 120, 1, 1, 0.25, 0.997, 8.0, False),
+        (7, 50, 1, 1, 0.25, 0.998, 1.0, False),
+    ]
+    nets = {}
+    for ci, (A, S, depth, tp, nf, disc, scale, uniform) in enumerate(cases):
+        key = (A, scale, uniform)
+        if key not in nets:
+            h, g, f = build_ref_nets((2, 3, 3), (2, 3, 3), A, 1, [16], [16], [16], seed=7 + A)
+            with torch.no_grad():
+                if scale != 1.0:
+                    g.reward_mlp[-2].weight.mul_(scale)
+                    f.value_mlp[-2].weight.mul_(scale)
+                    f.value_mlp[-2].bias.add_(0.3)
+                if uniform:
+                    f.policy_mlp[-2].weight.zero_()
+                    f.policy_mlp[-2].bias.zero_()
+            nets[key] = (len(nets), g, f)
+        ni, g, f = nets[key]
+        torch.manual_seed(seed + ci)
+        root_latent = torch.randn(1, 2, 3, 3)
+        c = capture_tree(g, f, A, S, depth, tp, nf, disc, root_latent, seed + ci)
+        c["net"] = ni
+        for k, v in c.items():
+            out[f"c{ci}_{k}"] = np.asarray(v)
+    for key, (ni, g, f) in nets.items():
+        out.update(sd_arrays(f"net{ni}_g.", g))
+        out.update(sd_arrays(f"net{ni}_f.", f))
+        out[f"net{ni}_A"] = np.int32(key[0])
+    out["n_cases"] = np.int32(len(cases))
+    out["n_nets"] = np.int32(len(nets))
+    np.savez_compressed(os.path.join(OUT, "mcts_trees.npz"), **out)
+    print("mcts_trees.npz:", len(cases), "cases")
+
+
+# ----------------------------------------------------------------------------------------
+# c4_mlp: tree driven by the benchmark networks + network input/output vectors
+# ----------------------------------------------------------------------------------------
+def make_c4_mlp():
+    out = {}
+    A = 7
+    h, g, f = build_ref_nets((2, 6, 7), (4, 6, 7), A, 1, [128], [256, 128], [256, 256], seed=0)
+    out["weights_sha256"] = np.array(sd_hash(h, g, f))
+    # the package's own modules must produce the same initial weights from the same seed
+    from muzero_amd.config import load_config
+    from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork, RepresentationNetwork
+    cfg = load_config("config_c4_mlp.yaml")
+    torch.manual_seed(0)
+    mh = RepresentationNetwork((2, 6, 7), cfg.networks.latent_shape, cfg.networks.representation)
+    mg = DynamicsNetwork(cfg.networks.latent_shape, A, cfg.networks.dynamics)
+    mf = PredictionNetwork(cfg.networks.latent_shape, A, cfg.networks.prediction)
+    assert sd_hash(mh, mg, mf) == sd_hash(h, g, f), "package modules do not reproduce reference init"
+    # network vectors
+    torch.manual_seed(11)
+    B = 16
+    obs = (torch.rand(B, 3, 6, 7) > 0.6).float()
+    obs[:, 2] = 0.0
+    lat = torch.randn(B, 4, 6, 7)
+    act = torch.randint(0, A, (B,))
+    with torch.no_grad():
+        out["h_in"] = obs.numpy()
+        out["h_out"] = h(obs).numpy()
+        out["g_latent"] = lat.numpy()
+        out["g_action"] = act.numpy().astype(np.int64)
+        nl, r = g(lat, act)
+        out["g_next"], out["g_reward"] = nl.numpy(), r.numpy()
+        p, v = f(lat)
+        out["f_policy"], out["f_value"] = p.numpy(), v.numpy()
+        # expansion-shaped call: one latent repeated for all actions
+        nl7, r7 = g(lat[:1].repeat(A, 1, 1, 1), torch.arange(A))
+        out["g7_next"], out["g7_reward"] = nl7.numpy(), r7.numpy()
+        # trees from the empty board, both noise settings
+        empty = torch.zeros(1, 3, 6, 7)
+        root_latent = h(empty)
+    for i, (nf, tp, seed) in enumerate([(0.25, 1, 0), (0.0, 1, 1), (0.25, -1, 2)]):
+        c = capture_tree(g, f, A, 50, 1, tp, nf, 0.998, root_latent, seed)
+        for k, v in c.items():
+            out[f"t{i}_{k}"] = np.asarray(v)
+    out["n_trees"] = np.int32(3)
+    np.savez_compressed(os.path.join(OUT, "c4_mlp.npz"), **out)
+    print("c4_mlp.npz ok")
+
+
+# ----------------------------------------------------------------------------------------
+# data side: history tensor, z-targets, replay sampling
+# ----------------------------------------------------------------------------------------
+def make_data():
+    from src.replay_buffer import ReplayBuffer as RefReplay
+    from src.ring_buffer import Frame, FrameRingBuffer, make_history_tensor
+    from src.training import NeuralNetworkManager as RefManager
+    from src.training_data_generator import Chunk, Episode
+
+    out = {}
+    # history tensors: K in {1,3,4}, T steps, random actions
+    rng = np.random.default_rng(5)
+    hi = 0
+    for K in (1, 3, 4):
+        T = 7
+        frames = rng.standard_normal((T, 1, 2, 3, 4)).astype(np.float32)
+        actions = rng.integers(0, 7, size=T)
+        rb = FrameRingBuffer(size=K)
+        for t in range(T):
+            fr = Frame(state=torch.from_numpy(frames[t]), action=int(actions[t]))
+            if not rb.full():
+                rb.fill(fr)
+            else:
+                rb.add(fr)
+            out[f"hist{hi}_K"] = np.int32(K)
+            out[f"hist{hi}_t"] = np.int32(t)
+            out[f"hist{hi}_out"] = make_history_tensor(rb).numpy()
+            hi += 1
+        out[f"histseq_K{K}_frames"] = frames
+        out[f"histseq_K{K}_actions"] = actions.astype(np.int32)
+    out["n_hist"] = np.int32(hi)
+
+    # z targets
+    mgr = RefManager.__new__(RefManager)
+    zi = 0
+    for w, gamma in ((5, 0.998), (3, 0.9), (1, 1.0), (5, 0.5)):
+        mgr.roll_ahead = w
+        R = rng.standard_normal(w + 1).astype(np.float32).astype(np.float64)
+        V = rng.standard_normal(w + 1)
+        z = mgr._compute_z_targets([float(x) for x in R], [float(x) for x in V], gamma)
+        out[f"z{zi}_w"], out[f"z{zi}_gamma"] = np.int32(w), np.float64(gamma)
+        out[f"z{zi}_R"], out[f"z{zi}_V"], out[f"z{zi}_z"] = R, V, np.array(z, np.float64)
+        zi += 1
+    out["n_z"] = np.int32(zi)
+
+    # replay buffer: add, sample, update priorities, sample again (numpy global RNG)
+    def fake_episode(n, base):
+        return Episode(chunks=[Chunk(state=torch.zeros(1), policy=torch.zeros(1), reward=float(base + i),
+                                     value=0.0, best_action=0) for i in range(n)])
+    np.random.seed(1234)
+    rb = RefReplay(buffer_size=10, batch_size=4, alpha=0.6, beta=1.0)
+    rb.add_episodes([fake_episode(3 + i, i) for i in range(12)])
+    out["rp_kept_first_reward"] = np.array([ep.chunks[0].reward for ep, _ in rb.episode_buffer])
+    b1, i1, w1 = rb.sample_batch()
+    rb.update_priorities(i1, [0.5, 2.0, 0.0, 3.5])
+    b2, i2, w2 = rb.sample_batch()
+    rb.add_episodes([fake_episode(2, 100)])
+    b3, i3, w3 = rb.sample_batch()
+    out["rp_idx1"], out["rp_w1"] = np.array(i1, np.int64), np.array(w1, np.float64)
+    out["rp_idx2"], out["rp_w2"] = np.array(i2, np.int64), np.array(w2, np.float64)
+    out["rp_idx3"], out["rp_w3"] = np.array(i3, np.int64), np.array(w3, np.float64)
+    out["rp_prio_final"] = np.array([p for _, p in rb.episode_buffer], np.float64)
+    out["rp_max_priority"] = np.float64(rb.max_priority)
+    np.savez_compressed(os.path.join(OUT, "data_path.npz"), **out)
+    print("data_path.npz ok")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["trees", "c4", "data"]
+    if "trees" in which:
+        make_trees()
+    if "c4" in which:
+        make_c4_mlp()
+    if "data" in which:
+        make_data()
