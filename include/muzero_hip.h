@@ -1,0 +1,238 @@
+/*
+ * libmuzero_hip.so -- C ABI of the MI355X (gfx950) MuZero search / self-play hot path.
+ *
+ * The reference (SverreNystad/MuZero) is pure Python with no FFI, so the boundary this
+ * library replaces is the set of Python call sites named beside each entry point; the
+ * host-side mirror in muzero_amd/ binds these symbols with ctypes and keeps the
+ * reference's Python signatures on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name starts with `h_`;
+ *   - the caller owns all memory; the library never allocates device memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     asynchronous on that stream and keep no host state between calls;
+ *   - return value 0 = success, negative = failure (argument validation or a HIP launch
+ *     error); mz_last_error() returns a thread-local description of the last failure;
+ *   - arrays are row-major and densely packed; `G` = number of independent trees/games,
+ *     `A` = actions per expansion (1..64), `cap` = node capacity per tree, `D` = floats
+ *     per latent state.
+ */
+#ifndef MUZERO_HIP_H
+#define MUZERO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_OK 0
+#define MZ_ERR_ARG (-1)
+#define MZ_ERR_HIP (-2)
+
+#define MZ_SELECT_ROOT_F32 1
+
+#define MZ_ACT_NONE 0
+#define MZ_ACT_RELU 1
+#define MZ_ACT_TANH 2
+#define MZ_ACT_SIGMOID 3
+#define MZ_ACT_SOFTMAX 4
+
+const char *mz_last_error(void);
+int mz_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Node pool: G trees x cap nodes, structure-of-arrays.  Node 0 of every tree is its root;
+ * an expansion appends A children in action order, so the children of node i are
+ * first_child[i] .. first_child[i]+A-1.   Replaces the per-node Python object
+ * src/search/nodes.py:7-30 (fields visit_count, value_sum, policy_priority, reward,
+ * parent, children, to_play, latent_state).
+ * ------------------------------------------------------------------------------------ */
+typedef struct mz_pool {
+    int32_t G, A, cap, D;
+    int32_t *visit;       /* [G][cap]      Node.visit_count                                  */
+    double *value_sum;    /* [G][cap]      Node.value_sum                                    */
+    double *prior;        /* [G][cap]      Node.policy_priority (a float32 value, widened)   */
+    float *reward;        /* [G][cap]      Node.reward                                       */
+    int32_t *parent;      /* [G][cap]      -1 for the root                                   */
+    int32_t *first_child; /* [G][cap]      -1 while the node has no children                 */
+    int8_t *to_play;      /* [G][cap]      Node.to_play                                      */
+    int32_t *n_nodes;     /* [G]           nodes in use                                      */
+    float *latent;        /* [G][cap][D]   Node.latent_state (may be NULL: statistics only)  */
+} mz_pool;
+
+/* Fills the two PUCT lookup tables on the HOST with the C library's sqrt/log so the
+ * device never evaluates a transcendental on the argmax path:
+ *   h_sqrt_tab[n] = sqrt(n),  h_log_tab[n] = log((n + 19652 + 1) / 19652) + 1.25,  n < len
+ * (src/search/selection.py:46-47; c1 = 1.25, c2 = 19652 are the reference's fixed
+ * defaults, src/search/factory.py:37).  The caller copies them to the device. */
+int mz_puct_tables(double *h_sqrt_tab, double *h_log_tab, int32_t len);
+
+/* Root creation: Node(latent_state, to_play) -- src/training_data_generator.py:119.
+ * root_to_play i8[G]; root_latent f32[G][D] or NULL. */
+int mz_tree_init(const mz_pool *pool, const int8_t *root_to_play, const float *root_latent,
+                 void *stream);
+
+/* PUCT descent root -> childless node: src/search/selection.py:43-59.  Children of the
+ * root are scored in float32 when `flags & MZ_SELECT_ROOT_F32` (the state MCTS.run leaves
+ * them in: src/search/mcts.py:94 turns their priors into float32 tensors), every other
+ * level in float64; the first maximum wins.  out_leaf i32[G], out_depth i32[G] (may be NULL).
+ * sqrt_tab/log_tab: device copies of mz_puct_tables, tab_len entries; a visit count
+ * >= tab_len fails the call's tree with leaf = -1. */
+int mz_tree_select(const mz_pool *pool, const double *sqrt_tab, const double *log_tab,
+                   int32_t tab_len, int32_t flags, int32_t *out_leaf, int32_t *out_depth,
+                   void *stream);
+
+/* Child creation for one expansion per tree: src/search/expansion.py:30-35 with
+ * src/search/nodes.py:24-30.  leaf i32[G]; prior f32[G][A] (the value the reference stores
+ * with .item() after its extra softmax); reward f32[G][A]; next_latent f32[G][A][D] or NULL
+ * (NULL: latents were already written in place by mz_dynamics_expand); rand_child i32[G]
+ * in [0,A) = the index random.choice drew; out_child i32[G] = pool index of that child.
+ * A tree whose pool is full is left unchanged and gets out_child = -1. */
+int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float *prior,
+                          const float *reward, const float *next_latent,
+                          const int32_t *rand_child, int32_t *out_child, void *stream);
+
+/* Root prior perturbation: src/search/mcts.py:91-94 (in float32:
+ * P <- P + ((1-eps)*P + eps*eta), i.e. (2-eps)*P + eps*eta).  eta f32[G][A]. */
+int mz_tree_root_noise(const mz_pool *pool, const float *eta, double noise_frac, void *stream);
+
+/* Discounted return + path update: src/search/backpropagation.py:9-18.
+ * child i32[G] (start node), leaf i32[G] (its to_play decides the sign),
+ * rollout f32[G][n_rollout] = [r_1 .. r_depth, v] from src/search/simulation.py:44.
+ * Trees with child < 0 are skipped. */
+int mz_tree_backup(const mz_pool *pool, const int32_t *child, const int32_t *leaf,
+                   const float *rollout, int32_t n_rollout, double discount, void *stream);
+
+/* Search result: src/search/mcts.py:71-72,97-103.  policy f64[G][A] = softmax over the
+ * root children's value sums, policy32 f32[G][A] = its float32 cast
+ * (src/training_data_generator.py:122), value f64[G] = root value_sum / visit_count,
+ * visits i32[G][A] = root children's visit counts.  Any output may be NULL. */
+int mz_tree_result(const mz_pool *pool, double *policy, float *policy32, double *value,
+                   int32_t *visits, void *stream);
+
+/* out[g][:] = pool.latent[g][idx[g]][:]   (idx < 0 -> zeros). */
+int mz_tree_gather_latent(const mz_pool *pool, const int32_t *idx, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * MLP networks (`res_net: []` configurations): fused fp32 MFMA kernels.
+ * Weights are passed in torch.nn.Linear layout W[out][in] (row stride ldw), bias[out].
+ * ------------------------------------------------------------------------------------ */
+#define MZ_MAX_LAYERS 8
+
+typedef struct mz_dense {
+    const float *weight; /* [out][in], row stride ldw floats (0 = in_features) */
+    const float *bias;   /* [out] or NULL */
+    int32_t in_features, out_features, activation, ldw;
+} mz_dense;
+
+/* Sequence of Linear+activation layers: build_mlp, src/neural_networks/network_builder.py:183-205. */
+typedef struct mz_mlp {
+    int32_t n_layers;
+    mz_dense layer[MZ_MAX_LAYERS];
+} mz_mlp;
+
+/* Layout of one MLP inside a packed weight blob (offsets in floats from the blob start). */
+typedef struct mz_packed_layer {
+    int32_t K, N, Kp, Np, act, _pad;
+    int64_t w_off, b_off;
+} mz_packed_layer;
+
+typedef struct mz_packed_mlp {
+    int32_t n_layers, in_features, out_features, max_width;
+    mz_packed_layer layer[MZ_MAX_LAYERS];
+} mz_packed_mlp;
+
+/* Host-only: computes the packed layout of `h_mlp` starting at float offset `base_off`;
+ * returns the number of floats it occupies (negative on error). */
+int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out);
+/* Re-tiles the weights named by `h_mlp` (device pointers) into blob[plan offsets]. */
+int mz_mlp_pack(const mz_mlp *h_mlp, const mz_packed_mlp *h_plan, float *blob, void *stream);
+/* y = MLP(x) for B rows.  x f32 rows of in_features floats, row stride ldx, optional row
+ * gather x_rows i32[B] (row r is read from x + x_rows[r]*ldx; negative -> zeros);
+ * y f32[B][out_features] with row stride ldy.  A MZ_ACT_SOFTMAX layer normalises over its
+ * out_features. */
+int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,
+                   const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream);
+
+/* g: DynamicsNetwork.forward for MLP-only configs, src/neural_networks/neural_network.py:152-188
+ *    next = relu(fc_merge([latent ; action_embedding[action]])), reward = reward_mlp(next).
+ * f: PredictionNetwork.forward, :234-262: value = value_mlp(latent), policy = policy_mlp(latent)
+ *    (policy_mlp ends in a softmax layer). */
+typedef struct mz_dynamics_net {
+    const float *embedding;    /* action_embedding.weight [A][D]   */
+    const float *merge_weight; /* fc_merge.weight [D][2D]          */
+    const float *merge_bias;   /* fc_merge.bias [D]                */
+    mz_mlp reward;             /* reward_mlp, D -> ... -> 1        */
+    int32_t D, A;
+} mz_dynamics_net;
+
+typedef struct mz_prediction_net {
+    mz_mlp value;  /* value_mlp, D -> ... -> 1                      */
+    mz_mlp policy; /* policy_mlp, D -> ... -> A (last act softmax)  */
+    int32_t D, A;
+} mz_prediction_net;
+
+typedef struct mz_packed_nets {
+    int32_t D, A, Dp, _pad;
+    int64_t total_floats;
+    int64_t action_table_off; /* [A][Dp]: fc_merge.weight[:, D:] @ embedding[a] + fc_merge.bias */
+    mz_packed_mlp merge;      /* one linear layer: fc_merge.weight[:, :D], no bias              */
+    mz_packed_mlp reward, value, policy;
+} mz_packed_nets;
+
+/* Host-only layout computation; fills *h_out including total_floats (blob size). */
+int mz_nets_plan(const mz_dynamics_net *h_dyn, const mz_prediction_net *h_pred, mz_packed_nets *h_out);
+/* Fills blob (total_floats floats of device memory) from the networks' device weights. */
+int mz_nets_pack(const mz_dynamics_net *h_dyn, const mz_prediction_net *h_pred,
+                 const mz_packed_nets *h_plan, float *blob, void *stream);
+
+/* Batched g for B rows: latent rows gathered like mz_mlp_forward's x; action i32[B] or NULL
+ * (NULL: action of row r is r % A, the expansion pattern where consecutive groups of A rows
+ * share one latent -- pass x_rows accordingly).  next_latent f32[B][D] row stride ld_next
+ * with optional row scatter next_rows i32[B]; reward f32[B]. */
+int mz_dynamics_forward(const mz_packed_nets *h_plan, const float *blob, const float *latent,
+                        int64_t ld_latent, const int32_t *latent_rows, const int32_t *action,
+                        float *next_latent, int64_t ld_next, const int32_t *next_rows,
+                        float *reward, int32_t B, void *stream);
+
+/* Batched f for B rows.  policy f32[B][A] (softmax_times extra softmax passes applied on
+ * top of the network's own: 0 = network output, 1 = the prior expand_node stores,
+ * src/search/expansion.py:26-27), value f32[B], argmax i32[B] (first maximum of the network
+ * policy, src/search/simulation.py:36).  NULL outputs are skipped, including their head. */
+int mz_prediction_forward(const mz_packed_nets *h_plan, const float *blob, const float *latent,
+                          int64_t ld_latent, const int32_t *latent_rows, int32_t softmax_times,
+                          float *policy, float *value, int32_t *argmax, int32_t B, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Connect Four on the GPU: the environment behind src/environments/connect_four.py:18-72
+ * (PettingZoo connect_four_v3 seen through the reference's adapter).
+ *   pieces  u64[G][2]  bitboards of player_0 / player_1 (bit = column*7 + height)
+ *   to_move i8[G]      0 = player_0 (to_play +1), 1 = player_1 (to_play -1)
+ *   done    i8[G]
+ * ------------------------------------------------------------------------------------ */
+typedef struct mz_c4_state {
+    int32_t G, _pad;
+    unsigned long long *pieces;
+    int8_t *to_move;
+    int8_t *done;
+} mz_c4_state;
+
+/* ConnectFour.reset, connect_four.py:59-66.  mask i8[G] or NULL: reset only games with
+ * mask != 0. */
+int mz_c4_reset(const mz_c4_state *state, const int8_t *mask, void *stream);
+/* ConnectFour.step, connect_four.py:43-51: action i32[G]; reward f32[G] and done i8[G] are
+ * those of the player to move AFTER the step (a winning move reports -1).  A full column or
+ * out-of-range action ends the game (mover -1, opponent 0, player_0's view reported).
+ * Finished games are left unchanged and report reward 0, done 1. */
+int mz_c4_step(const mz_c4_state *state, const int32_t *action, float *reward, int8_t *done,
+               void *stream);
+/* ConnectFour.get_state + get_to_play, connect_four.py:26-30,53-57: obs f32[G][2][6][7]
+ * (plane 0 = player to move, row 0 = top), to_play i8[G] in {+1,-1} (may be NULL). */
+int mz_c4_observe(const mz_c4_state *state, float *obs, int8_t *to_play, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUZERO_HIP_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libmuzero_hip.so (the C ABI declared in include/muzero_hip.h).
+
+The library is built in-tree by `make -C muzero_amd/csrc` (or __graft_entry__.build()).
+There is no CPU fallback: every product path that needs a kernel calls `lib()` and raises
+when the shared object is missing or a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmuzero_hip.so")
+MAX_LAYERS = 8
+
+ACT = {"none": 0, "linear": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "softmax": 4}
+SELECT_ROOT_F32 = 1
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class Pool(C.Structure):
+    _fields_ = [("G", C.c_int32), ("A", C.c_int32), ("cap", C.c_int32), ("D", C.c_int32),
+                ("visit", C.c_void_p), ("value_sum", C.c_void_p), ("prior", C.c_void_p),
+                ("reward", C.c_void_p), ("parent", C.c_void_p), ("first_child", C.c_void_p),
+                ("to_play", C.c_void_p), ("n_nodes", C.c_void_p), ("latent", C.c_void_p)]
+
+
+class Dense(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("in_features", C.c_int32),
+                ("out_features", C.c_int32), ("activation", C.c_int32), ("ldw", C.c_int32)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("layer", Dense * MAX_LAYERS)]
+
+
+class PackedLayer(C.Structure):
+    _fields_ = [("K", C.c_int32), ("N", C.c_int32), ("Kp", C.c_int32), ("Np", C.c_int32),
+                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class PackedMlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("in_features", C.c_int32), ("out_features", C.c_int32),
+                ("max_width", C.c_int32), ("layer", PackedLayer * MAX_LAYERS)]
+
+
+class DynamicsNet(C.Structure):
+    _fields_ = [("embedding", C.c_void_p), ("merge_weight", C.c_void_p), ("merge_bias", C.c_void_p),
+                ("reward", Mlp), ("D", C.c_int32), ("A", C.c_int32)]
+
+
+class PredictionNet(C.Structure):
+    _fields_ = [("value", Mlp), ("policy", Mlp), ("D", C.c_int32), ("A", C.c_int32)]
+
+
+class C4State(C.Structure):
+    _fields_ = [("G", C.c_int32), ("_pad", C.c_int32), ("pieces", C.c_void_p), ("to_move", C.c_void_p),
+                ("done", C.c_void_p)]
+
+
+class PackedNets(C.Structure):
+    _fields_ = [("D", C.c_int32), ("A", C.c_int32), ("Dp", C.c_int32), ("_pad", C.c_int32),
+                ("total_floats", C.c_int64), ("action_table_off", C.c_int64),
+                ("merge", PackedMlp), ("reward", PackedMlp), ("value", PackedMlp), ("policy", PackedMlp)]
+
+
+_LIB = None
+
+_P = C.c_void_p
+_SIGS = {
+    "mz_last_error": (C.c_char_p, []),
+    "mz_abi_version": (C.c_int, []),
+    "mz_puct_tables": (C.c_int, [_P, _P, C.c_int32]),
+    "mz_tree_init": (C.c_int, [C.POINTER(Pool), _P, _P, _P]),
+    "mz_tree_select": (C.c_int, [C.POINTER(Pool), _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "mz_tree_expand_commit": (C.c_int, [C.POINTER(Pool), _P, _P, _P, _P, _P, _P, _P]),
+    "mz_tree_root_noise": (C.c_int, [C.POINTER(Pool), _P, C.c_double, _P]),
+    "mz_tree_backup": (C.c_int, [C.POINTER(Pool), _P, _P, _P, C.c_int32, C.c_double, _P]),
+    "mz_tree_result": (C.c_int, [C.POINTER(Pool), _P, _P, _P, _P, _P]),
+    "mz_tree_gather_latent": (C.c_int, [C.POINTER(Pool), _P, _P, _P]),
+    "mz_mlp_plan": (C.c_int64, [C.POINTER(Mlp), C.c_int64, C.POINTER(PackedMlp)]),
+    "mz_mlp_pack": (C.c_int, [C.POINTER(Mlp), C.POINTER(PackedMlp), _P, _P]),
+    "mz_mlp_forward": (C.c_int, [C.POINTER(PackedMlp), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P]),
+    "mz_nets_plan": (C.c_int, [C.POINTER(DynamicsNet), C.POINTER(PredictionNet), C.POINTER(PackedNets)]),
+    "mz_nets_pack": (C.c_int, [C.POINTER(DynamicsNet), C.POINTER(PredictionNet), C.POINTER(PackedNets), _P, _P]),
+    "mz_dynamics_forward": (C.c_int, [C.POINTER(PackedNets), _P, _P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P,
+                                      C.c_int32, _P]),
+    "mz_prediction_forward": (C.c_int, [C.POINTER(PackedNets), _P, _P, C.c_int64, _P, C.c_int32, _P, _P, _P,
+                                        C.c_int32, _P]),
+    "mz_c4_reset": (C.c_int, [C.POINTER(C4State), _P, _P]),
+    "mz_c4_step": (C.c_int, [C.POINTER(C4State), _P, _P, _P, _P]),
+    "mz_c4_observe": (C.c_int, [C.POINTER(C4State), _P, _P, _P]),
+}
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGS)
+
+
+def register(name: str, restype, argtypes) -> None:
+    """Adds a symbol signature (used by sibling modules that bind further entry points)."""
+    _SIGS[name] = (restype, argtypes)
+    if _LIB is not None:
+        fn = getattr(_LIB, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: build it with `make -C muzero_amd/csrc` "
+                           "(there is no CPU fallback for the search kernels)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipError(f"{what} failed ({rc}): {lib().mz_last_error().decode(errors='replace')}")
+
+
+def ptr(t) -> int | None:
+    """Device (or host) address of a torch tensor / numpy array; None passes NULL."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,372 @@
+// Batched fp32 MFMA forward passes of the MLP-only h/g/f networks (gfx950) and the
+// weight re-tiling they read.  Device-side building blocks: mz_mlp_device.h.
+#include <algorithm>
+#include <cstring>
+
+#include "mz_common.h"
+#include "mz_mlp_device.h"
+
+using namespace mzd;
+
+namespace {
+
+// ------------------------------------------------------------------ weight packing
+__global__ void k_pack_layer(const float *__restrict__ W, int ldw, const float *__restrict__ bias, int K, int N,
+                             int Kp, int Np, float *__restrict__ w_out, float *__restrict__ b_out) {
+    const long long total = (long long)Np * Kp;
+    const int KT = Kp >> 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3);
+        const int lane = (int)((i >> 2) & 63);
+        const long long tile = i >> 8;
+        const int kt = (int)(tile % KT), nt = (int)(tile / KT);
+        const int n = nt * 16 + (lane & 15);
+        const int k = kt * 16 + 4 * (lane >> 4) + j;
+        w_out[i] = (n < N && k < K) ? W[(size_t)n * ldw + k] : 0.0f;
+    }
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Np; n += gridDim.x * blockDim.x)
+        b_out[n] = (bias != nullptr && n < N) ? bias[n] : 0.0f;
+}
+
+// table[a][n] = merge_bias[n] + sum_k merge_weight[n][D + k] * embedding[a][k]
+__global__ void k_action_table(const float *__restrict__ emb, const float *__restrict__ Wm,
+                               const float *__restrict__ bm, int D, int Dp, int A, float *__restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * Dp) return;
+    const int a = i / Dp, n = i % Dp;
+    float s = 0.0f;
+    if (n < D) {
+        s = bm ? bm[n] : 0.0f;
+        for (int k = 0; k < D; ++k) s = fmaf(Wm[(size_t)n * 2 * D + D + k], emb[(size_t)a * D + k], s);
+    }
+    table[i] = s;
+}
+
+// ------------------------------------------------------------------ forward kernels
+template <int MT>
+__global__ void __launch_bounds__(kThreads)
+k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__restrict__ x, long long ldx,
+              const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int TM = 16 * MT;
+    const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
+    float *X = smem, *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
+    const int row0 = blockIdx.x * TM;
+    const int rows = min(TM, B - row0);
+    load_rows(X, ld_in, TM, rows, M.in_features, [&](int r) -> const float * {
+        long long src = x_rows ? (long long)x_rows[row0 + r] : (long long)(row0 + r);
+        return src < 0 ? nullptr : x + src * ldx;
+    });
+    int ld_out;
+    const float *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    const int N = M.out_features;
+    for (int i = threadIdx.x; i < rows * N; i += kThreads) {
+        const int r = i / N, c = i - r * N;
+        y[(long long)(row0 + r) * ldy + c] = out[r * ld_out + c];
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(kThreads)
+k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__restrict__ latent, long long ld_latent,
+           const int32_t *__restrict__ latent_rows, const int32_t *__restrict__ action,
+           float *__restrict__ next_latent, long long ld_next, const int32_t *__restrict__ next_rows,
+           float *__restrict__ reward, int B) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int TM = 16 * MT;
+    const int ld_d = lds_stride(P.D), ld_w = lds_stride(P.reward.max_width);
+    float *X = smem, *C = X + TM * ld_d, *bufA = C + TM * ld_d, *bufB = bufA + TM * ld_w;
+    int *sel = reinterpret_cast<int *>(bufB + TM * ld_w);
+    const int row0 = blockIdx.x * TM;
+    const int rows = min(TM, B - row0);
+    if ((int)threadIdx.x < TM) {
+        const int r = row0 + threadIdx.x;
+        int a = 0;
+        if ((int)threadIdx.x < rows) a = action ? action[r] : (r % P.A);
+        sel[threadIdx.x] = min(max(a, 0), P.A - 1);
+    }
+    load_rows(X, ld_d, TM, rows, P.D, [&](int r) -> const float * {
+        long long src = latent_rows ? (long long)latent_rows[row0 + r] : (long long)(row0 + r);
+        return src < 0 ? nullptr : latent + src * ld_latent;
+    });
+    // next = relu(W[:, :D] x + (W[:, D:] e_a + b))
+    dense_tile<MT>(X, ld_d, blob, P.merge.layer[0], C, ld_d, blob + P.action_table_off, P.Dp, sel);
+    if (next_latent) {
+        for (int i = threadIdx.x; i < rows * P.D; i += kThreads) {
+            const int r = i / P.D, c = i - r * P.D;
+            long long dst = next_rows ? (long long)next_rows[row0 + r] : (long long)(row0 + r);
+            if (dst >= 0) next_latent[dst * ld_next + c] = C[r * ld_d + c];
+        }
+    }
+    if (reward) {
+        int ld_out;
+        const float *out = mlp_tile<MT>(P.reward, blob, C, ld_d, bufA, bufB, &ld_out);
+        if ((int)threadIdx.x < rows) reward[row0 + threadIdx.x] = out[threadIdx.x * ld_out];
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(kThreads)
+k_prediction(mz_packed_nets P, const float *__restrict__ blob, const float *__restrict__ latent, long long ld_latent,
+             const int32_t *__restrict__ latent_rows, int softmax_times, float *__restrict__ policy,
+             float *__restrict__ value, int32_t *__restrict__ argmax, int B) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int TM = 16 * MT;
+    const int ld_d = lds_stride(P.D);
+    const int ld_w = lds_stride(max(P.value.max_width, P.policy.max_width));
+    float *X = smem, *bufA = X + TM * ld_d, *bufB = bufA + TM * ld_w;
+    const int row0 = blockIdx.x * TM;
+    const int rows = min(TM, B - row0);
+    load_rows(X, ld_d, TM, rows, P.D, [&](int r) -> const float * {
+        long long src = latent_rows ? (long long)latent_rows[row0 + r] : (long long)(row0 + r);
+        return src < 0 ? nullptr : latent + src * ld_latent;
+    });
+    int ld_out;
+    if (policy || argmax) {
+        float *out = mlp_tile<MT>(P.policy, blob, X, ld_d, bufA, bufB, &ld_out);
+        if (argmax && (int)threadIdx.x < rows) {
+            const float *p = out + threadIdx.x * ld_out;
+            int best = 0;
+            for (int i = 1; i < P.A; ++i)
+                if (p[i] > p[best]) best = i;
+            argmax[row0 + threadIdx.x] = best;
+        }
+        if (policy) {
+            if (softmax_times > 0) {
+                __syncthreads();
+                softmax_rows(out, ld_out, TM, P.A, softmax_times);
+            }
+            for (int i = threadIdx.x; i < rows * P.A; i += kThreads) {
+                const int r = i / P.A, c = i - r * P.A;
+                policy[(long long)(row0 + r) * P.A + c] = out[r * ld_out + c];
+            }
+        }
+        __syncthreads();
+    }
+    if (value) {
+        const float *out = mlp_tile<MT>(P.value, blob, X, ld_d, bufA, bufB, &ld_out);
+        if ((int)threadIdx.x < rows) value[row0 + threadIdx.x] = out[threadIdx.x * ld_out];
+    }
+}
+
+// ------------------------------------------------------------------ host helpers
+int validate_mlp(const mz_mlp *m, const char *what) {
+    if (!m || m->n_layers <= 0 || m->n_layers > MZ_MAX_LAYERS)
+        return mz::fail(MZ_ERR_ARG, "%s: n_layers must be 1..%d", what, MZ_MAX_LAYERS);
+    for (int i = 0; i < m->n_layers; ++i) {
+        const mz_dense &d = m->layer[i];
+        if (d.in_features <= 0 || d.out_features <= 0 || !d.weight)
+            return mz::fail(MZ_ERR_ARG, "%s: layer %d has bad dims or NULL weight", what, i);
+        if (i > 0 && d.in_features != m->layer[i - 1].out_features)
+            return mz::fail(MZ_ERR_ARG, "%s: layer %d in_features %d != previous out_features %d", what, i,
+                            d.in_features, m->layer[i - 1].out_features);
+        if (d.activation < MZ_ACT_NONE || d.activation > MZ_ACT_SOFTMAX)
+            return mz::fail(MZ_ERR_ARG, "%s: layer %d has unknown activation %d", what, i, d.activation);
+        if (d.out_features > 4096 || d.in_features > 4096)
+            return mz::fail(MZ_ERR_ARG, "%s: layer %d wider than 4096 does not fit the LDS-resident tile", what, i);
+    }
+    return MZ_OK;
+}
+
+int pack_layer(const mz_dense &d, const mz_packed_layer &L, float *blob, hipStream_t st) {
+    const long long total = (long long)L.Np * L.Kp;
+    const int nb = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_pack_layer, dim3(nb), dim3(256), 0, st, d.weight, d.ldw > 0 ? d.ldw : d.in_features, d.bias,
+                       L.K, L.N, L.Kp, L.Np, blob + L.w_off, blob + L.b_off);
+    return mz::check_launch("k_pack_layer");
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+// Dynamic LDS above 64 KiB has to be enabled per kernel.
+template <typename K>
+int allow_lds(K kernel, size_t bytes, const char *what) {
+    if (bytes <= 64 * 1024) return MZ_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "%s: cannot enable %zu bytes of LDS: %s", what, bytes, hipGetErrorString(e));
+    return MZ_OK;
+}
+
+template <typename Launch1, typename Launch2>
+int launch_by_rows(int B, size_t lds_per_row_floats, size_t extra_bytes, Launch1 &&l1, Launch2 &&l2) {
+    // 32-row tiles halve the weight traffic per row; 16-row tiles keep all 256 CUs busy when
+    // the batch is small.
+    int mt = (B >= 16 * 512) ? 2 : 1;
+    if ((size_t)mt * 16 * lds_per_row_floats * sizeof(float) + extra_bytes > kMaxLds) mt = 1;
+    size_t lds = (size_t)mt * 16 * lds_per_row_floats * sizeof(float) + extra_bytes;
+    if (lds > kMaxLds) return mz::fail(MZ_ERR_ARG, "network too wide: needs %zu bytes of LDS per tile", lds);
+    return mt == 2 ? l2(lds) : l1(lds);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out) {
+    if (validate_mlp(h_mlp, "mz_mlp_plan") != MZ_OK) return MZ_ERR_ARG;
+    if (!h_out || base_off < 0 || (base_off & 3))
+        return mz::fail(MZ_ERR_ARG, "mz_mlp_plan: h_out is NULL or base_off is not a non-negative multiple of 4");
+    std::memset(h_out, 0, sizeof(*h_out));
+    int64_t off = base_off;
+    h_out->n_layers = h_mlp->n_layers;
+    h_out->in_features = h_mlp->layer[0].in_features;
+    h_out->out_features = h_mlp->layer[h_mlp->n_layers - 1].out_features;
+    for (int i = 0; i < h_mlp->n_layers; ++i) {
+        const mz_dense &d = h_mlp->layer[i];
+        mz_packed_layer &L = h_out->layer[i];
+        L.K = d.in_features;
+        L.N = d.out_features;
+        L.Kp = ceil16(L.K);
+        L.Np = ceil16(L.N);
+        L.act = d.activation;
+        L.w_off = off;
+        off += (int64_t)L.Kp * L.Np;
+        L.b_off = off;
+        off += L.Np;
+        h_out->max_width = std::max(h_out->max_width, L.N);
+    }
+    return off - base_off;
+}
+
+int mz_mlp_pack(const mz_mlp *h_mlp, const mz_packed_mlp *h_plan, float *blob, void *stream) {
+    MZ_TRY(validate_mlp(h_mlp, "mz_mlp_pack"));
+    if (!h_plan || !blob || h_plan->n_layers != h_mlp->n_layers)
+        return mz::fail(MZ_ERR_ARG, "mz_mlp_pack: plan does not match the network");
+    for (int i = 0; i < h_mlp->n_layers; ++i) MZ_TRY(pack_layer(h_mlp->layer[i], h_plan->layer[i], blob, (hipStream_t)stream));
+    return MZ_OK;
+}
+
+int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,
+                   const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream) {
+    if (!h_plan || !blob || !x || !y || B < 0 || ldx < h_plan->in_features || ldy < h_plan->out_features)
+        return mz::fail(MZ_ERR_ARG, "mz_mlp_forward: NULL argument, negative B or row stride below the row width");
+    if (B == 0) return MZ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    size_t per_row = (size_t)lds_stride(h_plan->in_features) + 2 * (size_t)lds_stride(h_plan->max_width);
+    return launch_by_rows(
+        B, per_row, 0,
+        [&](size_t lds) {
+            MZ_TRY(allow_lds(k_mlp_forward<1>, lds, "k_mlp_forward"));
+            hipLaunchKernelGGL(k_mlp_forward<1>, dim3((B + 15) / 16), dim3(kThreads), lds, st, *h_plan, blob, x,
+                               (long long)ldx, x_rows, y, (long long)ldy, B);
+            return mz::check_launch("k_mlp_forward<1>");
+        },
+        [&](size_t lds) {
+            MZ_TRY(allow_lds(k_mlp_forward<2>, lds, "k_mlp_forward"));
+            hipLaunchKernelGGL(k_mlp_forward<2>, dim3((B + 31) / 32), dim3(kThreads), lds, st, *h_plan, blob, x,
+                               (long long)ldx, x_rows, y, (long long)ldy, B);
+            return mz::check_launch("k_mlp_forward<2>");
+        });
+}
+
+int mz_nets_plan(const mz_dynamics_net *h_dyn, const mz_prediction_net *h_pred, mz_packed_nets *h_out) {
+    if (!h_dyn || !h_pred || !h_out) return mz::fail(MZ_ERR_ARG, "mz_nets_plan: NULL argument");
+    if (h_dyn->D <= 0 || h_dyn->A <= 0 || h_dyn->A > 64 || h_pred->D != h_dyn->D || h_pred->A != h_dyn->A)
+        return mz::fail(MZ_ERR_ARG, "mz_nets_plan: dynamics (D=%d, A=%d) and prediction (D=%d, A=%d) dims disagree",
+                        h_dyn->D, h_dyn->A, h_pred->D, h_pred->A);
+    MZ_TRY(validate_mlp(&h_dyn->reward, "reward_mlp"));
+    MZ_TRY(validate_mlp(&h_pred->value, "value_mlp"));
+    MZ_TRY(validate_mlp(&h_pred->policy, "policy_mlp"));
+    const int D = h_dyn->D, A = h_dyn->A;
+    if (h_dyn->reward.layer[0].in_features != D || h_pred->value.layer[0].in_features != D ||
+        h_pred->policy.layer[0].in_features != D)
+        return mz::fail(MZ_ERR_ARG, "mz_nets_plan: a head's input width differs from D=%d", D);
+    if (h_dyn->reward.layer[h_dyn->reward.n_layers - 1].out_features != 1 ||
+        h_pred->value.layer[h_pred->value.n_layers - 1].out_features != 1 ||
+        h_pred->policy.layer[h_pred->policy.n_layers - 1].out_features != A)
+        return mz::fail(MZ_ERR_ARG, "mz_nets_plan: heads must end in 1 (reward, value) and A (policy) outputs");
+    if (!h_dyn->embedding || !h_dyn->merge_weight) return mz::fail(MZ_ERR_ARG, "mz_nets_plan: NULL dynamics weight");
+    std::memset(h_out, 0, sizeof(*h_out));
+    h_out->D = D;
+    h_out->A = A;
+    h_out->Dp = ceil16(D);
+    mz_mlp merge;
+    std::memset(&merge, 0, sizeof(merge));
+    merge.n_layers = 1;
+    merge.layer[0] = mz_dense{h_dyn->merge_weight, nullptr, D, D, MZ_ACT_RELU, 2 * D};
+    int64_t off = 0, n;
+    if ((n = mz_mlp_plan(&merge, off, &h_out->merge)) < 0) return (int)n;
+    off += n;
+    h_out->action_table_off = off;
+    off += (int64_t)A * h_out->Dp;
+    if ((n = mz_mlp_plan(&h_dyn->reward, off, &h_out->reward)) < 0) return (int)n;
+    off += n;
+    if ((n = mz_mlp_plan(&h_pred->value, off, &h_out->value)) < 0) return (int)n;
+    off += n;
+    if ((n = mz_mlp_plan(&h_pred->policy, off, &h_out->policy)) < 0) return (int)n;
+    off += n;
+    h_out->total_floats = off;
+    return MZ_OK;
+}
+
+int mz_nets_pack(const mz_dynamics_net *h_dyn, const mz_prediction_net *h_pred, const mz_packed_nets *h_plan,
+                 float *blob, void *stream) {
+    if (!h_dyn || !h_pred || !h_plan || !blob) return mz::fail(MZ_ERR_ARG, "mz_nets_pack: NULL argument");
+    if (h_plan->D != h_dyn->D || h_plan->A != h_dyn->A) return mz::fail(MZ_ERR_ARG, "mz_nets_pack: plan/network mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = h_dyn->D, A = h_dyn->A;
+    mz_dense merge{h_dyn->merge_weight, nullptr, D, D, MZ_ACT_RELU, 2 * D};
+    MZ_TRY(pack_layer(merge, h_plan->merge.layer[0], blob, st));
+    hipLaunchKernelGGL(k_action_table, dim3((A * h_plan->Dp + 255) / 256), dim3(256), 0, st, h_dyn->embedding,
+                       h_dyn->merge_weight, h_dyn->merge_bias, D, h_plan->Dp, A, blob + h_plan->action_table_off);
+    MZ_TRY(mz::check_launch("k_action_table"));
+    MZ_TRY(mz_mlp_pack(&h_dyn->reward, &h_plan->reward, blob, stream));
+    MZ_TRY(mz_mlp_pack(&h_pred->value, &h_plan->value, blob, stream));
+    MZ_TRY(mz_mlp_pack(&h_pred->policy, &h_plan->policy, blob, stream));
+    return MZ_OK;
+}
+
+int mz_dynamics_forward(const mz_packed_nets *h_plan, const float *blob, const float *latent, int64_t ld_latent,
+                        const int32_t *latent_rows, const int32_t *action, float *next_latent, int64_t ld_next,
+                        const int32_t *next_rows, float *reward, int32_t B, void *stream) {
+    if (!h_plan || !blob || !latent || B < 0 || ld_latent < h_plan->D || (next_latent && ld_next < h_plan->D))
+        return mz::fail(MZ_ERR_ARG, "mz_dynamics_forward: NULL argument, negative B or row stride below D");
+    if (B == 0) return MZ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    size_t per_row = 2 * (size_t)lds_stride(h_plan->D) + 2 * (size_t)lds_stride(h_plan->reward.max_width);
+    return launch_by_rows(
+        B, per_row, 32 * sizeof(int),
+        [&](size_t lds) {
+            MZ_TRY(allow_lds(k_dynamics<1>, lds, "k_dynamics"));
+            hipLaunchKernelGGL(k_dynamics<1>, dim3((B + 15) / 16), dim3(kThreads), lds, st, *h_plan, blob, latent,
+                               (long long)ld_latent, latent_rows, action, next_latent, (long long)ld_next, next_rows,
+                               reward, B);
+            return mz::check_launch("k_dynamics<1>");
+        },
+        [&](size_t lds) {
+            MZ_TRY(allow_lds(k_dynamics<2>, lds, "k_dynamics"));
+            hipLaunchKernelGGL(k_dynamics<2>, dim3((B + 31) / 32), dim3(kThreads), lds, st, *h_plan, blob, latent,
+                               (long long)ld_latent, latent_rows, action, next_latent, (long long)ld_next, next_rows,
+                               reward, B);
+            return mz::check_launch("k_dynamics<2>");
+        });
+}
+
+int mz_prediction_forward(const mz_packed_nets *h_plan, const float *blob, const float *latent, int64_t ld_latent,
+                          const int32_t *latent_rows, int32_t softmax_times, float *policy, float *value,
+                          int32_t *argmax, int32_t B, void *stream) {
+    if (!h_plan || !blob || !latent || B < 0 || ld_latent < h_plan->D || softmax_times < 0)
+        return mz::fail(MZ_ERR_ARG, "mz_prediction_forward: NULL argument, negative B or row stride below D");
+    if (B == 0 || (!policy && !value && !argmax)) return MZ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    size_t per_row = (size_t)lds_stride(h_plan->D) +
+                     2 * (size_t)lds_stride(std::max(h_plan->value.max_width, h_plan->policy.max_width));
+    return launch_by_rows(
+        B, per_row, 0,
+        [&](size_t lds) {
+            MZ_TRY(allow_lds(k_prediction<1>, lds, "k_prediction"));
+            hipLaunchKernelGGL(k_prediction<1>, dim3((B + 15) / 16), dim3(kThreads), lds, st, *h_plan, blob, latent,
+                               (long long)ld_latent, latent_rows, softmax_times, policy, value, argmax, B);
+            return mz::check_launch("k_prediction<1>");
+        },
+        [&](size_t lds) {
+            MZ_TRY(allow_lds(k_prediction<2>, lds, "k_prediction"));
+            hipLaunchKernelGGL(k_prediction<2>, dim3((B + 31) / 32), dim3(kThreads), lds, st, *h_plan, blob, latent,
+                               (long long)ld_latent, latent_rows, softmax_times, policy, value, argmax, B);
+            return mz::check_launch("k_prediction<2>");
+        });
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// Tree kernels for gfx950: G independent MCTS trees held as a flat SoA node pool in HBM.
+//
+// Work decomposition: each tree is served by a group of LPT = next_pow2(A) adjacent lanes
+// of one wavefront (LPT = 64 -> one wavefront per tree); lane a of the group owns child a
+// of the node being scored.  Group-wide maxima use DPP lane exchanges (quad_perm,
+// row_half_mirror, row_mirror) and the first-maximum tie-break is a wave ballot + ffs.
+// The PUCT sqrt/log tables are staged in LDS (per-lane random index, so LDS not L1).
+//
+// This file is compiled with -ffp-contract=off: every score and return is a chain of
+// individually rounded IEEE operations in the reference's order and precision, never an
+// FMA, so that argmax decisions and float64 value sums are bit-identical to CPython's.
+#include <algorithm>
+#include <type_traits>
+
+#include "mz_common.h"
+
+namespace {
+
+constexpr int kBlock = 64;  // one wavefront per block: spreads G*LPT/64 blocks over all CUs
+
+// ---------------------------------------------------------------- lane exchange helpers
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double max_nan_last(double a, double b) { return b > a ? b : a; }
+
+// Maximum over the LPT lanes of a group; every lane of the group receives it.
+template <int LPT>
+__device__ __forceinline__ double group_max(double v) {
+    v = max_nan_last(v, dpp_f64<0xB1>(v));                          // quad_perm [1,0,3,2]
+    if constexpr (LPT > 2) v = max_nan_last(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    if constexpr (LPT > 4) v = max_nan_last(v, dpp_f64<0x141>(v));  // row_half_mirror
+    if constexpr (LPT > 8) v = max_nan_last(v, dpp_f64<0x140>(v));  // row_mirror
+    if constexpr (LPT > 16) v = max_nan_last(v, __shfl_xor(v, 16, 64));
+    if constexpr (LPT > 32) v = max_nan_last(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ void k_init(mz_pool p, const int8_t *__restrict__ root_to_play) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.G) return;
+    size_t o = (size_t)g * p.cap;
+    p.visit[o] = 0;
+    p.value_sum[o] = 0.0;
+    p.prior[o] = 0.0;
+    p.reward[o] = 0.0f;
+    p.parent[o] = -1;
+    p.first_child[o] = -1;
+    p.to_play[o] = root_to_play[g];
+    p.n_nodes[g] = 1;
+}
+
+// dst row (g, base_g + a) of the latent pool <- src row (g, a); base_g = n_nodes[g] when
+// `use_n_nodes`, else `const_base`.
+__global__ void k_scatter_latent(mz_pool p, const float *__restrict__ src, int rows_per_tree, int use_n_nodes,
+                                 int const_base) {
+    const int D = p.D;
+    long long total = (long long)p.G * rows_per_tree * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int d = (int)(i % D);
+        long long r = i / D;
+        int a = (int)(r % rows_per_tree);
+        int g = (int)(r / rows_per_tree);
+        int base = use_n_nodes ? p.n_nodes[g] : const_base;
+        if (base + rows_per_tree > p.cap) continue;
+        p.latent[((size_t)g * p.cap + base + a) * D + d] = src[i];
+    }
+}
+
+__global__ void k_gather_latent(mz_pool p, const int32_t *__restrict__ idx, float *__restrict__ out) {
+    const int D = p.D;
+    long long total = (long long)p.G * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int d = (int)(i % D);
+        int g = (int)(i / D);
+        int n = idx[g];
+        out[i] = (n >= 0 && n < p.cap) ? p.latent[((size_t)g * p.cap + n) * D + d] : 0.0f;
+    }
+}
+
+// src/search/selection.py:43-59.  flags bit 0: children of the root carry float32 priors
+// and are scored in float32 (the state MCTS.run leaves them in, src/search/mcts.py:94).
+template <int LPT>
+__global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const double *__restrict__ log_tab,
+                         int tab_len, int flags, int32_t *__restrict__ out_leaf, int32_t *__restrict__ out_depth) {
+    extern __shared__ double s_tab[];  // [tab_len] sqrt, then [tab_len] log term
+    for (int i = threadIdx.x; i < tab_len; i += blockDim.x) {
+        s_tab[i] = sqrt_tab[i];
+        s_tab[tab_len + i] = log_tab[i];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t / LPT;
+    const int a = t % LPT;
+    if (g >= p.G) return;
+    const int lane = threadIdx.x & 63;
+    const int group_lane0 = lane - a;
+    const size_t o = (size_t)g * p.cap;
+    const bool child_lane = a < p.A;
+    const bool root_f32 = flags & 1;
+
+    int node = 0, depth = 0;
+    int fc = p.first_child[o];
+    int n_parent = p.visit[o];
+    bool failed = false;
+    while (fc >= 0 && depth < p.cap) {
+        int n = 0, cfc = -1;
+        double w = 0.0, pr = 0.0;
+        if (child_lane) {
+            size_t c = o + fc + a;
+            n = p.visit[c];
+            w = p.value_sum[c];
+            pr = p.prior[c];
+            cfc = p.first_child[c];
+        }
+        const bool bad = n_parent >= tab_len || n_parent < 0 || n >= tab_len || n < 0;
+        if ((__ballot(bad) >> group_lane0) & ((LPT == 64) ? ~0ull : ((1ull << LPT) - 1))) {
+            failed = true;  // a visit count outside the lookup tables: report leaf = -1
+            break;
+        }
+        double score = -__builtin_inf();
+        if (child_lane) {
+            double pb = s_tab[n_parent] / (double)(n + 1);
+            pb = pb * s_tab[tab_len + n];
+            if (node == 0 && root_f32) {
+                float ps = (float)pb * (float)pr;
+                float sc = ps;
+                if (n > 0) sc = (float)(w / (double)n) + ps;
+                score = (double)sc;
+            } else {
+                double ps = pb * pr;
+                score = (n > 0) ? (w / (double)n + ps) : (0.0 + ps);
+            }
+        }
+        const double best = group_max<LPT>(score);
+        unsigned long long hit = __ballot(child_lane && score == best);
+        hit = (hit >> group_lane0) & ((LPT == 64) ? ~0ull : ((1ull << LPT) - 1));
+        // all-NaN scores leave no hit: fall back to child 0 like max() keeping its first item
+        const int best_a = hit ? (__ffsll((long long)hit) - 1) : 0;
+        node = fc + best_a;
+        n_parent = __shfl(n, group_lane0 + best_a, 64);
+        fc = __shfl(cfc, group_lane0 + best_a, 64);
+        ++depth;
+    }
+    if (a == 0) {
+        out_leaf[g] = failed ? -1 : node;
+        if (out_depth) out_depth[g] = depth;
+    }
+}
+
+// src/search/expansion.py:30-35 + src/search/nodes.py:24-30.
+template <int LPT>
+__global__ void k_expand_commit(mz_pool p, const int32_t *__restrict__ leaf, const float *__restrict__ prior,
+                                const float *__restrict__ reward, const int32_t *__restrict__ rand_child,
+                                int32_t *__restrict__ out_child) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t / LPT;
+    const int a = t % LPT;
+    if (g >= p.G) return;
+    const size_t o = (size_t)g * p.cap;
+    const int base = p.n_nodes[g];
+    const int lf = leaf[g];
+    const bool ok = lf >= 0 && lf < base && base + p.A <= p.cap && p.first_child[o + lf] < 0;
+    if (ok && a < p.A) {
+        size_t c = o + base + a;
+        p.visit[c] = 0;
+        p.value_sum[c] = 0.0;
+        p.prior[c] = (double)prior[(size_t)g * p.A + a];
+        p.reward[c] = reward[(size_t)g * p.A + a];
+        p.parent[c] = lf;
+        p.first_child[c] = -1;
+        p.to_play[c] = (int8_t)(-p.to_play[o + lf]);
+    }
+    // every lane of the group has read n_nodes / first_child before lane 0 rewrites them
+    __builtin_amdgcn_wave_barrier();
+    if (a == 0) {
+        if (ok) {
+            p.first_child[o + lf] = base;
+            p.n_nodes[g] = base + p.A;
+            int rc = rand_child[g];
+            out_child[g] = (rc >= 0 && rc < p.A) ? base + rc : -1;
+        } else {
+            out_child[g] = -1;
+        }
+    }
+}
+
+// src/search/mcts.py:91-94, all in float32 as the reference's tensor arithmetic does.
+__global__ void k_root_noise(mz_pool p, const float *__restrict__ eta, double noise_frac) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int g = t / p.A, a = t % p.A;
+    if (g >= p.G) return;
+    size_t o = (size_t)g * p.cap;
+    int fc = p.first_child[o];
+    if (fc < 0) return;
+    double pr = p.prior[o + fc + a];
+    float keep = (float)((1.0 - noise_frac) * pr);
+    float mix = (float)noise_frac * eta[(size_t)g * p.A + a];
+    float add = keep + mix;
+    float out = (float)pr + add;
+    p.prior[o + fc + a] = (double)out;
+}
+
+// src/search/backpropagation.py:9-18.  One lane per tree: the path is a pointer chase of
+// depth+2 nodes; trees are independent so the wave's 64 chases overlap.
+__global__ void k_backup(mz_pool p, const int32_t *__restrict__ child, const int32_t *__restrict__ leaf,
+                         const float *__restrict__ rollout, int n_rollout, double discount) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.G) return;
+    int node = child[g];
+    int lf = leaf[g];
+    if (node < 0 || lf < 0) return;
+    size_t o = (size_t)g * p.cap;
+    double ret = 0.0;
+    for (int i = n_rollout - 1; i >= 0; --i) {
+        double m = discount * ret;
+        ret = (double)rollout[(size_t)g * n_rollout + i] + m;
+    }
+    const int8_t leaf_tp = p.to_play[o + lf];
+    for (int steps = 0; node >= 0 && steps < p.cap; ++steps) {
+        size_t c = o + node;
+        p.visit[c] += 1;
+        double add = (p.to_play[c] == leaf_tp) ? ret : -ret;
+        p.value_sum[c] = p.value_sum[c] + add;
+        node = p.parent[c];
+    }
+}
+
+// src/search/mcts.py:71-72,97-103.
+__global__ void k_result(mz_pool p, double *__restrict__ policy, float *__restrict__ policy32,
+                         double *__restrict__ value, int32_t *__restrict__ visits) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.G) return;
+    size_t o = (size_t)g * p.cap;
+    int fc = p.first_child[o];
+    if (value) value[g] = p.value_sum[o] / (double)p.visit[o];
+    if (fc < 0) return;
+    double s = 0.0;
+    for (int a = 0; a < p.A; ++a) s = s + exp(p.value_sum[o + fc + a]);
+    for (int a = 0; a < p.A; ++a) {
+        double e = exp(p.value_sum[o + fc + a]) / s;
+        if (policy) policy[(size_t)g * p.A + a] = e;
+        if (policy32) policy32[(size_t)g * p.A + a] = (float)e;
+        if (visits) visits[(size_t)g * p.A + a] = p.visit[o + fc + a];
+    }
+}
+
+template <typename F>
+int dispatch_lpt(int A, F &&f) {
+    switch (mz::lanes_per_tree(A)) {
+        case 2: return f(std::integral_constant<int, 2>{});
+        case 4: return f(std::integral_constant<int, 4>{});
+        case 8: return f(std::integral_constant<int, 8>{});
+        case 16: return f(std::integral_constant<int, 16>{});
+        case 32: return f(std::integral_constant<int, 32>{});
+        default: return f(std::integral_constant<int, 64>{});
+    }
+}
+
+inline int blocks_for(long long threads, int block) { return (int)((threads + block - 1) / block); }
+
+}  // namespace
+
+extern "C" {
+
+int mz_puct_tables(double *h_sqrt_tab, double *h_log_tab, int32_t len) {
+    if (!h_sqrt_tab || !h_log_tab || len <= 0) return mz::fail(MZ_ERR_ARG, "mz_puct_tables: bad arguments");
+    for (int n = 0; n < len; ++n) {
+        h_sqrt_tab[n] = sqrt((double)n);
+        h_log_tab[n] = log(((double)n + 19652.0 + 1.0) / 19652.0) + 1.25;
+    }
+    return MZ_OK;
+}
+
+int mz_tree_init(const mz_pool *pool, const int8_t *root_to_play, const float *root_latent, void *stream) {
+    MZ_TRY(mz::check_pool(pool, root_latent != nullptr));
+    if (!root_to_play) return mz::fail(MZ_ERR_ARG, "mz_tree_init: root_to_play is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_init, dim3(blocks_for(pool->G, kBlock)), dim3(kBlock), 0, st, *pool, root_to_play);
+    MZ_TRY(mz::check_launch("k_init"));
+    if (root_latent) {
+        long long total = (long long)pool->G * pool->D;
+        int nb = (int)std::min<long long>(blocks_for(total, 256), 65535);
+        hipLaunchKernelGGL(k_scatter_latent, dim3(nb), dim3(256), 0, st, *pool, root_latent, 1, 0, 0);
+        MZ_TRY(mz::check_launch("k_scatter_latent(root)"));
+    }
+    return MZ_OK;
+}
+
+int mz_tree_select(const mz_pool *pool, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
+                   int32_t flags, int32_t *out_leaf, int32_t *out_depth, void *stream) {
+    MZ_TRY(mz::check_pool(pool, false));
+    if (!sqrt_tab || !log_tab || tab_len <= 0 || !out_leaf)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_select: NULL table/output or tab_len <= 0");
+    size_t lds = sizeof(double) * 2 * (size_t)tab_len;
+    if (lds > 64 * 1024) return mz::fail(MZ_ERR_ARG, "mz_tree_select: tab_len %d exceeds the 4096-entry LDS table", tab_len);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_lpt(pool->A, [&](auto lpt) {
+        constexpr int LPT = decltype(lpt)::value;
+        hipLaunchKernelGGL(k_select<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), lds, st,
+                           *pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth);
+        return mz::check_launch("k_select");
+    });
+}
+
+int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float *prior, const float *reward,
+                          const float *next_latent, const int32_t *rand_child, int32_t *out_child, void *stream) {
+    MZ_TRY(mz::check_pool(pool, next_latent != nullptr));
+    if (!leaf || !prior || !reward || !rand_child || !out_child)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_expand_commit: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (next_latent) {
+        long long total = (long long)pool->G * pool->A * pool->D;
+        int nb = (int)std::min<long long>(blocks_for(total, 256), 65535);
+        hipLaunchKernelGGL(k_scatter_latent, dim3(nb), dim3(256), 0, st, *pool, next_latent, pool->A, 1, 0);
+        MZ_TRY(mz::check_launch("k_scatter_latent(children)"));
+    }
+    return dispatch_lpt(pool->A, [&](auto lpt) {
+        constexpr int LPT = decltype(lpt)::value;
+        hipLaunchKernelGGL(k_expand_commit<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), 0,
+                           st, *pool, leaf, prior, reward, rand_child, out_child);
+        return mz::check_launch("k_expand_commit");
+    });
+}
+
+int mz_tree_root_noise(const mz_pool *pool, const float *eta, double noise_frac, void *stream) {
+    MZ_TRY(mz::check_pool(pool, false));
+    if (!eta) return mz::fail(MZ_ERR_ARG, "mz_tree_root_noise: eta is NULL");
+    hipLaunchKernelGGL(k_root_noise, dim3(blocks_for((long long)pool->G * pool->A, 256)), dim3(256), 0,
+                       (hipStream_t)stream, *pool, eta, noise_frac);
+    return mz::check_launch("k_root_noise");
+}
+
+int mz_tree_backup(const mz_pool *pool, const int32_t *child, const int32_t *leaf, const float *rollout,
+                   int32_t n_rollout, double discount, void *stream) {
+    MZ_TRY(mz::check_pool(pool, false));
+    if (!child || !leaf || !rollout || n_rollout <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_backup: NULL argument or n_rollout <= 0");
+    hipLaunchKernelGGL(k_backup, dim3(blocks_for(pool->G, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *pool, child,
+                       leaf, rollout, n_rollout, discount);
+    return mz::check_launch("k_backup");
+}
+
+int mz_tree_result(const mz_pool *pool, double *policy, float *policy32, double *value, int32_t *visits,
+                   void *stream) {
+    MZ_TRY(mz::check_pool(pool, false));
+    hipLaunchKernelGGL(k_result, dim3(blocks_for(pool->G, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *pool,
+                       policy, policy32, value, visits);
+    return mz::check_launch("k_result");
+}
+
+int mz_tree_gather_latent(const mz_pool *pool, const int32_t *idx, float *out, void *stream) {
+    MZ_TRY(mz::check_pool(pool, true));
+    if (!idx || !out) return mz::fail(MZ_ERR_ARG, "mz_tree_gather_latent: NULL argument");
+    long long total = (long long)pool->G * pool->D;
+    int nb = (int)std::min<long long>(blocks_for(total, 256), 65535);
+    hipLaunchKernelGGL(k_gather_latent, dim3(nb), dim3(256), 0, (hipStream_t)stream, *pool, idx, out);
+    return mz::check_launch("k_gather_latent");
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+"""Batched search engine: G independent MCTS trees advanced in lock step on one MI355X.
+
+Host-side orchestration only -- every tree operation and every network evaluation is a
+kernel of libmuzero_hip.so reached through muzero_amd._hip (no CPU fallback).  The data
+model is the flat node pool of include/muzero_hip.h; PyTorch supplies device memory and
+the stream.
+
+The per-move algorithm is the reference's MCTS.run (src/search/mcts.py:44-74) with its
+randomness turned into inputs: `eta` (the Dirichlet sample of mcts.py:91) and `rand_child`
+(the S+1 random.choice draws of src/search/expansion.py:35, index 0 being the discarded
+draw of the root expansion).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from muzero_amd import _hip
+from muzero_amd._hip import ptr
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class TreePool:
+    """Device storage of G trees x cap nodes (SoA) and the PUCT lookup tables."""
+
+    def __init__(self, G: int, A: int, num_simulations: int, D: int, device="cuda", with_latent=True,
+                 cap: int | None = None):
+        self.G, self.A, self.D = G, A, D
+        self.cap = cap or (1 + A + num_simulations * A)
+        self.device = torch.device(device)
+        dev = self.device
+        n = G * self.cap
+        self.visit = torch.zeros(n, dtype=torch.int32, device=dev).view(G, self.cap)
+        self.value_sum = torch.zeros(n, dtype=torch.float64, device=dev).view(G, self.cap)
+        self.prior = torch.zeros(n, dtype=torch.float64, device=dev).view(G, self.cap)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=dev).view(G, self.cap)
+        self.parent = torch.full((G, self.cap), -1, dtype=torch.int32, device=dev)
+        self.first_child = torch.full((G, self.cap), -1, dtype=torch.int32, device=dev)
+        self.to_play = torch.zeros(n, dtype=torch.int8, device=dev).view(G, self.cap)
+        self.n_nodes = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.latent = torch.zeros((G, self.cap, D), dtype=torch.float32, device=dev) if with_latent else None
+        self.c = _hip.Pool(G, A, self.cap, D, ptr(self.visit), ptr(self.value_sum), ptr(self.prior),
+                           ptr(self.reward), ptr(self.parent), ptr(self.first_child), ptr(self.to_play),
+                           ptr(self.n_nodes), ptr(self.latent))
+        self.set_table_len(max(num_simulations + 2, 64))
+
+    def set_table_len(self, n: int) -> None:
+        sq = np.zeros(n, np.float64)
+        lg = np.zeros(n, np.float64)
+        _hip.check(_hip.lib().mz_puct_tables(ptr(sq), ptr(lg), n), "mz_puct_tables")
+        self.tab_len = n
+        self.sqrt_tab = torch.from_numpy(sq).to(self.device)
+        self.log_tab = torch.from_numpy(lg).to(self.device)
+
+    # ---- thin wrappers over the C ABI -------------------------------------------------
+    def init(self, root_to_play: torch.Tensor, root_latent: torch.Tensor | None = None) -> None:
+        assert root_to_play.dtype == torch.int8 and root_to_play.numel() == self.G
+        if root_latent is not None:
+            assert root_latent.dtype == torch.float32 and root_latent.numel() == self.G * self.D
+            assert root_latent.is_contiguous()
+        _hip.check(_hip.lib().mz_tree_init(C.byref(self.c), ptr(root_to_play), ptr(root_latent), _stream()),
+                   "mz_tree_init")
+
+    def select(self, out_leaf: torch.Tensor, out_depth: torch.Tensor | None = None, root_f32: bool = True) -> None:
+        assert out_leaf.dtype == torch.int32 and out_leaf.numel() == self.G
+        _hip.check(_hip.lib().mz_tree_select(C.byref(self.c), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
+                                             _hip.SELECT_ROOT_F32 if root_f32 else 0, ptr(out_leaf),
+                                             ptr(out_depth), _stream()), "mz_tree_select")
+
+    def expand_commit(self, leaf, prior, reward, rand_child, out_child, next_latent=None) -> None:
+        assert prior.dtype == torch.float32 and prior.numel() == self.G * self.A and prior.is_contiguous()
+        assert reward.dtype == torch.float32 and reward.numel() == self.G * self.A and reward.is_contiguous()
+        assert rand_child.dtype == torch.int32 and rand_child.numel() == self.G and rand_child.is_contiguous()
+        assert leaf.dtype == torch.int32 and out_child.dtype == torch.int32
+        if next_latent is not None:
+            assert next_latent.dtype == torch.float32 and next_latent.numel() == self.G * self.A * self.D
+        _hip.check(_hip.lib().mz_tree_expand_commit(C.byref(self.c), ptr(leaf), ptr(prior), ptr(reward),
+                                                    ptr(next_latent), ptr(rand_child), ptr(out_child), _stream()),
+                   "mz_tree_expand_commit")
+
+    def root_noise(self, eta: torch.Tensor, noise_frac: float) -> None:
+        assert eta.dtype == torch.float32 and eta.numel() == self.G * self.A and eta.is_contiguous()
+        _hip.check(_hip.lib().mz_tree_root_noise(C.byref(self.c), ptr(eta), float(noise_frac), _stream()),
+                   "mz_tree_root_noise")
+
+    def backup(self, child, leaf, rollout: torch.Tensor, discount: float) -> None:
+        assert rollout.dtype == torch.float32 and rollout.is_contiguous() and rollout.shape[0] == self.G
+        _hip.check(_hip.lib().mz_tree_backup(C.byref(self.c), ptr(child), ptr(leaf), ptr(rollout),
+                                             rollout.shape[1], float(discount), _stream()), "mz_tree_backup")
+
+    def result(self):
+        dev = self.device
+        policy = torch.empty((self.G, self.A), dtype=torch.float64, device=dev)
+        policy32 = torch.empty((self.G, self.A), dtype=torch.float32, device=dev)
+        value = torch.empty(self.G, dtype=torch.float64, device=dev)
+        visits = torch.empty((self.G, self.A), dtype=torch.int32, device=dev)
+        _hip.check(_hip.lib().mz_tree_result(C.byref(self.c), ptr(policy), ptr(policy32), ptr(value), ptr(visits),
+                                             _stream()), "mz_tree_result")
+        return policy, policy32, value, visits
+
+
+class PackedNetworks:
+    """Device copy of the g/f weights in the MFMA tile layout of the fused kernels.
+
+    Accepts DynamicsNetwork / PredictionNetwork modules whose `res_net` is empty (the MLP
+    configurations); call `refresh()` after the weights change."""
+
+    def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda"):
+        if len(dynamics.res_blocks) or len(prediction.res_blocks):
+            raise NotImplementedError("the fused HIP networks cover res_net: [] configurations")
+        if not isinstance(dynamics.res_final, torch.nn.Identity) or not isinstance(prediction.res_final, torch.nn.Identity):
+            raise NotImplementedError("res_final must be the identity for MLP-only networks")
+        self.device = torch.device(device)
+        self.dynamics_net, self.prediction_net = dynamics, prediction
+        c, h, w = dynamics.latent_shape
+        self.D, self.A = c * h * w, dynamics.num_actions
+        self._keep: list[torch.Tensor] = []
+        self.plan = _hip.PackedNets()
+        self.blob = None
+        self.refresh()
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _mlp(self, seq: torch.nn.Sequential) -> _hip.Mlp:
+        m = _hip.Mlp()
+        mods = list(seq)
+        i = n = 0
+        while i < len(mods):
+            lin = mods[i]
+            assert isinstance(lin, torch.nn.Linear), f"unexpected module {type(lin)} in MLP"
+            act = mods[i + 1] if i + 1 < len(mods) else torch.nn.Identity()
+            name = {torch.nn.Identity: "none", torch.nn.ReLU: "relu", torch.nn.Tanh: "tanh",
+                    torch.nn.Sigmoid: "sigmoid", torch.nn.Softmax: "softmax"}[type(act)]
+            w = self._dev(lin.weight)
+            b = self._dev(lin.bias) if lin.bias is not None else None
+            m.layer[n] = _hip.Dense(ptr(w), ptr(b), lin.in_features, lin.out_features, _hip.ACT[name], 0)
+            n += 1
+            i += 2
+        m.n_layers = n
+        return m
+
+    def refresh(self) -> None:
+        self._keep = []
+        g, f = self.dynamics_net, self.prediction_net
+        dyn = _hip.DynamicsNet(ptr(self._dev(g.action_embedding.weight)), ptr(self._dev(g.fc_merge.weight)),
+                               ptr(self._dev(g.fc_merge.bias)), self._mlp(g.reward_mlp), self.D, self.A)
+        pred = _hip.PredictionNet(self._mlp(f.value_mlp), self._mlp(f.policy_mlp), self.D, self.A)
+        lib = _hip.lib()
+        _hip.check(lib.mz_nets_plan(C.byref(dyn), C.byref(pred), C.byref(self.plan)), "mz_nets_plan")
+        if self.blob is None or self.blob.numel() != self.plan.total_floats:
+            self.blob = torch.empty(self.plan.total_floats, dtype=torch.float32, device=self.device)
+        _hip.check(lib.mz_nets_pack(C.byref(dyn), C.byref(pred), C.byref(self.plan), ptr(self.blob), _stream()),
+                   "mz_nets_pack")
+
+    # ---- batched g / f ------------------------------------------------------------------
+    def dynamics(self, latent, B, *, ld=None, rows=None, action=None, next_latent=None, ld_next=None, next_rows=None,
+                 reward=None) -> None:
+        _hip.check(_hip.lib().mz_dynamics_forward(
+            C.byref(self.plan), ptr(self.blob), ptr(latent), ld or self.D, ptr(rows), ptr(action), ptr(next_latent),
+            ld_next or self.D, ptr(next_rows), ptr(reward), B, _stream()), "mz_dynamics_forward")
+
+    def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None) -> None:
+        _hip.check(_hip.lib().mz_prediction_forward(
+            C.byref(self.plan), ptr(self.blob), ptr(latent), ld or self.D, ptr(rows), softmax_times, ptr(policy),
+            ptr(value), ptr(argmax), B, _stream()), "mz_prediction_forward")
+
+
+@dataclass
+class SearchResult:
+    policy: torch.Tensor    # f64 [G, A]  softmax of root children's value sums
+    policy32: torch.Tensor  # f32 [G, A]  the tensor the reference stores in a Chunk
+    value: torch.Tensor     # f64 [G]     root mean value
+    visits: torch.Tensor    # i32 [G, A]
+
+
+class BatchedMCTS:
+    """MCTS.run for G trees at once (PUCT selection, `max_iterations` mode)."""
+
+    def __init__(self, nets: PackedNetworks, G: int, num_simulations: int, model_look_ahead: int,
+                 discount: float, noise_frac: float, device="cuda"):
+        self.nets = nets
+        self.G, self.S, self.depth = G, num_simulations, model_look_ahead
+        self.discount, self.noise_frac = discount, noise_frac
+        self.A, self.D = nets.A, nets.D
+        self.pool = TreePool(G, self.A, num_simulations, self.D, device=device)
+        dev = self.pool.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        G, A, D = self.G, self.A, self.D
+        self.leaf = torch.zeros(G, **i32)
+        self.child = torch.zeros(G, **i32)
+        self.prior = torch.zeros((G, A), **f32)
+        self.reward = torch.zeros((G, A), **f32)
+        self.rollout_t = torch.zeros((self.depth + 1, G), **f32)
+        self.act = torch.zeros(G, **i32)
+        self.tmp = [torch.zeros((G, D), **f32) for _ in range(2)]
+        self.tree_base = (torch.arange(G, **i32) * self.pool.cap)
+        self.arange_a = torch.arange(A, **i32)
+
+    def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor) -> None:
+        """expand_node (src/search/expansion.py:9-35) for one node per tree."""
+        pool, nets, G, A = self.pool, self.nets, self.G, self.A
+        rows = self.tree_base + node
+        nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
+        rows_rep = rows.repeat_interleave(A)
+        next_rows = ((self.tree_base + pool.n_nodes)[:, None] + self.arange_a[None, :]).reshape(-1).contiguous()
+        nets.dynamics(pool.latent, G * A, rows=rows_rep, action=None, next_latent=pool.latent, next_rows=next_rows,
+                      reward=self.reward)
+        pool.expand_commit(node, self.prior, self.reward, rand_child, out_child)
+
+    def _simulate(self, child: torch.Tensor) -> torch.Tensor:
+        """MuZeroSimulation (src/search/simulation.py:23-45) from one node per tree;
+        returns rollout f32[G, depth+1]."""
+        pool, nets, G = self.pool, self.nets, self.G
+        cur, rows = pool.latent, self.tree_base + child
+        for d in range(self.depth):
+            nets.prediction(cur, G, rows=rows, argmax=self.act)
+            nxt = self.tmp[d & 1]
+            nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d])
+            cur, rows = nxt, None
+        nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth])
+        return self.rollout_t.t().contiguous()
+
+    def run(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
+            rand_child: torch.Tensor, trace: dict | None = None) -> SearchResult:
+        """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1]."""
+        pool = self.pool
+        assert rand_child.shape == (self.G, self.S + 1) and rand_child.dtype == torch.int32
+        rand_t = rand_child.t().contiguous()
+        pool.init(root_to_play, root_latent.reshape(self.G, self.D).contiguous())
+        self.leaf.zero_()
+        self._expand(self.leaf, rand_t[0], self.child)
+        pool.root_noise(eta.contiguous(), self.noise_frac)
+        for s in range(self.S):
+            pool.select(self.leaf)
+            self._expand(self.leaf, rand_t[s + 1], self.child)
+            rollout = self._simulate(self.child)
+            pool.backup(self.child, self.leaf, rollout, self.discount)
+            if trace is not None:
+                trace.setdefault("leaf", []).append(self.leaf.clone())
+                trace.setdefault("child", []).append(self.child.clone())
+                trace.setdefault("rollout", []).append(rollout.clone())
+                trace.setdefault("prior", []).append(self.prior.clone())
+        return SearchResult(*pool.result())
+
+
+def run_recorded(pool: TreePool, root_to_play, prior_stream, reward_stream, rand_stream, sim_stream, eta,
+                 noise_frac: float, discount: float):
+    """Tree kernels only, driven by recorded network outputs (the parity harness of the
+    bit-exact contract).  Streams are device tensors shaped [S+1, G, A], [S+1, G, A],
+    [S+1, G], [S, G, depth+1], eta [G, A].  Returns (leaf[S, G], child[S, G])."""
+    S = sim_stream.shape[0]
+    G = pool.G
+    dev = pool.device
+    leaf = torch.zeros(G, dtype=torch.int32, device=dev)
+    child = torch.zeros(G, dtype=torch.int32, device=dev)
+    leaves = torch.zeros((S, G), dtype=torch.int32, device=dev)
+    children = torch.zeros((S, G), dtype=torch.int32, device=dev)
+    pool.init(root_to_play)
+    pool.expand_commit(leaf, prior_stream[0], reward_stream[0], rand_stream[0], child)
+    pool.root_noise(eta, noise_frac)
+    for s in range(S):
+        pool.select(leaf)
+        pool.expand_commit(leaf, prior_stream[s + 1], reward_stream[s + 1], rand_stream[s + 1], child)
+        pool.backup(child, leaf, sim_stream[s], discount)
+        leaves[s].copy_(leaf)
+        children[s].copy_(child)
+    return leaves, children

@@ -93,9 +93,9 @@ class Tree:
         e = np.ascontiguousarray(eta, np.float32)
         lib().mzo_root_noise(C.byref(self.s), _p(e, C.c_float), C.c_double(noise_frac))
 
-    def select(self):
+    def select(self, root_f32: bool = True):
         d = C.c_int32(0)
-        leaf = lib().mzo_select(C.byref(self.s), C.byref(d))
+        leaf = lib().mzo_select(C.byref(self.s), C.c_int32(int(root_f32)), C.byref(d))
         return leaf, d.value
 
     def backup(self, child, rewards, leaf_to_play, discount):

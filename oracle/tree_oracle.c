@@ -85,9 +85,10 @@ void mzo_root_noise(mzo_tree *t, const float *eta, double noise_frac) {
 }
 
 /* src/search/selection.py:43-59.  Children of the root are scored in float32 (their
- * prior is a float32 tensor after mcts.py:94), all other children in float64.
+ * prior is a float32 tensor after mcts.py:94; `root_f32` = 0 models a bare tree whose
+ * root children still hold Python floats), all other children in float64.
  * max(..., key=) keeps the first maximal element.                                   */
-int32_t mzo_select(const mzo_tree *t, int32_t *out_depth) {
+int32_t mzo_select(const mzo_tree *t, int32_t root_f32, int32_t *out_depth) {
     int32_t node = 0, depth = 0;
     while (t->first_child[node] >= 0) {
         int32_t base = t->first_child[node];
@@ -101,7 +102,7 @@ int32_t mzo_select(const mzo_tree *t, int32_t *out_depth) {
             volatile double pb = sqrt_np / (double)(n + 1);
             volatile double lg = log(((double)n + MZ_C2 + 1.0) / MZ_C2) + MZ_C1;
             pb = pb * lg;
-            if (node == 0) {
+            if (node == 0 && root_f32) {
                 volatile float ps = (float)pb * (float)t->prior[c];
                 volatile float sc = ps;
                 if (n > 0) {
@@ -179,7 +180,7 @@ void mzo_run(mzo_tree *t, int32_t root_to_play, int32_t S, int32_t depth,
     (void)mzo_expand(t, 0, prior_stream, reward_stream, rand_stream[0]);
     mzo_root_noise(t, eta, noise_frac);
     for (int s = 0; s < S; ++s) {
-        int32_t leaf = mzo_select(t, 0);
+        int32_t leaf = mzo_select(t, 1, 0);
         int32_t child = mzo_expand(t, leaf, prior_stream + (size_t)(s + 1) * A,
                                    reward_stream + (size_t)(s + 1) * A, rand_stream[s + 1]);
         double g = mzo_backup(t, child, sim_stream + (size_t)s * (depth + 1), depth + 1,

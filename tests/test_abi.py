@@ -1,0 +1,52 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads and exports every
+symbol include/muzero_hip.h declares (no kernel is launched here)."""
+import ctypes
+import os
+import re
+
+from muzero_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "muzero_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_hip.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/muzero_hip.h but not exported"
+
+
+def test_binding_covers_header():
+    assert set(_declared()) <= set(_hip.exported_symbols())
+    lib = _hip.lib()
+    assert lib.mz_abi_version() >= 1
+
+
+def test_host_only_entry_points():
+    """mz_puct_tables and the *_plan calls run on the host: check them without a GPU."""
+    import math
+
+    import numpy as np
+    sq, lg = np.zeros(64), np.zeros(64)
+    assert _hip.lib().mz_puct_tables(_hip.ptr(sq), _hip.ptr(lg), 64) == 0
+    for n in (0, 1, 7, 50, 63):
+        assert sq[n] == math.sqrt(n)
+        assert lg[n] == math.log((n + 19652 + 1) / 19652) + 1.25  # src/search/selection.py:47
+    m = _hip.Mlp()
+    m.n_layers = 2
+    m.layer[0] = _hip.Dense(1, None, 168, 256, 1, 0)
+    m.layer[1] = _hip.Dense(1, None, 256, 7, 4, 0)
+    plan = _hip.PackedMlp()
+    n = _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan))
+    assert n == 176 * 256 + 256 + 256 * 16 + 16
+    assert (plan.in_features, plan.out_features, plan.max_width) == (168, 7, 256)
+    m.layer[1].in_features = 255  # chain mismatch must be rejected with a message
+    assert _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan)) < 0
+    assert b"in_features" in _hip.lib().mz_last_error()
