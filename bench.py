@@ -1,0 +1,224 @@
+"""Headline benchmark: MCTS simulations/sec at 4096 concurrent Connect-Four games per GPU,
+50 simulations per move (MLP h/g/f, A=7, D=168, model_look_ahead=1).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one MCTS.run over all G trees of this rank (root expansion + noise + 50
+select/expand/simulate/backup rounds), inputs resident in HBM.  Games shard per GPU with no
+data-path collective (weak scaling); torch.distributed is used for the barrier and the
+max-over-ranks of the timed region only.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+A, D = 7, 168
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_networks():
+    from muzero_amd.config import load_config
+    from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork, RepresentationNetwork
+    cfg = load_config("config_c4_mlp.yaml")
+    torch.manual_seed(0)
+    h = RepresentationNetwork((2, 6, 7), cfg.networks.latent_shape, cfg.networks.representation)
+    g = DynamicsNetwork(cfg.networks.latent_shape, A, cfg.networks.dynamics)
+    f = PredictionNetwork(cfg.networks.latent_shape, A, cfg.networks.prediction)
+    return cfg, h, g, f
+
+
+def synthetic_roots(h, G, seed, device):
+    """Root observations: Connect-Four positions after 0..15 random moves from the empty board
+    (played by the GPU env kernels; games that ended early fall back to the empty board),
+    assembled into the K=1 history tensor and passed through h."""
+    from muzero_amd.environments.connect_four import BatchedConnectFour
+    rng = np.random.default_rng(seed)
+    env = BatchedConnectFour(G, device=device)
+    env.reset()
+    plies = torch.from_numpy(rng.integers(0, 16, size=G)).to(device)
+    obs_t, tp_t, done_t = [], [], []
+    for t in range(16):
+        obs, to_play = env.observe()
+        obs_t.append(obs.clone()), tp_t.append(to_play.clone()), done_t.append(env.done.clone())
+        env.step(torch.from_numpy(rng.integers(0, 7, size=G).astype(np.int32)).to(device))
+    obs_t, tp_t, done_t = torch.stack(obs_t), torch.stack(tp_t), torch.stack(done_t)
+    idx = torch.arange(G, device=device)
+    pick = torch.where(done_t[plies, idx].bool(), torch.zeros_like(plies), plies)
+    obs, to_play = obs_t[pick, idx], tp_t[pick, idx].contiguous()
+    hist = torch.cat([obs, torch.zeros(G, 1, 6, 7, device=device)], dim=1)  # frame + action plane (action id 0)
+    with torch.no_grad():
+        latent = h.to(device)(hist).reshape(G, D).contiguous()
+    return latent, to_play
+
+
+def child_choice_streams(G, S, base_seed):
+    out = np.empty((G, S + 1), np.int32)
+    for g in range(G):
+        r = random.Random(base_seed + g)
+        out[g] = [r.randrange(A) for _ in range(S + 1)]
+    return out
+
+
+def time_kernel(fn, iters=20):
+    """Average duration (s) of `fn`'s launches on the current stream, by HIP events."""
+    stream = torch.cuda.current_stream()
+    fn()
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_rooflines(mcts, plan):
+    """Times the network kernels in the exact shapes one simulation round launches them and
+    returns per-kernel {seconds, flop, calls_per_sim}."""
+    nets, pool, G = mcts.nets, mcts.pool, mcts.G
+    def mlp_flop(p):
+        return sum(2 * p.layer[i].K * p.layer[i].N for i in range(p.n_layers))
+    rows = (mcts.tree_base + 1).contiguous()
+    rows_rep = rows.repeat_interleave(A)
+    base = 1 + A
+    next_rows = ((mcts.tree_base + base)[:, None] + mcts.arange_a[None, :]).reshape(-1).contiguous()
+    out = {}
+    out["k_dynamics[expand B=G*A]"] = dict(
+        s=time_kernel(lambda: nets.dynamics(pool.latent, G * A, rows=rows_rep, next_latent=pool.latent,
+                                            next_rows=next_rows, reward=mcts.reward)),
+        flop=G * A * (2 * D * D + mlp_flop(plan.reward)), calls=1)
+    out["k_prediction[policy B=G]"] = dict(
+        s=time_kernel(lambda: nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=mcts.prior)),
+        flop=G * mlp_flop(plan.policy), calls=2)
+    out["k_dynamics[step B=G]"] = dict(
+        s=time_kernel(lambda: nets.dynamics(pool.latent, G, rows=rows, action=mcts.act, next_latent=mcts.tmp[0],
+                                            reward=mcts.rollout_t[0])),
+        flop=G * (2 * D * D + mlp_flop(plan.reward)), calls=1)
+    out["k_prediction[value B=G]"] = dict(
+        s=time_kernel(lambda: nets.prediction(mcts.tmp[0], G, value=mcts.rollout_t[1])),
+        flop=G * mlp_flop(plan.value), calls=1)
+    return out
+
+
+def cpu_baseline(g, f, budget_s=12.0):
+    """The per-node CPU port (same Python/torch call structure as the reference) on one core."""
+    from oracle import pyref
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(1)
+    ev = pyref.TorchEvaluator(g, f, torch.arange(A), 1)
+    sims = moves = 0
+    with torch.no_grad():
+        for warm in (True, False):
+            t0 = time.perf_counter()
+            while True:
+                lat = torch.from_numpy(rng.standard_normal((1, 4, 6, 7)).astype(np.float32))
+                pyref.run_mcts(lat, 1, ev, A, 50, discount=0.998, noise_frac=0.25)
+                if warm:
+                    break
+                sims += 50
+                moves += 1
+                if time.perf_counter() - t0 > budget_s:
+                    break
+        dt = time.perf_counter() - t0
+    return {"value": sims / dt, "unit": "sims/s", "cores": 1, "kind": "port",
+            "sample": f"{moves} single-game MCTS.run calls (50 sims, c4_mlp nets, torch CPU 1 thread) in {dt:.1f}s",
+            "env_steps_per_s": moves / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    cfg, h, g, f = build_networks()
+    G, S = args.games, args.sims
+    nets = PackedNetworks(g, f, device=dev)
+    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev)
+    latent, to_play = synthetic_roots(h, G, seed=100 + rank, device=dev)
+    eta = torch.from_numpy(np.random.default_rng(7 + rank).dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).to(dev)
+    rand = torch.from_numpy(child_choice_streams(G, S, base_seed=rank * G)).to(dev)
+
+    def step():
+        return mcts.run(latent, to_play, eta, rand)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert int(res.visits.sum().item()) == G * S, "search did not complete every simulation"
+
+    sims_total = world * G * S * args.steps
+    line = {
+        "metric": "mcts_simulations_per_sec", "value": sims_total / dt, "unit": "sims/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
+        "config": {"workload": f"c4_mlp: {G} Connect-Four games per GPU x {S} sims/move, A=7, D=168, "
+                               "model_look_ahead=1, noise_frac=0.25 (fixed eta), MT19937 child-choice streams",
+                   "games_per_gpu": G, "sims_per_move": S, "parallelism": f"games sharded x{world}, no collective"},
+        "env_steps_per_sec": world * G * args.steps / dt,
+    }
+    if rank == 0 and not args.no_roofline:
+        ks = kernel_rooflines(mcts, nets.plan)
+        dom = max(ks, key=lambda k: ks[k]["s"] * ks[k]["calls"])
+        tf = ks[dom]["flop"] / ks[dom]["s"] / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                            "avg_launch_us": ks[dom]["s"] * 1e6, "flop_per_launch": ks[dom]["flop"]}
+        line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12,
+                               "launches_per_sim": v["calls"]} for k, v in ks.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(g, f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
