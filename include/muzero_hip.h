@@ -232,6 +232,42 @@ int mz_c4_step(const mz_c4_state *state, const int32_t *action, float *reward, i
  * (plane 0 = player to move, row 0 = top), to_play i8[G] in {+1,-1} (may be NULL). */
 int mz_c4_observe(const mz_c4_state *state, float *obs, int8_t *to_play, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Data side of self-play and of the learner's targets.
+ * ------------------------------------------------------------------------------------ */
+
+/* FrameRingBuffer.fill/add + make_history_tensor, src/ring_buffer.py:11-83, for G games.
+ * ring f32[G][K][C*H*W] and act_ring i32[G][K] persist between calls (caller-owned).
+ * frame f32[G][C][H][W] is this step's observation, action i32[G] the action id stored with
+ * it (NULL = 0, as self-play does: src/training_data_generator.py:110).  step i32[G] = moves
+ * already played in the game's episode: 0 replicates the frame into every slot (fill),
+ * t > 0 overwrites slot (t-1) % K (add).  out f32[G][C*K+K][H][W] = frames in SLOT order on
+ * the channel axis, then K planes filled with each slot's action id. */
+int mz_history_push_assemble(float *ring, int32_t *act_ring, const float *frame,
+                             const int32_t *action, const int32_t *step, int32_t G, int32_t K,
+                             int32_t C, int32_t H, int32_t W, float *out, void *stream);
+
+/* RepresentationNetwork.forward for `downsample: [], res_net: []` configs whose latent H, W
+ * equal the observation's: a 1x1 convolution (final_conv) followed by an identity pool,
+ * src/neural_networks/neural_network.py:83-102.  x f32[G][Cin][P], weight f32[Cout][Cin],
+ * bias f32[Cout] or NULL, out f32[G][Cout][P] (P = H*W). */
+int mz_repr_pointwise(const float *x, const float *weight, const float *bias, int32_t G,
+                      int32_t Cin, int32_t Cout, int32_t P, float *out, void *stream);
+
+/* Greedy / exploratory action pick of _select_action, src/training_data_generator.py:148-163:
+ * action[g] = explore[g] ? random_action[g] : first argmax of policy[g][0..A).  The caller
+ * draws explore (random() < epsilon) and random_action on the host.  explore may be NULL. */
+int mz_pick_action(const float *policy, const int8_t *explore, const int32_t *random_action,
+                   int32_t G, int32_t A, int32_t *action, void *stream);
+
+/* Host-only: h_out[j] = gamma^(j-1) for j = 0..w+1 with the C library's pow (the factors
+ * _compute_z_targets uses, src/training.py:236-240). */
+int mz_gamma_powers(double gamma, int32_t w, double *h_out);
+/* _compute_z_targets, src/training.py:223-242, for B unroll windows: R, V f64[B][w+1]
+ * (chunks k..k+w), pow_tab = device copy of mz_gamma_powers, z f64[B][w+1]. */
+int mz_z_targets(const double *R, const double *V, const double *pow_tab, int32_t B, int32_t w,
+                 double *z, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,12 @@ _SIGS = {
     "mz_c4_reset": (C.c_int, [C.POINTER(C4State), _P, _P]),
     "mz_c4_step": (C.c_int, [C.POINTER(C4State), _P, _P, _P, _P]),
     "mz_c4_observe": (C.c_int, [C.POINTER(C4State), _P, _P, _P]),
+    "mz_history_push_assemble": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           _P, _P]),
+    "mz_repr_pointwise": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mz_pick_action": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "mz_gamma_powers": (C.c_int, [C.c_double, C.c_int32, _P]),
+    "mz_z_targets": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
 }
 
 

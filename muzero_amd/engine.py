@@ -230,19 +230,23 @@ class BatchedMCTS:
         nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth])
         return self.rollout_t.t().contiguous()
 
-    def run(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
-            rand_child: torch.Tensor, trace: dict | None = None) -> SearchResult:
-        """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1]."""
+    def begin(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
+              rand_root: torch.Tensor) -> None:
+        """Root creation, root expansion (its child draw `rand_root` i32[G] is discarded, as in
+        src/search/mcts.py:89) and the prior perturbation of mcts.py:91-94."""
         pool = self.pool
-        assert rand_child.shape == (self.G, self.S + 1) and rand_child.dtype == torch.int32
-        rand_t = rand_child.t().contiguous()
         pool.init(root_to_play, root_latent.reshape(self.G, self.D).contiguous())
         self.leaf.zero_()
-        self._expand(self.leaf, rand_t[0], self.child)
+        self._expand(self.leaf, rand_root.reshape(self.G).contiguous(), self.child)
         pool.root_noise(eta.contiguous(), self.noise_frac)
-        for s in range(self.S):
+
+    def advance(self, rand_child: torch.Tensor, trace: dict | None = None) -> None:
+        """One `_step` (src/search/mcts.py:76-83) per column of rand_child i32[G, n]."""
+        pool = self.pool
+        rand_t = rand_child.t().contiguous()
+        for s in range(rand_t.shape[0]):
             pool.select(self.leaf)
-            self._expand(self.leaf, rand_t[s + 1], self.child)
+            self._expand(self.leaf, rand_t[s], self.child)
             rollout = self._simulate(self.child)
             pool.backup(self.child, self.leaf, rollout, self.discount)
             if trace is not None:
@@ -250,7 +254,17 @@ class BatchedMCTS:
                 trace.setdefault("child", []).append(self.child.clone())
                 trace.setdefault("rollout", []).append(rollout.clone())
                 trace.setdefault("prior", []).append(self.prior.clone())
-        return SearchResult(*pool.result())
+
+    def finish(self) -> SearchResult:
+        return SearchResult(*self.pool.result())
+
+    def run(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
+            rand_child: torch.Tensor, trace: dict | None = None) -> SearchResult:
+        """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1]."""
+        assert rand_child.shape == (self.G, self.S + 1) and rand_child.dtype == torch.int32
+        self.begin(root_latent, root_to_play, eta, rand_child[:, 0])
+        self.advance(rand_child[:, 1:], trace)
+        return self.finish()
 
 
 def run_recorded(pool: TreePool, root_to_play, prior_stream, reward_stream, rand_stream, sim_stream, eta,

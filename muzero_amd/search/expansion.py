@@ -1,0 +1,50 @@
+"""expand_node (src/search/expansion.py:9-40) for a host-side `Node`, evaluated by the fused
+network kernels (one f row, A g rows)."""
+from __future__ import annotations
+
+import random
+
+import torch
+
+from muzero_amd.search.nodes import Node
+
+_PACK_CACHE: dict = {}
+
+
+def packed_for(dynamics_network, prediction_network):
+    """PackedNetworks for a (g, f) module pair, rebuilt when a parameter was modified."""
+    from muzero_amd.engine import PackedNetworks
+    key = (id(dynamics_network), id(prediction_network))
+    version = tuple(p._version for p in list(dynamics_network.parameters()) + list(prediction_network.parameters()))
+    hit = _PACK_CACHE.get(key)
+    if hit is None or hit[0] != version:
+        hit = (version, PackedNetworks(dynamics_network, prediction_network))
+        _PACK_CACHE[key] = hit
+    return hit[1]
+
+
+def _transform_latent_state(batch_size: int, latent_state: torch.Tensor) -> torch.Tensor:
+    return latent_state.repeat(batch_size, 1, 1, 1)
+
+
+def expand_node(node: Node, actions: torch.Tensor, dynamics_network, prediction_network) -> Node:
+    batch_size = actions.size(0)
+    if batch_size <= 0:
+        raise ValueError("No possible actions to expand the node with")
+    nets = packed_for(dynamics_network, prediction_network)
+    dev = nets.device
+    lat = node.latent_state.detach().to(dev, torch.float32).reshape(1, -1).contiguous()
+    prior = torch.empty((1, nets.A), dtype=torch.float32, device=dev)
+    nets.prediction(lat, 1, softmax_times=1, policy=prior)
+    rep = lat.repeat(batch_size, 1).contiguous()
+    nxt = torch.empty((batch_size, nets.D), dtype=torch.float32, device=dev)
+    rew = torch.empty(batch_size, dtype=torch.float32, device=dev)
+    nets.dynamics(rep, batch_size, action=actions.to(dev, torch.int32).contiguous(), next_latent=nxt, reward=rew)
+    prior_h = prior[0].cpu()
+    shape = (1,) + tuple(node.latent_state.shape[1:])
+    out_dev = node.latent_state.device
+    for i in range(batch_size):
+        child = node.add_child(nxt[i].reshape(shape).to(out_dev), actions[i])
+        child.policy_priority = prior_h[i].item()
+        child.reward = rew[i:i + 1].to(out_dev)
+    return random.choice(list(node.children.values()))

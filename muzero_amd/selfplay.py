@@ -1,0 +1,154 @@
+"""Batched self-play: G Connect-Four games advance in lock step entirely on one GPU.
+
+Per move (the pipeline of src/training_data_generator.py:107-142, for all games at once):
+observe (k_c4_observe) -> history ring + tensor (k_history) -> h (k_pointwise_conv, or the torch
+module on the GPU for convolutional configs) -> MCTS.run (muzero_amd.engine.BatchedMCTS) ->
+epsilon-greedy pick (k_pick_action) -> env step (k_c4_step) -> append to the trajectory store.
+Finished games restart in place, so the batch never drains.
+
+Randomness: the reference plays games one after another from three global generators, an
+interleaving a batched engine cannot reproduce; here every stream is drawn per move from one
+seeded numpy Generator (child choices, exploration coin and action) and torch's Dirichlet.
+For the stream-exact single-game path use muzero_amd.training_data_generator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from muzero_amd import _hip
+from muzero_amd._hip import ptr
+from muzero_amd.engine import BatchedMCTS, PackedNetworks, _stream
+from muzero_amd.environments.connect_four import BatchedConnectFour
+
+
+class DeviceHistory:
+    """K-slot observation ring per game + history tensor assembly (src/ring_buffer.py)."""
+
+    def __init__(self, G: int, K: int, obs_shape: tuple[int, int, int], device="cuda"):
+        self.G, self.K = G, K
+        self.C, self.H, self.W = obs_shape
+        dev = torch.device(device)
+        self.ring = torch.zeros((G, K, self.C * self.H * self.W), dtype=torch.float32, device=dev)
+        self.act_ring = torch.zeros((G, K), dtype=torch.int32, device=dev)
+        self.out = torch.zeros((G, self.C * K + K, self.H, self.W), dtype=torch.float32, device=dev)
+
+    def push(self, frame: torch.Tensor, step: torch.Tensor, action: torch.Tensor | None = None) -> torch.Tensor:
+        assert frame.dtype == torch.float32 and frame.is_contiguous() and frame.numel() == self.G * self.C * self.H * self.W
+        assert step.dtype == torch.int32 and step.numel() == self.G
+        _hip.check(_hip.lib().mz_history_push_assemble(ptr(self.ring), ptr(self.act_ring), ptr(frame), ptr(action),
+                                                       ptr(step), self.G, self.K, self.C, self.H, self.W, ptr(self.out),
+                                                       _stream()), "mz_history_push_assemble")
+        return self.out
+
+
+class RepresentationRunner:
+    """h on the GPU.  MLP-style configs (`downsample: [], res_net: []`, latent H, W equal to the
+    observation's) are one 1x1 convolution and run the HIP kernel; every other configuration
+    runs the torch module on the GPU (its convolutions are not part of this path yet)."""
+
+    def __init__(self, repr_net: torch.nn.Module, device="cuda"):
+        self.net = repr_net
+        self.device = torch.device(device)
+        self.pointwise = (len(repr_net.downsample_layers) == 0 and len(repr_net.res_blocks) == 0
+                          and isinstance(repr_net.final_conv, torch.nn.Conv2d))
+        if self.pointwise:
+            conv = repr_net.final_conv
+            self.weight = conv.weight.detach().to(self.device, torch.float32).reshape(conv.out_channels, -1).contiguous()
+            self.bias = conv.bias.detach().to(self.device, torch.float32).contiguous() if conv.bias is not None else None
+        else:
+            self.net = repr_net.to(self.device)
+
+    def __call__(self, history: torch.Tensor) -> torch.Tensor:
+        G, cin, H, W = history.shape
+        if self.pointwise and (H, W) == (self.net.latent_height, self.net.latent_width):
+            x = history.to(self.device, torch.float32).contiguous()
+            cout = self.weight.shape[0]
+            out = torch.empty((G, cout, H, W), dtype=torch.float32, device=self.device)
+            _hip.check(_hip.lib().mz_repr_pointwise(ptr(x), ptr(self.weight), ptr(self.bias), G, cin, cout, H * W,
+                                                    ptr(out), _stream()), "mz_repr_pointwise")
+            return out
+        with torch.no_grad():
+            return self.net.to(self.device)(history.to(self.device))
+
+
+def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_action: torch.Tensor | None,
+                out: torch.Tensor) -> torch.Tensor:
+    G, A = policy32.shape
+    _hip.check(_hip.lib().mz_pick_action(ptr(policy32), ptr(explore), ptr(random_action), G, A, ptr(out), _stream()),
+               "mz_pick_action")
+    return out
+
+
+class SelfPlayEngine:
+    def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0):
+        """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps)."""
+        self.G, self.cfg = G, config
+        self.device = torch.device(device)
+        m = config.mcts
+        if m.max_iterations <= 0:
+            raise ValueError("batched self-play needs max_iterations > 0 (the time-bounded mode is single-game only)")
+        self.env = BatchedConnectFour(G, device=device)
+        self.A = self.env.num_actions
+        self.h = RepresentationRunner(repr_net, device=device)
+        self.nets = PackedNetworks(dyn_net, pred_net, device=device)
+        self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
+                                device=device)
+        self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
+        self.rng = np.random.default_rng(seed)
+        self.alpha = m.dirichlet_alpha
+        dev = self.device
+        self.step_in_episode = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.action = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.env.reset()
+
+    def epsilon(self, training_steps: int) -> float:
+        c = self.cfg
+        return max(c.epsilon * (c.epsilon_decay ** training_steps), c.min_epsilon)
+
+    def move(self, training_steps: int = 0):
+        """One move of every game.  Returns device tensors (obs, policy32, value, action, reward,
+        done) for this move; games that ended (or hit max_steps_per_episode) restart."""
+        G, A, S, dev = self.G, self.A, self.mcts.S, self.device
+        obs, to_play = self.env.observe()
+        hist = self.history.push(obs, self.step_in_episode, None)  # self-play stores action id 0 with every frame
+        latent = self.h(hist).reshape(G, -1)
+        rand = torch.from_numpy(self.rng.integers(0, A, size=(G, S + 1), dtype=np.int32)).to(dev)
+        eta = torch.from_numpy(self.rng.dirichlet(np.full(A, self.alpha), size=G).astype(np.float32)).to(dev)
+        res = self.mcts.run(latent, to_play, eta, rand)
+        eps = self.epsilon(training_steps)
+        explore = torch.from_numpy((self.rng.random(G) < eps).astype(np.int8)).to(dev)
+        p = self.cfg.random_action_probability
+        rnd = torch.from_numpy(self.rng.choice(A, size=G, p=p).astype(np.int32)).to(dev)
+        pick_action(res.policy32, explore, rnd, self.action)
+        reward, done = self.env.step(self.action)
+        self.step_in_episode += 1
+        ended = (done.bool() | (self.step_in_episode >= self.cfg.max_steps_per_episode)).to(torch.int8)
+        out = (obs, res.policy32, res.value, self.action.clone(), reward, ended)
+        self.env.reset(ended)
+        self.step_in_episode.masked_fill_(ended.bool(), 0)
+        return out
+
+    def generate(self, num_moves: int, training_steps: int = 0):
+        """Plays `num_moves` lock-step moves and returns the finished episodes as lists of Chunk
+        (states on the CPU), in the reference's Episode/Chunk format."""
+        from muzero_amd.training_data_generator import Chunk, Episode
+        rec = [self.move(training_steps) for _ in range(num_moves)]
+        obs = torch.stack([r[0] for r in rec]).cpu()
+        pol = torch.stack([r[1] for r in rec]).cpu()
+        val = torch.stack([r[2] for r in rec]).cpu()
+        act = torch.stack([r[3] for r in rec]).cpu()
+        rew = torch.stack([r[4] for r in rec]).cpu()
+        end = torch.stack([r[5] for r in rec]).cpu()
+        episodes = []
+        for g in range(self.G):
+            cur = []
+            for t in range(num_moves):
+                cur.append(Chunk(state=obs[t, g].unsqueeze(0), policy=pol[t, g], reward=float(rew[t, g]),
+                                 value=float(val[t, g]), best_action=int(act[t, g])))
+                if end[t, g]:
+                    episodes.append(Episode(chunks=cur))
+                    cur = []
+        return episodes

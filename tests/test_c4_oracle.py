@@ -40,15 +40,8 @@ def test_no_win_midgame_and_observation_layout():
 
 
 def test_draw_full_board():
-    order = [0, 1, 2, 4, 3, 5, 6]  # a column order that fills the board without a four
     g = C4()
-    cols = []
-    for base in (0, 2, 4):
-        pass
-    # classic draw pattern: fill columns in pairs with alternating offsets
-    seq = []
-    for c in (0, 1, 2, 4, 5, 6):
-        pass
+    # fill the columns pairwise with alternating offsets: no four in a row anywhere
     moves = [0, 1, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1,
              2, 3, 2, 3, 3, 2, 3, 2, 2, 3, 2, 3,
              4, 5, 4, 5, 5, 4, 5, 4, 4, 5, 4, 5,

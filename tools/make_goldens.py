@@ -326,11 +326,65 @@ def make_data():
     print("data_path.npz ok")
 
 
+# ----------------------------------------------------------------------------------------
+# single-game self-play (reference TrainingDataGenerator over the oracle Connect-Four env)
+# and the learner (reference NeuralNetworkManager.train on those episodes)
+# ----------------------------------------------------------------------------------------
+def make_selfplay_and_learner():
+    from oracle.c4 import C4Env
+    from src.replay_buffer import ReplayBuffer as RefReplay
+    from src.training import NeuralNetworkManager as RefManager
+    from src.training_data_generator import TrainingDataGenerator as RefGen
+
+    out = {}
+    A = 7
+    h, g, f = build_ref_nets((2, 6, 7), (4, 6, 7), A, 2, [128], [256, 128], [256, 256], seed=0)
+    out["weights_sha256"] = np.array(sd_hash(h, g, f))
+    gen_cfg = rcfg.TrainingDataGeneratorConfig(
+        num_episodes=3, max_steps_per_episode=9, total_time=0, epsilon=0.6, epsilon_decay=1.0, min_epsilon=0.25,
+        mcts=rcfg.MCTSConfig(selection_strategy="puct", max_iterations=12, max_time=0, model_look_ahead=1,
+                             discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
+    random.seed(5)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        episodes = RefGen(C4Env(), h, g, f, gen_cfg).generate_training_data(training_steps=0)
+    out["n_episodes"] = np.int32(len(episodes))
+    for e, ep in enumerate(episodes):
+        out[f"ep{e}_state"] = np.stack([c.state.numpy()[0] for c in ep.chunks])
+        out[f"ep{e}_policy"] = np.stack([c.policy.numpy() for c in ep.chunks])
+        out[f"ep{e}_reward"] = np.array([c.reward for c in ep.chunks], np.float64)
+        out[f"ep{e}_value"] = np.array([c.value for c in ep.chunks], np.float64)
+        out[f"ep{e}_action"] = np.array([c.best_action for c in ep.chunks], np.int64)
+
+    tcfg = rcfg.TrainingConfig(
+        learning_rate=0.01, weight_decay=1e-4, batch_size=3, replay_buffer_size=8, alpha=0.6, discount_factor=0.9,
+        epochs=1, betas=(0.9, 0.999), roll_ahead=2, look_back=2, mini_batch_size=3, reward_coefficient=1.0,
+        value_coefficient=0.5, policy_coefficient=0.25, min_learning_rate=0.0, total_training_steps=10,
+        lr_schedule="cosine", optimizer="sgd", momentum=0.9)
+    random.seed(9)
+    np.random.seed(9)
+    rb = RefReplay(buffer_size=8, batch_size=3, alpha=0.6, beta=1.0)
+    rb.add_episodes(episodes)
+    mgr = RefManager(tcfg, h, g, f)
+    last = mgr.train(rb)
+    out["learner_losses"] = np.array(mgr.loss_history, np.float64)
+    out["learner_last"] = np.float64(last)
+    out["learner_priorities"] = np.array([p for _, p in rb.episode_buffer], np.float64)
+    out["learner_fc_merge_bias"] = g.fc_merge.bias.detach().numpy().copy()
+    out["learner_policy_last_weight"] = f.policy_mlp[-2].weight.detach().numpy().copy()
+    out["learner_repr_weight"] = h.final_conv.weight.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "selfplay_learner.npz"), **out)
+    print("selfplay_learner.npz ok:", [len(ep.chunks) for ep in episodes], mgr.loss_history)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["trees", "c4", "data"]
+    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay"]
     if "trees" in which:
         make_trees()
     if "c4" in which:
         make_c4_mlp()
     if "data" in which:
         make_data()
+    if "selfplay" in which:
+        make_selfplay_and_learner()
