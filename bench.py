@@ -87,31 +87,44 @@ def time_kernel(fn, iters=20):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def kernel_rooflines(mcts, plan):
-    """Times the network kernels in the exact shapes one simulation round launches them and
-    returns per-kernel {seconds, flop, calls_per_sim}."""
+def mlp_flop(p):
+    return sum(2 * p.layer[i].K * p.layer[i].N for i in range(p.n_layers))
+
+
+def search_flop_per_tree(plan, S, depth):
+    """Multiply-add work the fused search kernel executes per tree (2 flop per MAC): per
+    expansion the policy head, the D x D merge product and A reward heads; per simulation
+    `depth` greedy steps (policy head, merge product, reward head) and one value head."""
+    expand = mlp_flop(plan.policy) + 2 * D * D + A * mlp_flop(plan.reward)
+    simulate = depth * (mlp_flop(plan.policy) + 2 * D * D + mlp_flop(plan.reward)) + mlp_flop(plan.value)
+    return (S + 1) * expand + S * simulate
+
+
+def kernel_rooflines(mcts, plan, step):
+    """Times (HIP events on the launch stream) the fused search kernel, which is the whole
+    step, and the per-stage network kernels in the shapes the lock-step path launches them."""
     nets, pool, G = mcts.nets, mcts.pool, mcts.G
-    def mlp_flop(p):
-        return sum(2 * p.layer[i].K * p.layer[i].N for i in range(p.n_layers))
+    out = {}
+    out["k_search[fused MCTS.run]"] = dict(s=time_kernel(step, iters=5), flop=G * search_flop_per_tree(plan, mcts.S, mcts.depth),
+                                           calls=1.0 / mcts.S)
     rows = (mcts.tree_base + 1).contiguous()
     rows_rep = rows.repeat_interleave(A)
     base = 1 + A
     next_rows = ((mcts.tree_base + base)[:, None] + mcts.arange_a[None, :]).reshape(-1).contiguous()
-    out = {}
     out["k_dynamics[expand B=G*A]"] = dict(
         s=time_kernel(lambda: nets.dynamics(pool.latent, G * A, rows=rows_rep, next_latent=pool.latent,
                                             next_rows=next_rows, reward=mcts.reward)),
-        flop=G * A * (2 * D * D + mlp_flop(plan.reward)), calls=1)
+        flop=G * A * (2 * D * D + mlp_flop(plan.reward)), calls=0)
     out["k_prediction[policy B=G]"] = dict(
         s=time_kernel(lambda: nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=mcts.prior)),
-        flop=G * mlp_flop(plan.policy), calls=2)
+        flop=G * mlp_flop(plan.policy), calls=0)
     out["k_dynamics[step B=G]"] = dict(
         s=time_kernel(lambda: nets.dynamics(pool.latent, G, rows=rows, action=mcts.act, next_latent=mcts.tmp[0],
                                             reward=mcts.rollout_t[0])),
-        flop=G * (2 * D * D + mlp_flop(plan.reward)), calls=1)
+        flop=G * (2 * D * D + mlp_flop(plan.reward)), calls=0)
     out["k_prediction[value B=G]"] = dict(
         s=time_kernel(lambda: nets.prediction(mcts.tmp[0], G, value=mcts.rollout_t[1])),
-        flop=G * mlp_flop(plan.value), calls=1)
+        flop=G * mlp_flop(plan.value), calls=0)
     return out
 
 
@@ -203,14 +216,13 @@ def main():
         "env_steps_per_sec": world * G * args.steps / dt,
     }
     if rank == 0 and not args.no_roofline:
-        ks = kernel_rooflines(mcts, nets.plan)
-        dom = max(ks, key=lambda k: ks[k]["s"] * ks[k]["calls"])
+        ks = kernel_rooflines(mcts, nets.plan, step)
+        dom = "k_search[fused MCTS.run]"
         tf = ks[dom]["flop"] / ks[dom]["s"] / 1e12
         line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                             "avg_launch_us": ks[dom]["s"] * 1e6, "flop_per_launch": ks[dom]["flop"]}
-        line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12,
-                               "launches_per_sim": v["calls"]} for k, v in ks.items()}
+        line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(g, f)
     if world > 1:

@@ -268,6 +268,39 @@ int mz_gamma_powers(double gamma, int32_t w, double *h_out);
 int mz_z_targets(const double *R, const double *V, const double *pow_tab, int32_t B, int32_t w,
                  double *z, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Whole search in one launch: MCTS.run (src/search/mcts.py:44-74) for all G trees of the pool
+ * -- root creation, root expansion, prior perturbation, S rounds of select / expand / simulate
+ * / backup, and the result -- with every network evaluation fused in (MLP-only g and f).
+ * Produces the same pool contents as the per-stage entry points driven in lock step.
+ * ------------------------------------------------------------------------------------ */
+typedef struct mz_search_params {
+    int32_t S;              /* simulations per tree (MCTSConfig.max_iterations)                */
+    int32_t depth;          /* rollout steps (MCTSConfig.model_look_ahead)                     */
+    int32_t tab_len;        /* entries of sqrt_tab / log_tab, >= S + 2                         */
+    int32_t lanes_per_tree; /* filled in by the library                                        */
+    double discount;        /* MCTSConfig.discount_factor                                      */
+    double noise_frac;      /* MCTSConfig.noise_frac                                           */
+    const double *sqrt_tab; /* device copies of mz_puct_tables                                 */
+    const double *log_tab;
+    const float *root_latent;   /* f32[G][D]   h(observation history)                          */
+    const int8_t *root_to_play; /* i8[G]                                                       */
+    const float *eta;           /* f32[G][A]   Dirichlet sample of src/search/mcts.py:91       */
+    const int32_t *rand_child;  /* i32[G][S+1] random.choice draws, column 0 = root expansion  */
+    int32_t *leaf_trace;        /* optional i32[G][S]: node selected by each simulation        */
+    int32_t *child_trace;       /* optional i32[G][S]: child the simulation started from       */
+    float *rollout_trace;       /* optional f32[G][S][depth+1]: [r_1..r_depth, v] per simulation */
+    float *prior_trace;         /* optional f32[G][S+1][A]: priors written by each expansion   */
+    unsigned long long *stamps; /* optional u64[24]: shader-clock cycles workgroup 0 spent per
+                                   stage (diagnostics; leave NULL in production)               */
+} mz_search_params;
+
+/* Requires pool->latent, pool->cap >= 1 + (S+1)*A, A <= 32.  policy f64[G][A], policy32
+ * f32[G][A], value f64[G], visits i32[G][A] as in mz_tree_result (any may be NULL). */
+int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob,
+                  const mz_search_params *prm, double *policy, float *policy32, double *value,
+                  int32_t *visits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmuzero_hip.so")
+LIB_PATH = os.environ.get("MUZERO_HIP_LIB", os.path.join(_HERE, "libmuzero_hip.so"))
 MAX_LAYERS = 8
 
 ACT = {"none": 0, "linear": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "softmax": 4}
@@ -67,6 +67,15 @@ class PackedNets(C.Structure):
                 ("merge", PackedMlp), ("reward", PackedMlp), ("value", PackedMlp), ("policy", PackedMlp)]
 
 
+class SearchParams(C.Structure):
+    _fields_ = [("S", C.c_int32), ("depth", C.c_int32), ("tab_len", C.c_int32), ("lanes_per_tree", C.c_int32),
+                ("discount", C.c_double), ("noise_frac", C.c_double), ("sqrt_tab", C.c_void_p),
+                ("log_tab", C.c_void_p), ("root_latent", C.c_void_p), ("root_to_play", C.c_void_p),
+                ("eta", C.c_void_p), ("rand_child", C.c_void_p), ("leaf_trace", C.c_void_p),
+                ("child_trace", C.c_void_p), ("rollout_trace", C.c_void_p), ("prior_trace", C.c_void_p),
+                ("stamps", C.c_void_p)]
+
+
 _LIB = None
 
 _P = C.c_void_p
@@ -93,6 +102,8 @@ _SIGS = {
     "mz_c4_reset": (C.c_int, [C.POINTER(C4State), _P, _P]),
     "mz_c4_step": (C.c_int, [C.POINTER(C4State), _P, _P, _P, _P]),
     "mz_c4_observe": (C.c_int, [C.POINTER(C4State), _P, _P, _P]),
+    "mz_search_run": (C.c_int, [C.POINTER(Pool), C.POINTER(PackedNets), _P, C.POINTER(SearchParams), _P, _P, _P, _P,
+                                _P]),
     "mz_history_push_assemble": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            _P, _P]),
     "mz_repr_pointwise": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

@@ -51,7 +51,7 @@ k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__re
     extern __shared__ __align__(16) float smem[];
     constexpr int TM = 16 * MT;
     const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
-    float *X = smem, *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
+    lds_f *X = to_lds(smem), *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
     const int row0 = blockIdx.x * TM;
     const int rows = min(TM, B - row0);
     load_rows(X, ld_in, TM, rows, M.in_features, [&](int r) -> const float * {
@@ -59,7 +59,7 @@ k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__re
         return src < 0 ? nullptr : x + src * ldx;
     });
     int ld_out;
-    const float *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    const lds_f *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
     for (int i = threadIdx.x; i < rows * N; i += kThreads) {
         const int r = i / N, c = i - r * N;
@@ -76,10 +76,12 @@ k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__rest
     extern __shared__ __align__(16) float smem[];
     constexpr int TM = 16 * MT;
     const int ld_d = lds_stride(P.D), ld_w = lds_stride(P.reward.max_width);
-    float *X = smem, *C = X + TM * ld_d, *bufA = C + TM * ld_d, *bufB = bufA + TM * ld_w;
-    int *sel = reinterpret_cast<int *>(bufB + TM * ld_w);
+    lds_f *X = to_lds(smem), *C = X + TM * ld_d, *bufA = C + TM * ld_d, *bufB = bufA + TM * ld_w;
+    lds_f *table = bufB + TM * ld_w;  // [A][Dp] per-action additive table of the merge layer
+    lds_i *sel = (lds_i *)(table + P.A * P.Dp);
     const int row0 = blockIdx.x * TM;
     const int rows = min(TM, B - row0);
+    for (int i = threadIdx.x; i < P.A * P.Dp; i += kThreads) table[i] = blob[P.action_table_off + i];
     if ((int)threadIdx.x < TM) {
         const int r = row0 + threadIdx.x;
         int a = 0;
@@ -91,7 +93,7 @@ k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__rest
         return src < 0 ? nullptr : latent + src * ld_latent;
     });
     // next = relu(W[:, :D] x + (W[:, D:] e_a + b))
-    dense_tile<MT>(X, ld_d, blob, P.merge.layer[0], C, ld_d, blob + P.action_table_off, P.Dp, sel);
+    dense_tile<MT>(X, ld_d, blob, P.merge.layer[0], C, ld_d, table, P.Dp, sel);
     if (next_latent) {
         for (int i = threadIdx.x; i < rows * P.D; i += kThreads) {
             const int r = i / P.D, c = i - r * P.D;
@@ -101,7 +103,7 @@ k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__rest
     }
     if (reward) {
         int ld_out;
-        const float *out = mlp_tile<MT>(P.reward, blob, C, ld_d, bufA, bufB, &ld_out);
+        const lds_f *out = mlp_tile<MT>(P.reward, blob, C, ld_d, bufA, bufB, &ld_out);
         if ((int)threadIdx.x < rows) reward[row0 + threadIdx.x] = out[threadIdx.x * ld_out];
     }
 }
@@ -115,7 +117,7 @@ k_prediction(mz_packed_nets P, const float *__restrict__ blob, const float *__re
     constexpr int TM = 16 * MT;
     const int ld_d = lds_stride(P.D);
     const int ld_w = lds_stride(max(P.value.max_width, P.policy.max_width));
-    float *X = smem, *bufA = X + TM * ld_d, *bufB = bufA + TM * ld_w;
+    lds_f *X = to_lds(smem), *bufA = X + TM * ld_d, *bufB = bufA + TM * ld_w;
     const int row0 = blockIdx.x * TM;
     const int rows = min(TM, B - row0);
     load_rows(X, ld_d, TM, rows, P.D, [&](int r) -> const float * {
@@ -124,9 +126,9 @@ k_prediction(mz_packed_nets P, const float *__restrict__ blob, const float *__re
     });
     int ld_out;
     if (policy || argmax) {
-        float *out = mlp_tile<MT>(P.policy, blob, X, ld_d, bufA, bufB, &ld_out);
+        lds_f *out = mlp_tile<MT>(P.policy, blob, X, ld_d, bufA, bufB, &ld_out);
         if (argmax && (int)threadIdx.x < rows) {
-            const float *p = out + threadIdx.x * ld_out;
+            const lds_f *p = out + threadIdx.x * ld_out;
             int best = 0;
             for (int i = 1; i < P.A; ++i)
                 if (p[i] > p[best]) best = i;
@@ -145,7 +147,7 @@ k_prediction(mz_packed_nets P, const float *__restrict__ blob, const float *__re
         __syncthreads();
     }
     if (value) {
-        const float *out = mlp_tile<MT>(P.value, blob, X, ld_d, bufA, bufB, &ld_out);
+        const lds_f *out = mlp_tile<MT>(P.value, blob, X, ld_d, bufA, bufB, &ld_out);
         if ((int)threadIdx.x < rows) value[row0 + threadIdx.x] = out[threadIdx.x * ld_out];
     }
 }
@@ -327,7 +329,7 @@ int mz_dynamics_forward(const mz_packed_nets *h_plan, const float *blob, const f
     hipStream_t st = (hipStream_t)stream;
     size_t per_row = 2 * (size_t)lds_stride(h_plan->D) + 2 * (size_t)lds_stride(h_plan->reward.max_width);
     return launch_by_rows(
-        B, per_row, 32 * sizeof(int),
+        B, per_row, 32 * sizeof(int) + sizeof(float) * (size_t)h_plan->A * h_plan->Dp,
         [&](size_t lds) {
             MZ_TRY(allow_lds(k_dynamics<1>, lds, "k_dynamics"));
             hipLaunchKernelGGL(k_dynamics<1>, dim3((B + 15) / 16), dim3(kThreads), lds, st, *h_plan, blob, latent,

@@ -1,7 +1,7 @@
 // Device-side building blocks of the fused fp32 MLP kernels (gfx950).
 //
-// A workgroup of kWaves wavefronts owns a tile of TM = 16*MT rows whose activations live in
-// LDS; one dense layer is   Y[TM][N] = act(X[TM][K] * W^T + b)   on v_mfma_f32_16x16x4_f32
+// A workgroup of kWaves wavefronts owns a tile of 16*MT rows whose activations live in LDS;
+// one dense layer is   Y[rows][N] = act(X[rows][K] * W^T + b)   on v_mfma_f32_16x16x4_f32
 // (exact fp32 multiply-add chains, so results differ from another fp32 GEMM only by
 // summation order).
 //
@@ -13,6 +13,17 @@
 // 16-row tile.  Lane l of MFMA k-step j then multiplies X[row l&15][kt*16 + 4*(l>>4) + j]
 // by W[col l&15][same k]: both operands agree on k, which is all the instruction needs.
 // Bias is stored padded to Np behind the tiles.
+//
+// The row tile is small (16..112 rows) and every weight is used once per workgroup, so this
+// is the "GEMV-like" regime: weights go straight from L2 to registers (no LDS staging),
+// kPrefetch k-steps ahead, a wave keeps two column tiles in flight so that the MFMA pipe
+// always has an independent accumulator to issue into, and the weight stream of a wave runs
+// on across its consecutive tiles.
+//
+// The layer functions are deliberately NOT inlined into their callers: each gets its own
+// register allocation (the fused search kernel calls them ~15 times per simulation round and
+// would otherwise spill).  LDS operands are passed as address-space-3 pointers so that the
+// out-of-line code still uses ds_read/ds_write rather than flat accesses.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -20,10 +31,19 @@
 
 namespace mzd {
 
-constexpr int kWaves = 4;
+constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
+constexpr int kPrefetch = 4;  // k-steps of weights held in registers ahead of the MFMAs
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
+typedef __attribute__((address_space(1))) const float glb_f;    // read-only global memory (weights)
+typedef __attribute__((address_space(1))) const f32x4 glb_f4;
+
+__device__ __forceinline__ lds_f *to_lds(void *generic) { return (lds_f *)generic; }
+__device__ __forceinline__ lds_i *to_lds_i(void *generic) { return (lds_i *)generic; }
 
 __host__ __device__ inline int ceil16(int x) { return (x + 15) & ~15; }
 // LDS row stride (floats) for a buffer holding rows of `width` valid floats: padded to a
@@ -39,64 +59,382 @@ __device__ __forceinline__ float activate(float v, int act) {
     }
 }
 
-// One dense layer over the workgroup's row tile.  Xs: LDS [16*MT][ldx], columns [K, Kp)
-// must be zero.  Ys: LDS [16*MT][ldy]; columns [N, Np) are written as act(0 + 0) of the
-// zero-padded weights, i.e. 0 for none/relu/tanh -- callers that chain a sigmoid layer
-// must not rely on the padding (sigmoid(0) = 0.5), so the padding is re-zeroed here.
-// `row_add` (optional, global memory): per-row additive table row_add[row_sel[r]][n] added
-// before the activation (the action-embedding contribution of the dynamics merge layer).
-// Ends with __syncthreads(): Ys is complete and Xs may be overwritten afterwards.
+// Wave-uniform values arrive in vector registers when a function is not inlined (arguments
+// travel in VGPRs); these helpers move them to scalar registers so that loop bounds, tile
+// bases and LDS bases are scalar again and control flow stays branch-based, not exec-masked.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *uni_ptr(T *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ lds_f *uni_lds(const lds_f *p) {
+    return (lds_f *)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)p);
+}
+__device__ __forceinline__ lds_i *uni_lds(const lds_i *p) {
+    return (lds_i *)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)p);
+}
+
+// One output of a group of layers that read the same input rows (passed by value).
+struct DensePart {
+    int w_off, b_off;  // float offsets of the packed tiles / padded bias inside the blob
+    int N, Np, act;
+    lds_f *Ys;
+    int ldy;
+    const lds_f *row_add;  // optional additive table in LDS, indexed [row_sel[row]][col]
+    int row_add_ld;
+    const lds_i *row_sel;
+    __device__ __forceinline__ DensePart uniform() const {
+        return DensePart{uni(w_off), uni(b_off), uni(N), uni(Np), uni(act), uni_lds(Ys), uni(ldy),
+                         uni_lds(row_add), uni(row_add_ld), uni_lds(row_sel)};
+    }
+};
+__device__ __forceinline__ DensePart make_part(const mz_packed_layer &L, lds_f *Ys, int ldy, int act,
+                                               const lds_f *row_add = nullptr, int row_add_ld = 0,
+                                               const lds_i *row_sel = nullptr) {
+    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, act, Ys, ldy, row_add, row_add_ld, row_sel};
+}
+
+// Epilogue of one 16-column tile: bias, optional per-row additive table, activation, store.
+// C layout of the MFMA: column = lane & 15, row = 4*(lane >> 4) + reg.
 template <int MT>
-__device__ __forceinline__ void dense_tile(const float *Xs, int ldx, const float *__restrict__ packed,
-                                           const mz_packed_layer &L, float *Ys, int ldy,
-                                           const float *__restrict__ row_add, int row_add_ld, const int *row_sel) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float b, const DensePart &P) {
+    const int lane = threadIdx.x & 63;
     const int m = lane & 15, kq = lane >> 4;
-    const int KT = L.Kp >> 4, NT = L.Np >> 4;
-    const float4 *__restrict__ Wp = reinterpret_cast<const float4 *>(packed + L.w_off);
-    const float *__restrict__ bias = packed + L.b_off;
-    for (int nt = wave; nt < NT; nt += kWaves) {
-        f32x4 acc[MT];
+    const int col = nt * 16 + m;
+    const bool real_col = col < P.N;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float4 *wp = Wp + (size_t)nt * KT * 64 + lane;
-        const float *xp = Xs + m * ldx + 4 * kq;
-#pragma unroll 2
-        for (int kt = 0; kt < KT; ++kt) {
-            const float4 w = wp[(size_t)kt * 64];
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float4 x = *reinterpret_cast<const float4 *>(xp + mt * 16 * ldx + kt * 16);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, w.z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, w.w, acc[mt], 0, 0, 0);
-            }
-        }
-        // C layout: column = lane & 15, row = 4*(lane >> 4) + reg
-        const int col = nt * 16 + m;
-        const float b = bias[col];
-        const bool real_col = col < L.N;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = mt * 16 + kq * 4 + r;
-                float v = acc[mt][r] + b;
-                if (row_add != nullptr && real_col) v += row_add[(size_t)row_sel[row] * row_add_ld + col];
-                Ys[row * ldy + col] = real_col ? activate(v, L.act) : 0.0f;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + kq * 4 + r;
+            float v = acc[mt][r] + b;
+            if (P.row_add != nullptr && real_col) v += P.row_add[P.row_sel[row] * P.row_add_ld + col];
+            P.Ys[row * P.ldy + col] = real_col ? activate(v, P.act) : 0.0f;
         }
     }
+}
+
+// A-operand sources.  operator()(mt, m, koff) returns X[row 16*mt + m][koff .. koff+3].
+struct LdsRows {  // activations resident in LDS
+    const lds_f *x;
+    int ld;
+    __device__ __forceinline__ LdsRows uniform() const { return LdsRows{uni_lds(x), uni(ld)}; }
+    __device__ __forceinline__ f32x4 operator()(int mt, int m, int koff) const {
+        return *reinterpret_cast<const lds_f4 *>(x + (mt * 16 + m) * ld + koff);
+    }
+};
+// Rows of the expansion: row (mt = action a, m = tree t) = relu(z[t][:] + table[a][:]), formed
+// on the fly from the merge pre-activation z (LDS, 16 rows) and the per-action table (LDS), so
+// the A*16 child latents never need an LDS image of their own.
+struct ChildRows {
+    const lds_f *z;
+    int ldz;
+    const lds_f *table;
+    int ldt;
+    __device__ __forceinline__ ChildRows uniform() const { return ChildRows{uni_lds(z), uni(ldz), uni_lds(table), uni(ldt)}; }
+    __device__ __forceinline__ f32x4 operator()(int mt, int m, int koff) const {
+        const f32x4 a = *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff);
+        const f32x4 b = *reinterpret_cast<const lds_f4 *>(table + mt * ldt + koff);
+        f32x4 r;
+        r.x = fmaxf(a.x + b.x, 0.f);
+        r.y = fmaxf(a.y + b.y, 0.f);
+        r.z = fmaxf(a.z + b.z, 0.f);
+        r.w = fmaxf(a.w + b.w, 0.f);
+        return r;
+    }
+};
+
+// Several dense layers over the SAME input rows in one pass (e.g. the policy head's first
+// layer and the dynamics merge layer both read the latent): their column tiles form one list
+// that is split evenly over the waves, so narrow layers do not leave waves idle and the
+// workgroup pays one barrier for all of them.  All parts must share Kp.
+//
+// A wave walks its tiles NTW at a time.  The weights of those tiles are consumed as a stream
+// of batches of kPrefetch k-steps; two register sets alternate so that batch i+1 is in flight
+// (global_load_dwordx4, 1 KiB per tile and k-step) while the MFMAs of batch i issue, and the
+// stream runs on from one tile group into the next without draining.  Every loop bound below
+// is wave-uniform (the wave index goes through readfirstlane), so control flow is scalar.
+template <int MT, int NTW, int NPARTS, typename Rows>
+__device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__restrict__ packed,
+                                             const DensePart (&parts)[NPARTS], int KT, int first_tile, int ngroups) {
+#ifdef MZ_EXP_EMPTY
+    return;
+#endif
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    const int nb = (KT + kPrefetch - 1) / kPrefetch;  // batches per tile group
+    const int total = ngroups * nb;
+    auto locate = [&](int tl, int &part, int &nt) {
+        part = 0;
+        nt = tl;
+#pragma unroll
+        for (int i = 0; i < NPARTS - 1; ++i) {
+            const int n = parts[i].Np >> 4;
+            if (part == i && nt >= n) {
+                nt -= n;
+                part = i + 1;
+            }
+        }
+    };
+    // fetch cursor: (group fg, batch fb) of the next weight batch to request
+    int fg = 0, fb = 0;
+    glb_f4 *fbase[NTW];
+    auto fetch_bases = [&]() {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            int part, nt;
+            locate(first_tile + fg * NTW + t, part, nt);
+            fbase[t] = (glb_f4 *)(packed + parts[part].w_off) + (size_t)nt * KT * 64;
+        }
+    };
+    fetch_bases();
+    auto fetch = [&](f32x4 (&w)[NTW][kPrefetch]) {
+        const int kt0 = fb * kPrefetch;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int j = 0; j < kPrefetch; ++j) {
+#ifdef MZ_EXP_NOLOAD
+                w[t][j] = f32x4{1.f, 2.f, 3.f, (float)(kt0 + j + lane)};
+#else
+                w[t][j] = fbase[t][(size_t)min(kt0 + j, KT - 1) * 64 + lane];
+#endif
+            }
+        if (++fb == nb) {
+            fb = 0;
+            if (++fg < ngroups) fetch_bases();
+        }
+    };
+    // compute cursor
+    int cg = 0, cb = 0;
+    f32x4 acc[NTW][MT];
+    float bias[NTW];
+    int c_part[NTW], c_nt[NTW];
+    auto compute = [&](const f32x4 (&w)[NTW][kPrefetch]) {
+        const int kt0 = cb * kPrefetch;
+        if (cb == 0) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                locate(first_tile + cg * NTW + t, c_part[t], c_nt[t]);
+                // requested now, needed only by the epilogue after the last batch
+                bias[t] = ((glb_f *)packed)[parts[c_part[t]].b_off + c_nt[t] * 16 + m];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if constexpr (MT <= 2) {
+            // few row tiles: fetch the A operands of the whole batch first so their LDS
+            // latency overlaps the MFMAs instead of preceding every k-step
+            f32x4 x[kPrefetch][MT];
+#pragma unroll
+            for (int j = 0; j < kPrefetch; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) x[j][mt] = rows(mt, m, min(kt0 + j, KT - 1) * 16 + 4 * kq);
+#pragma unroll
+            for (int j = 0; j < kPrefetch; ++j) {
+                if (kt0 + j < KT) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) {
+#ifdef MZ_EXP_NOMFMA
+                            acc[t][mt] += x[j][mt] * w[t][j];
+#else
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
+#endif
+                        }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPrefetch; ++j) {
+                if (kt0 + j < KT) {
+                    f32x4 x[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) x[mt] = rows(mt, m, (kt0 + j) * 16 + 4 * kq);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) {
+#ifdef MZ_EXP_NOMFMA
+                            acc[t][mt] += x[mt] * w[t][j];
+#else
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
+#endif
+                        }
+                }
+            }
+        }
+        if (++cb == nb) {
+            cb = 0;
+            ++cg;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+#ifdef MZ_EXP_NOEPI
+                if (acc[t][0].x == 123.456f) store_tile<MT>(acc[t], c_nt[t], bias[t], parts[c_part[t]]);
+#else
+                store_tile<MT>(acc[t], c_nt[t], bias[t], parts[c_part[t]]);
+#endif
+            }
+        }
+    };
+    f32x4 wa[NTW][kPrefetch], wb[NTW][kPrefetch];
+    fetch(wa);
+    for (int i = 0; i < total; i += 2) {
+        if (i + 1 < total) fetch(wb);
+        compute(wa);
+        if (i + 2 < total) fetch(wa);
+        if (i + 1 < total) compute(wb);
+    }
+}
+
+// Entry points (not inlined: own register allocation).  Kp is shared by all parts.  No
+// trailing barrier.
+template <int MT, int NPARTS, typename Rows>
+__device__ __forceinline__ void dense_group_body(const Rows &rows, const float *packed, int Kp,
+                                                 const DensePart (&parts)[NPARTS]) {
+    const int wave = uni(threadIdx.x >> 6);
+    const int KT = Kp >> 4;
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < NPARTS; ++i) total += parts[i].Np >> 4;
+    // tiles are dealt as evenly as possible: waves w and w+4 usually share a SIMD, so the
+    // larger shares go to the first waves and every SIMD ends up with nearly the same count
+    const int share = total / kWaves, extra = total - share * kWaves;
+    const int first = wave * share + min(wave, extra);
+    const int count = share + (wave < extra ? 1 : 0);
+    if (count <= 0) return;
+    const int pairs = count >> 1;
+    if (pairs > 0) stream_tiles<MT, 2, NPARTS>(rows, packed, parts, KT, first, pairs);
+    if (count & 1) stream_tiles<MT, 1, NPARTS>(rows, packed, parts, KT, first + 2 * pairs, 1);
+}
+template <int MT, typename Rows>
+__device__ __noinline__ void dense_group1(Rows rows, const float *packed, int Kp, DensePart p0) {
+    const DensePart parts[1] = {p0.uniform()};
+    dense_group_body<MT, 1>(rows.uniform(), uni_ptr(packed), uni(Kp), parts);
+}
+template <int MT, typename Rows>
+__device__ __noinline__ void dense_group2(Rows rows, const float *packed, int Kp, DensePart p0, DensePart p1) {
+    const DensePart parts[2] = {p0.uniform(), p1.uniform()};
+    dense_group_body<MT, 2>(rows.uniform(), uni_ptr(packed), uni(Kp), parts);
+}
+
+// Weight sources of dense_narrow: chunk q (4 consecutive k) of output column `col`.
+struct PackedNarrowWeights {  // straight from the packed blob in global memory
+    const f32x4 *wp;
+    const float *bias;
+    __device__ __forceinline__ PackedNarrowWeights uniform() const { return PackedNarrowWeights{uni_ptr(wp), uni_ptr(bias)}; }
+    __device__ __forceinline__ f32x4 operator()(int q, int col) const { return ((glb_f4 *)wp)[(size_t)(q >> 2) * 64 + (q & 3) * 16 + col]; }
+    __device__ __forceinline__ float b(int col) const { return ((glb_f *)bias)[col]; }
+};
+struct LdsNarrowWeights {  // compact copy [Kp/4][N] of float4 + 8 bias floats staged in LDS
+    const lds_f *wl;
+    int N, quads;
+    __device__ __forceinline__ LdsNarrowWeights uniform() const { return LdsNarrowWeights{uni_lds(wl), uni(N), uni(quads)}; }
+    __device__ __forceinline__ f32x4 operator()(int q, int col) const {
+        return *reinterpret_cast<const lds_f4 *>(wl + (q * N + col) * 4);
+    }
+    __device__ __forceinline__ float b(int col) const { return wl[quads * N * 4 + col]; }
+};
+
+// Narrow layers (N <= 8: value/reward scalars, policy logits): a 16-wide MFMA tile would idle
+// all but one wave, so these run on the vector ALU instead.  Four adjacent lanes share one
+// output (row, col), each summing a quarter of K as float4 dot products, then a lane
+// exchange adds the quarters.  The summation order is fixed by this function alone, so the
+// result does not depend on where the weights are fetched from.  No trailing barrier.
+template <typename Weights>
+__device__ __noinline__ void dense_narrow(const lds_f *Xs_, int ldx_, int rows_, Weights wf_, int Kp_, int N_, int act_,
+                                          lds_f *Ys_, int ldy_) {
+    const lds_f *Xs = uni_lds(Xs_);
+    lds_f *Ys = uni_lds(Ys_);
+    const int ldx = uni(ldx_), rows = uni(rows_), Kp = uni(Kp_), N = uni(N_), act = uni(act_), ldy = uni(ldy_);
+    const Weights wf = wf_.uniform();
+    const int quads = Kp >> 2;  // float4 chunks along K
+    const int outputs = rows * N;
+    for (int o0 = 0; o0 < outputs; o0 += kThreads / 4) {
+        const int o = o0 + (threadIdx.x >> 2);
+        const int part = threadIdx.x & 3;
+        float s = 0.0f;
+        int row = 0, col = 0;
+        if (o < outputs) {
+            row = o / N;
+            col = o - row * N;
+            const lds_f *x = Xs + row * ldx;
+#pragma unroll 4
+            for (int q = part; q < quads; q += 4) {
+                const f32x4 w = wf(q, col);
+                const f32x4 v = *reinterpret_cast<const lds_f4 *>(x + 4 * q);
+                s = fmaf(v.x, w.x, s);
+                s = fmaf(v.y, w.y, s);
+                s = fmaf(v.z, w.z, s);
+                s = fmaf(v.w, w.w, s);
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (o < outputs && part == 0) Ys[row * ldy + col] = activate(s + wf.b(col), act);
+    }
+    // zero the padding columns so a following layer may read whole 16-float chunks
+    const int pad = ceil16(N) - N;
+    for (int i = threadIdx.x; i < rows * pad; i += kThreads) {
+        const int r = i / pad, c = N + i % pad;
+        Ys[r * ldy + c] = 0.0f;
+    }
+}
+
+// Copies a narrow layer's weights and bias into LDS in the layout LdsNarrowWeights reads:
+// [Kp/4][N] float4 followed by 8 bias floats.
+__host__ __device__ inline int narrow_lds_floats(const mz_packed_layer &L) { return (L.Kp >> 2) * L.N * 4 + 8; }
+__device__ __forceinline__ void stage_narrow(const float *__restrict__ packed, const mz_packed_layer &L, lds_f *dst) {
+    const int quads = L.Kp >> 2;
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(packed + L.w_off);
+    for (int i = threadIdx.x; i < quads * L.N; i += kThreads) {
+        const int q = i / L.N, col = i - q * L.N;
+        *reinterpret_cast<lds_f4 *>(dst + i * 4) = wp[(size_t)(q >> 2) * 64 + (q & 3) * 16 + col];
+    }
+    for (int i = threadIdx.x; i < 8; i += kThreads) dst[quads * L.N * 4 + i] = (i < L.N) ? packed[L.b_off + i] : 0.0f;
+}
+
+// One dense layer over the workgroup's row tile.  Xs: LDS [16*MT][ldx], columns [K, Kp)
+// must be zero.  Ys: LDS [16*MT][ldy]; columns [N, Np) are written as zero.
+// `row_add` (optional, LDS): per-row additive table row_add[row_sel[r]][n] added before the
+// activation (the action-embedding contribution of the dynamics merge layer).
+// `narrow_lds` (optional): LDS copy of a narrow layer's weights made by stage_narrow.
+// Ends with __syncthreads(): Ys is complete and Xs may be overwritten afterwards.
+template <int MT>
+__device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float *__restrict__ packed,
+                                           const mz_packed_layer &L, lds_f *Ys, int ldy, const lds_f *row_add = nullptr,
+                                           int row_add_ld = 0, const lds_i *row_sel = nullptr,
+                                           const lds_f *narrow_lds = nullptr) {
+    if (L.N <= 8 && row_add == nullptr) {
+        if (narrow_lds)
+            dense_narrow(Xs, ldx, 16 * MT, LdsNarrowWeights{narrow_lds, L.N, L.Kp >> 2}, L.Kp, L.N, L.act, Ys, ldy);
+        else
+            dense_narrow(Xs, ldx, 16 * MT,
+                         PackedNarrowWeights{reinterpret_cast<const f32x4 *>(packed + L.w_off), packed + L.b_off}, L.Kp,
+                         L.N, L.act, Ys, ldy);
+        __syncthreads();
+        return;
+    }
+    dense_group1<MT>(LdsRows{Xs, ldx}, packed, L.Kp, make_part(L, Ys, ldy, L.act, row_add, row_add_ld, row_sel));
     __syncthreads();
 }
 
 // In-place softmax over the first N columns of each of `rows` LDS rows, applied `times`
 // times (torch.softmax semantics: subtract the row maximum, exp, normalise).  One lane per
 // row; N is the action count (small).  Ends with __syncthreads().
-__device__ __forceinline__ void softmax_rows(float *Ys, int ldy, int rows, int N, int times) {
+__device__ __forceinline__ void softmax_rows(lds_f *Ys, int ldy, int rows, int N, int times) {
     if ((int)threadIdx.x < rows) {
-        float *y = Ys + threadIdx.x * ldy;
+        lds_f *y = Ys + threadIdx.x * ldy;
         for (int t = 0; t < times; ++t) {
             float mx = y[0];
             for (int i = 1; i < N; ++i) mx = fmaxf(mx, y[i]);
@@ -116,15 +454,15 @@ __device__ __forceinline__ void softmax_rows(float *Ys, int ldy, int rows, int N
 // Returns the buffer that holds the output.  A final MZ_ACT_SOFTMAX layer is computed as a
 // linear layer followed by softmax_rows.
 template <int MT>
-__device__ __forceinline__ float *mlp_tile(const mz_packed_mlp &M, const float *__restrict__ packed, float *in_buf,
-                                           int in_ld, float *buf_a, float *buf_b, int *out_ld) {
-    float *src = in_buf;
+__device__ __forceinline__ lds_f *mlp_tile(const mz_packed_mlp &M, const float *__restrict__ packed, lds_f *in_buf,
+                                           int in_ld, lds_f *buf_a, lds_f *buf_b, int *out_ld) {
+    lds_f *src = in_buf;
     int ld = in_ld;
-    float *dst = buf_a;
+    lds_f *dst = buf_a;
     for (int i = 0; i < M.n_layers; ++i) {
         const mz_packed_layer &L = M.layer[i];
         const int ldo = lds_stride(L.N);
-        dense_tile<MT>(src, ld, packed, L, dst, ldo, nullptr, 0, nullptr);
+        dense_tile<MT>(src, ld, packed, L, dst, ldo);
         if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, 16 * MT, L.N, 1);
         src = dst;
         ld = ldo;
@@ -137,7 +475,7 @@ __device__ __forceinline__ float *mlp_tile(const mz_packed_mlp &M, const float *
 // Cooperative load of up to `rows` global rows (row r from src + row_index(r)*src_ld) into
 // an LDS tile [TM][ld], zero-filling columns [K, ld) and rows >= rows.
 template <typename RowPtr>
-__device__ __forceinline__ void load_rows(float *Xs, int ld, int TM, int rows, int K, RowPtr row_ptr) {
+__device__ __forceinline__ void load_rows(lds_f *Xs, int ld, int TM, int rows, int K, RowPtr row_ptr) {
     for (int i = threadIdx.x; i < TM * ld; i += kThreads) {
         const int r = i / ld, c = i - r * ld;
         float v = 0.0f;

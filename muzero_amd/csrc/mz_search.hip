@@ -1,0 +1,501 @@
+// Fused search kernel for gfx950: one launch runs a whole MCTS.run (src/search/mcts.py:44-74)
+// for G trees.  A 512-thread workgroup owns 16 trees for all S simulations -- trees never
+// interact, so there is no inter-workgroup communication and no grid-wide barrier; the only
+// synchronisation is __syncthreads() between the stages of one simulation round.
+//
+// Per round and workgroup (16 trees = one MFMA row tile):
+//   select      16 lane groups walk their trees (DPP/ballot argmax, tables in LDS)
+//   expand      leaf latents -> LDS; {policy layer 1 | merge layer W[:, :D]} in one MFMA pass,
+//               remaining policy layers, softmax twice -> priors; child latents
+//               relu(z + table[a]) streamed to the node pool; reward MLP over all 16*A children
+//               with the child rows formed on the fly from z and the per-action table
+//   commit      child records written to the pool (root: priors perturbed by eta)
+//   simulate    depth x {policy -> first-max action -> merge -> reward}, then value
+//   backup      one lane per tree: discounted return, path update
+// Weights are read from L2 in the packed MFMA layout (mz_mlp_device.h); activations, priors,
+// rewards and rollouts stay in LDS; the node pool in HBM receives exactly the records the
+// stand-alone kernels would write, so both paths are interchangeable and comparable.
+//
+// Compiled with -ffp-contract=off (tree arithmetic is bit-exact by contract).
+#include <algorithm>
+
+#include "mz_common.h"
+#include "mz_mlp_device.h"
+#include "mz_tree_device.h"
+
+using namespace mzd;
+
+namespace {
+
+constexpr int kTrees = 16;  // trees per workgroup = one MFMA row tile
+
+constexpr int kPathCap = 16;  // select records the first kPathCap levels of its path in LDS
+
+struct Lds {
+    int ld_d, ld_h, ld_r, rows_r, tab_rows;
+    size_t x, z, tab, h1, h2, r1, r2, rout, prior, rew, roll, ints, path, tabs, total;  // byte offsets
+    int narrow[3][MZ_MAX_LAYERS];  // byte offset of a narrow layer's LDS weight copy (policy, value, reward), or -1
+};
+
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+__host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int depth, int tab_len) {
+    Lds L;
+    const int A = P.A;
+    L.ld_d = lds_stride(P.D);
+    int wh = P.policy.max_width > P.value.max_width ? P.policy.max_width : P.value.max_width;
+    if (P.reward.max_width > wh) wh = P.reward.max_width;
+    L.ld_h = lds_stride(wh);
+    const bool first_reward_narrow = P.reward.layer[0].N <= 8;
+    L.ld_r = lds_stride((first_reward_narrow && P.D > P.reward.max_width) ? P.D : P.reward.max_width);
+    L.rows_r = kTrees * mtc;
+    L.tab_rows = ((A + mtc - 1) / mtc) * mtc;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    L.x = take(sizeof(float) * kTrees * L.ld_d);
+    L.z = take(sizeof(float) * kTrees * L.ld_d);
+    L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
+    L.h1 = take(sizeof(float) * kTrees * L.ld_h);
+    L.h2 = take(sizeof(float) * kTrees * L.ld_h);
+    L.r1 = take(sizeof(float) * L.rows_r * L.ld_r);
+    L.r2 = take(P.reward.n_layers >= 3 ? sizeof(float) * L.rows_r * L.ld_r : 0);
+    L.rout = take(sizeof(float) * L.rows_r * lds_stride(1));
+    L.prior = take(sizeof(float) * kTrees * A);
+    L.rew = take(sizeof(float) * kTrees * L.tab_rows);
+    L.roll = take(sizeof(float) * kTrees * (depth + 1));
+    L.ints = take(sizeof(int) * kTrees * 6);
+    L.path = take(sizeof(int) * kTrees * kPathCap);
+    L.tabs = take(sizeof(double) * 2 * tab_len);
+    const mz_packed_mlp *mlps[3] = {&P.policy, &P.value, &P.reward};
+    for (int m = 0; m < 3; ++m)
+        for (int i = 0; i < MZ_MAX_LAYERS; ++i) {
+            L.narrow[m][i] = -1;
+            if (i < mlps[m]->n_layers && mlps[m]->layer[i].N <= 8)
+                L.narrow[m][i] = (int)take(sizeof(float) * narrow_lds_floats(mlps[m]->layer[i]));
+        }
+    L.total = off;
+    return L;
+}
+
+// Layers [first, n) of an MLP over the workgroup's 16 rows, ping-ponging h1/h2.
+__device__ __forceinline__ lds_f *mlp16(const mz_packed_mlp &M, int first, const float *__restrict__ blob, lds_f *src,
+                                        int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
+                                        const int (&narrow)[MZ_MAX_LAYERS]) {
+    for (int i = first; i < M.n_layers; ++i) {
+        const mz_packed_layer &L = M.layer[i];
+        lds_f *dst = (src == h1) ? h2 : h1;
+        const int ldo = lds_stride(L.N);
+        const lds_f *nw = narrow[i] >= 0 ? to_lds(smem + narrow[i]) : nullptr;
+        dense_tile<1>(src, ld, blob, L, dst, ldo, nullptr, 0, nullptr, nw);
+        if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, kTrees, L.N, 1);
+        src = dst;
+        ld = ldo;
+    }
+    *out_ld = ld;
+    return src;
+}
+
+template <int MTC>
+__global__ void __launch_bounds__(kThreads)
+k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_params q, Lds L,
+         double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
+         int32_t *__restrict__ visits) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    lds_f *X = to_lds(smem_raw + L.x);
+    lds_f *Z = to_lds(smem_raw + L.z);
+    lds_f *Tab = to_lds(smem_raw + L.tab);
+    lds_f *H1 = to_lds(smem_raw + L.h1);
+    lds_f *H2 = to_lds(smem_raw + L.h2);
+    lds_f *R1 = to_lds(smem_raw + L.r1);
+    lds_f *R2 = to_lds(smem_raw + L.r2);
+    lds_f *Rout = to_lds(smem_raw + L.rout);
+    lds_f *s_prior = to_lds(smem_raw + L.prior);
+    lds_f *s_rew = to_lds(smem_raw + L.rew);
+    lds_f *s_roll = to_lds(smem_raw + L.roll);
+    lds_i *s_leaf = to_lds_i(smem_raw + L.ints);
+    lds_i *s_child = s_leaf + kTrees;
+    lds_i *s_act = s_child + kTrees;
+    lds_i *s_leaf_tp = s_act + kTrees;
+    lds_i *s_depth = s_leaf_tp + kTrees;
+    lds_i *s_root = s_depth + kTrees;  // root to_play per tree
+    int *s_path = reinterpret_cast<int *>(smem_raw + L.path);
+    double *s_tab = reinterpret_cast<double *>(smem_raw + L.tabs);
+
+    // optional cycle stamps per stage (diagnostics: q.stamps == NULL in production)
+    __shared__ unsigned long long s_stamp[24];
+    unsigned long long t_prev = 0;
+    const bool stamping = q.stamps != nullptr && blockIdx.x == 0;
+    if (stamping && threadIdx.x < 24) s_stamp[threadIdx.x] = 0;
+    if (stamping && threadIdx.x == 0) t_prev = clock64();
+#define MZ_STAMP(slot)                                 \
+    if (stamping && threadIdx.x == 0) {                \
+        const unsigned long long t_now = clock64();    \
+        s_stamp[slot] += t_now - t_prev;               \
+        t_prev = t_now;                                \
+    }
+
+    const int A = P.A, D = P.D, S = q.S, depth = q.depth;
+    const int ld_d = L.ld_d;
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * kTrees;
+    const int trees = min(kTrees, p.G - g0);
+    const int lpt = q.lanes_per_tree;
+    const int ld_p1 = lds_stride(P.policy.layer[0].N);
+    // policy layer 1 -> H1 and merge pre-activation W[:, :D] x -> Z, from the same input rows
+    auto first_layers = [&](const lds_f *in) {
+        const lds_f *nw = L.narrow[0][0] >= 0 ? to_lds(smem_raw + L.narrow[0][0]) : nullptr;
+        if (P.policy.layer[0].N > 8 && P.policy.layer[0].Kp == P.merge.layer[0].Kp) {
+            dense_group2<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp,
+                            make_part(P.policy.layer[0], H1, ld_p1, P.policy.layer[0].act),
+                            make_part(P.merge.layer[0], Z, ld_d, MZ_ACT_NONE));
+            __syncthreads();
+        } else {
+            dense_tile<1>(in, ld_d, blob, P.policy.layer[0], H1, ld_p1, nullptr, 0, nullptr, nw);
+            dense_group1<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp, make_part(P.merge.layer[0], Z, ld_d, MZ_ACT_NONE));
+            __syncthreads();
+        }
+    };
+
+    // ---- one-time staging: PUCT tables, per-action table, root records ------------------
+    for (int i = tid; i < q.tab_len; i += kThreads) {
+        s_tab[i] = q.sqrt_tab[i];
+        s_tab[q.tab_len + i] = q.log_tab[i];
+    }
+    for (int i = tid; i < L.tab_rows * ld_d; i += kThreads) {
+        const int a = i / ld_d, c = i - a * ld_d;
+        Tab[i] = (a < A && c < P.Dp) ? blob[P.action_table_off + (size_t)a * P.Dp + c] : 0.0f;
+    }
+    {  // narrow layers (scalar heads, policy logits) keep their weights in LDS for the whole search
+        const mz_packed_mlp *mlps[3] = {&P.policy, &P.value, &P.reward};
+        for (int m = 0; m < 3; ++m)
+            for (int i = 0; i < mlps[m]->n_layers; ++i)
+                if (L.narrow[m][i] >= 0)
+                    stage_narrow(blob, mlps[m]->layer[i], to_lds(smem_raw + L.narrow[m][i]));
+    }
+    for (int i = tid; i < kTrees * ld_d; i += kThreads) {
+        const int t = i / ld_d, c = i - t * ld_d;
+        float v = 0.0f;
+        if (t < trees && c < D) {
+            v = q.root_latent[(size_t)(g0 + t) * D + c];
+            p.latent[((size_t)(g0 + t) * p.cap) * D + c] = v;
+        }
+        X[i] = v;
+    }
+    if (tid < kTrees) {
+        int tp = 0;
+        if (tid < trees) {
+            const size_t o = (size_t)(g0 + tid) * p.cap;
+            tp = q.root_to_play[g0 + tid];
+            p.visit[o] = 0;
+            p.value_sum[o] = 0.0;
+            p.prior[o] = 0.0;
+            p.reward[o] = 0.0f;
+            p.parent[o] = -1;
+            p.first_child[o] = -1;
+            p.to_play[o] = (int8_t)tp;
+        }
+        s_leaf[tid] = 0;
+        s_leaf_tp[tid] = tp;
+        s_root[tid] = tp;
+        s_depth[tid] = 0;
+    }
+    __syncthreads();
+    MZ_STAMP(0)  // staging
+
+    // expansion e = 0 is the root expansion (no simulation / backup follows it);
+    // expansion e >= 1 belongs to simulation s = e - 1
+    for (int e = 0; e <= S; ++e) {
+        const int base = 1 + e * A;  // pool index of this expansion's first child (lock step)
+
+        // ---- select (simulations only) + leaf latents --------------------------------------
+        if (e > 0) {
+            if (tid < kTrees * lpt) {
+                const int t = tid / lpt, a = tid % lpt;
+                int leaf = 0, dep = 0;
+                if (t < trees) {
+                    const size_t o = (size_t)(g0 + t) * p.cap;
+                    // the root's children start at node 1 and the root has e - 1 completed backups
+                    switch (lpt) {
+                        case 2: leaf = mzt::select_leaf<2>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        case 4: leaf = mzt::select_leaf<4>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        case 8: leaf = mzt::select_leaf<8>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        case 16: leaf = mzt::select_leaf<16>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        default: leaf = mzt::select_leaf<32>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                    }
+                    if (a == 0) {
+                        // a visit count outside the tables cannot happen for tab_len >= S + 2
+                        leaf = max(leaf, 0);
+                        s_leaf[t] = leaf;
+                        s_depth[t] = dep;
+                        // to_play alternates with depth below the root (src/search/nodes.py:28)
+                        s_leaf_tp[t] = (dep & 1) ? -s_root[t] : s_root[t];
+                        if (q.leaf_trace) q.leaf_trace[(size_t)(g0 + t) * S + (e - 1)] = leaf;
+                    }
+                }
+            }
+            __syncthreads();
+            MZ_STAMP(1)  // select
+            if ((D & 3) == 0) {  // 16-byte rows: one float4 per lane
+                const int q4 = ld_d >> 2;
+                for (int i = tid; i < kTrees * q4; i += kThreads) {
+                    const int t = i / q4, c = (i - t * q4) * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t < trees && c < D)
+                        v = *reinterpret_cast<const float4 *>(p.latent + ((size_t)(g0 + t) * p.cap + s_leaf[t]) * D + c);
+                    *reinterpret_cast<lds_f4 *>(X + t * ld_d + c) = f32x4{v.x, v.y, v.z, v.w};
+                }
+            } else {
+                for (int i = tid; i < kTrees * ld_d; i += kThreads) {
+                    const int t = i / ld_d, c = i - t * ld_d;
+                    X[i] = (t < trees && c < D) ? p.latent[((size_t)(g0 + t) * p.cap + s_leaf[t]) * D + c] : 0.0f;
+                }
+            }
+            __syncthreads();
+            MZ_STAMP(2)  // leaf latent gather
+        }
+
+        // ---- expand: policy layer 1 and merge layer share the input ------------------------
+        // (the merge layer's stored epilogue is a relu for the stand-alone kernel; here its
+        // pre-activation is kept and the per-action table is added afterwards)
+        first_layers(X);
+        MZ_STAMP(3)  // expand: policy layer 1 | merge
+        int ld_p;
+        lds_f *pol = mlp16(P.policy, 1, blob, H1, ld_p1, H1, H2, &ld_p, smem_raw, L.narrow[0]);
+        MZ_STAMP(4)  // expand: remaining policy layers
+        if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pol, ld_p, kTrees, A, 1);
+        softmax_rows(pol, ld_p, kTrees, A, 1);  // expand_node's extra softmax (expansion.py:27)
+        for (int i = tid; i < kTrees * A; i += kThreads) {
+            const int t = i / A, a = i - t * A;
+            const float pr = pol[t * ld_p + a];
+            s_prior[i] = pr;
+            if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + a] = pr;
+        }
+        MZ_STAMP(5)  // expand: softmax + priors
+        // child latents -> pool (coalesced along the latent)
+        // written once, read back at most a few times much later: streaming (non-temporal) stores
+        // keep them from displacing the weights and tree statistics in L2
+        if ((D & 3) == 0) {
+            const int q4 = D >> 2;
+            for (int i = tid; i < trees * A * q4; i += kThreads) {
+                const int c = (i % q4) * 4, r = i / q4;
+                const int a = r % A, t = r / A;
+                const f32x4 z = *reinterpret_cast<const lds_f4 *>(Z + t * ld_d + c);
+                const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + a * ld_d + c);
+                float *dst = p.latent + ((size_t)(g0 + t) * p.cap + base + a) * D + c;
+                __builtin_nontemporal_store(fmaxf(z.x + b.x, 0.f), dst);
+                __builtin_nontemporal_store(fmaxf(z.y + b.y, 0.f), dst + 1);
+                __builtin_nontemporal_store(fmaxf(z.z + b.z, 0.f), dst + 2);
+                __builtin_nontemporal_store(fmaxf(z.w + b.w, 0.f), dst + 3);
+            }
+        } else {
+            for (int i = tid; i < trees * A * D; i += kThreads) {
+                const int c = i % D, r = i / D;
+                const int a = r % A, t = r / A;
+                p.latent[((size_t)(g0 + t) * p.cap + base + a) * D + c] = fmaxf(Z[t * ld_d + c] + Tab[a * ld_d + c], 0.0f);
+            }
+        }
+        MZ_STAMP(6)  // expand: child latents to the pool
+        // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time
+        for (int a0 = 0; a0 < A; a0 += MTC) {
+            lds_f *src;
+            int ld, first;
+            if (P.reward.layer[0].N > 8) {
+                const mz_packed_layer &L0 = P.reward.layer[0];
+                dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp,
+                                  make_part(L0, R1, lds_stride(L0.N), L0.act));
+                __syncthreads();
+                MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
+                src = R1, ld = lds_stride(L0.N), first = 1;
+            } else {  // a reward head without hidden layers: materialise the child rows
+                for (int i = tid; i < kTrees * MTC * ld_d; i += kThreads) {
+                    const int r = i / ld_d, c = i - r * ld_d;
+                    R1[r * L.ld_r + c] = fmaxf(Z[(r % kTrees) * ld_d + c] + Tab[(a0 + r / kTrees) * ld_d + c], 0.0f);
+                }
+                __syncthreads();
+                src = R1, ld = L.ld_r, first = 0;
+            }
+            for (int i = first; i < P.reward.n_layers; ++i) {
+                const mz_packed_layer &Li = P.reward.layer[i];
+                const bool last = i == P.reward.n_layers - 1;
+                lds_f *dst = last ? Rout : (src == R1 ? R2 : R1);
+                const int ldo = lds_stride(Li.N);
+                dense_tile<MTC>(src, ld, blob, Li, dst, ldo, nullptr, 0, nullptr,
+                                L.narrow[2][i] >= 0 ? to_lds(smem_raw + L.narrow[2][i]) : nullptr);
+                src = dst, ld = ldo;
+            }
+            for (int i = tid; i < kTrees * MTC; i += kThreads) {
+                const int al = i / kTrees, t = i % kTrees;
+                s_rew[t * L.tab_rows + a0 + al] = src[i * ld];
+            }
+            __syncthreads();
+        }
+
+        MZ_STAMP(8)  // expand: remaining reward layers
+        // ---- commit child records ------------------------------------------------------------
+        for (int i = tid; i < trees * A; i += kThreads) {
+            const int t = i / A, a = i - t * A;
+            const size_t o = (size_t)(g0 + t) * p.cap;
+            float pr = s_prior[t * A + a];
+            if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
+            mzt::write_child(p, o, base, a, s_leaf[t], pr, s_rew[t * L.tab_rows + a], (int8_t)s_leaf_tp[t]);
+            if (a == 0) p.first_child[o + s_leaf[t]] = base;
+        }
+        if (e == 0) {
+            __syncthreads();
+            continue;
+        }
+
+        MZ_STAMP(9)  // commit
+        // ---- simulate from the drawn child ---------------------------------------------------
+        if (tid < kTrees) {
+            int rc = 0;
+            if (tid < trees) rc = q.rand_child[(size_t)(g0 + tid) * (S + 1) + e];
+            rc = min(max(rc, 0), A - 1);
+            s_act[tid] = rc;
+            s_child[tid] = base + rc;
+            if (q.child_trace && tid < trees) q.child_trace[(size_t)(g0 + tid) * S + (e - 1)] = base + rc;
+        }
+        __syncthreads();
+        for (int d = 0; d <= depth; ++d) {
+            // X <- relu(Z + table[action]): the drawn child for d = 0, the greedy step afterwards
+            {   // columns [D, Dp) of Z and the table are zero, so whole float4s can be processed
+                const int q4 = ld_d >> 2;
+                for (int i = tid; i < kTrees * q4; i += kThreads) {
+                    const int t = i / q4, c = (i - t * q4) * 4;
+                    const f32x4 z = *reinterpret_cast<const lds_f4 *>(Z + t * ld_d + c);
+                    const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + s_act[t] * ld_d + c);
+                    f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
+                    if (c >= P.Dp) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<lds_f4 *>(X + t * ld_d + c) = v;
+                }
+            }
+            __syncthreads();
+            MZ_STAMP(10)  // simulate: next latent
+            if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
+                int ld_o;
+                const lds_f *r = mlp16(P.reward, 0, blob, X, ld_d, H1, H2, &ld_o, smem_raw, L.narrow[2]);
+                if (tid < kTrees) s_roll[tid * (depth + 1) + (d - 1)] = r[tid * ld_o];
+                __syncthreads();
+                MZ_STAMP(11)  // simulate: reward head
+            }
+            if (d == depth) break;
+            first_layers(X);
+            MZ_STAMP(12)  // simulate: policy layer 1 | merge
+            int ld_q;
+            lds_f *pq = mlp16(P.policy, 1, blob, H1, ld_p1, H1, H2, &ld_q, smem_raw, L.narrow[0]);
+            MZ_STAMP(13)  // simulate: remaining policy layers
+            if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pq, ld_q, kTrees, A, 1);
+            if (tid < kTrees) {  // first maximum of the network's policy (simulation.py:36)
+                const lds_f *row = pq + tid * ld_q;
+                int best = 0;
+                for (int a = 1; a < A; ++a)
+                    if (row[a] > row[best]) best = a;
+                s_act[tid] = best;
+            }
+            __syncthreads();
+            MZ_STAMP(14)  // simulate: argmax
+        }
+        {
+            int ld_o;
+            const lds_f *v = mlp16(P.value, 0, blob, X, ld_d, H1, H2, &ld_o, smem_raw, L.narrow[1]);
+            if (tid < kTrees) s_roll[tid * (depth + 1) + depth] = v[tid * ld_o];
+            __syncthreads();
+            MZ_STAMP(15)  // simulate: value head
+        }
+
+        // ---- backup --------------------------------------------------------------------------
+        // The path root .. leaf was recorded by select, so its nodes are updated by independent
+        // lanes (lane i of a tree: i = 0 the drawn child, i >= 1 the node i - 1 levels above the
+        // leaf) instead of one lane chasing parent pointers.  Signs follow to_play, which
+        // alternates with depth; a root to_play of 0 makes every node equal to the leaf's.
+        if (tid < kTrees * kPathCap) {
+            const int t = tid / kPathCap, i = tid % kPathCap;
+            if (t < trees) {
+                const size_t o = (size_t)(g0 + t) * p.cap;
+                float roll[8];
+                for (int k = 0; k <= depth; ++k) roll[k] = s_roll[t * (depth + 1) + k];
+                const int dl = s_depth[t];  // depth of the leaf
+                const double ret = mzt::discounted_return(roll, depth + 1, q.discount);
+                if (i == 0 && q.rollout_trace)
+                    for (int k = 0; k <= depth; ++k) q.rollout_trace[((size_t)(g0 + t) * S + (e - 1)) * (depth + 1) + k] = roll[k];
+                if (dl + 1 <= kPathCap - 1) {
+                    if (i <= dl + 1) {
+                        const int node = (i == 0) ? s_child[t] : s_path[t * kPathCap + (dl - (i - 1))];
+                        const bool same = s_root[t] == 0 || (i >= 1 && ((i - 1) & 1) == 0);
+                        const size_t c = o + node;
+                        p.visit[c] += 1;
+                        const double add = same ? ret : -ret;
+                        p.value_sum[c] = p.value_sum[c] + add;
+                    }
+                } else if (i == 0) {  // deeper than the recorded path: walk the parent pointers
+                    mzt::backup_path(p, o, s_child[t], (int8_t)s_leaf_tp[t], ret);
+                }
+            }
+        }
+        __syncthreads();
+        MZ_STAMP(16)  // backup
+    }
+
+    // ---- result -------------------------------------------------------------------------------
+    if (tid < trees) {
+        p.n_nodes[g0 + tid] = 1 + (S + 1) * A;
+        mzt::tree_result(p, g0 + tid, policy, policy32, value, visits);
+    }
+    MZ_STAMP(17)  // result
+    if (stamping) {
+        __syncthreads();
+        if (threadIdx.x < 24) q.stamps[threadIdx.x] = s_stamp[threadIdx.x];
+    }
+#undef MZ_STAMP
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
+                  double *policy, float *policy32, double *value, int32_t *visits, void *stream) {
+    MZ_TRY(mz::check_pool(pool, true));
+    if (!plan || !blob || !prm) return mz::fail(MZ_ERR_ARG, "mz_search_run: NULL argument");
+    if (plan->D != pool->D || plan->A != pool->A)
+        return mz::fail(MZ_ERR_ARG, "mz_search_run: pool (D=%d, A=%d) and networks (D=%d, A=%d) disagree", pool->D,
+                        pool->A, plan->D, plan->A);
+    if (pool->A > 32) return mz::fail(MZ_ERR_ARG, "mz_search_run: at most 32 actions (use the per-stage entry points)");
+    if (prm->depth > 7) return mz::fail(MZ_ERR_ARG, "mz_search_run: model_look_ahead above 7 is not supported by the fused kernel");
+    if (prm->S < 0 || prm->depth < 0 || pool->cap < 1 + (prm->S + 1) * pool->A)
+        return mz::fail(MZ_ERR_ARG, "mz_search_run: pool capacity %d below 1 + (S+1)*A = %d", pool->cap,
+                        1 + (prm->S + 1) * pool->A);
+    if (!prm->root_latent || !prm->root_to_play || !prm->eta || !prm->rand_child || !prm->sqrt_tab || !prm->log_tab)
+        return mz::fail(MZ_ERR_ARG, "mz_search_run: NULL input stream or table");
+    if (prm->tab_len < prm->S + 2 || prm->tab_len > 4096)
+        return mz::fail(MZ_ERR_ARG, "mz_search_run: tab_len must be in [S+2, 4096]");
+    mz_search_params q = *prm;
+    q.lanes_per_tree = mz::lanes_per_tree(pool->A);
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (pool->G + kTrees - 1) / kTrees;
+    const int candidates[4] = {7, 4, 2, 1};
+    for (int mtc : candidates) {
+        if (mtc > pool->A && mtc != 1) continue;
+        const Lds L = lds_layout(*plan, mtc, q.depth, q.tab_len);
+        if (L.total > 160 * 1024) continue;
+        auto launch = [&](auto kernel) {
+            if (L.total > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+                if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_search: cannot enable %zu bytes of LDS: %s", L.total, hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), L.total, st, *pool, *plan, blob, q, L, policy, policy32,
+                               value, visits);
+            return mz::check_launch("k_search");
+        };
+        switch (mtc) {
+            case 7: return launch(k_search<7>);
+            case 4: return launch(k_search<4>);
+            case 2: return launch(k_search<2>);
+            default: return launch(k_search<1>);
+        }
+    }
+    return mz::fail(MZ_ERR_ARG, "mz_search_run: networks too wide for the LDS-resident search kernel");
+}
+
+}  // extern "C"

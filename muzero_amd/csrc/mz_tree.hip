@@ -13,33 +13,11 @@
 #include <type_traits>
 
 #include "mz_common.h"
+#include "mz_tree_device.h"
 
 namespace {
 
 constexpr int kBlock = 64;  // one wavefront per block: spreads G*LPT/64 blocks over all CUs
-
-// ---------------------------------------------------------------- lane exchange helpers
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double max_nan_last(double a, double b) { return b > a ? b : a; }
-
-// Maximum over the LPT lanes of a group; every lane of the group receives it.
-template <int LPT>
-__device__ __forceinline__ double group_max(double v) {
-    v = max_nan_last(v, dpp_f64<0xB1>(v));                          // quad_perm [1,0,3,2]
-    if constexpr (LPT > 2) v = max_nan_last(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
-    if constexpr (LPT > 4) v = max_nan_last(v, dpp_f64<0x141>(v));  // row_half_mirror
-    if constexpr (LPT > 8) v = max_nan_last(v, dpp_f64<0x140>(v));  // row_mirror
-    if constexpr (LPT > 16) v = max_nan_last(v, __shfl_xor(v, 16, 64));
-    if constexpr (LPT > 32) v = max_nan_last(v, __shfl_xor(v, 32, 64));
-    return v;
-}
 
 // ---------------------------------------------------------------- kernels
 __global__ void k_init(mz_pool p, const int8_t *__restrict__ root_to_play) {
@@ -101,57 +79,10 @@ __global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const d
     const int g = t / LPT;
     const int a = t % LPT;
     if (g >= p.G) return;
-    const int lane = threadIdx.x & 63;
-    const int group_lane0 = lane - a;
-    const size_t o = (size_t)g * p.cap;
-    const bool child_lane = a < p.A;
-    const bool root_f32 = flags & 1;
-
-    int node = 0, depth = 0;
-    int fc = p.first_child[o];
-    int n_parent = p.visit[o];
-    bool failed = false;
-    while (fc >= 0 && depth < p.cap) {
-        int n = 0, cfc = -1;
-        double w = 0.0, pr = 0.0;
-        if (child_lane) {
-            size_t c = o + fc + a;
-            n = p.visit[c];
-            w = p.value_sum[c];
-            pr = p.prior[c];
-            cfc = p.first_child[c];
-        }
-        const bool bad = n_parent >= tab_len || n_parent < 0 || n >= tab_len || n < 0;
-        if ((__ballot(bad) >> group_lane0) & ((LPT == 64) ? ~0ull : ((1ull << LPT) - 1))) {
-            failed = true;  // a visit count outside the lookup tables: report leaf = -1
-            break;
-        }
-        double score = -__builtin_inf();
-        if (child_lane) {
-            double pb = s_tab[n_parent] / (double)(n + 1);
-            pb = pb * s_tab[tab_len + n];
-            if (node == 0 && root_f32) {
-                float ps = (float)pb * (float)pr;
-                float sc = ps;
-                if (n > 0) sc = (float)(w / (double)n) + ps;
-                score = (double)sc;
-            } else {
-                double ps = pb * pr;
-                score = (n > 0) ? (w / (double)n + ps) : (0.0 + ps);
-            }
-        }
-        const double best = group_max<LPT>(score);
-        unsigned long long hit = __ballot(child_lane && score == best);
-        hit = (hit >> group_lane0) & ((LPT == 64) ? ~0ull : ((1ull << LPT) - 1));
-        // all-NaN scores leave no hit: fall back to child 0 like max() keeping its first item
-        const int best_a = hit ? (__ffsll((long long)hit) - 1) : 0;
-        node = fc + best_a;
-        n_parent = __shfl(n, group_lane0 + best_a, 64);
-        fc = __shfl(cfc, group_lane0 + best_a, 64);
-        ++depth;
-    }
+    int depth = 0;
+    const int leaf = mzt::select_leaf<LPT>(p, (size_t)g * p.cap, a, s_tab, tab_len, flags & 1, &depth);
     if (a == 0) {
-        out_leaf[g] = failed ? -1 : node;
+        out_leaf[g] = leaf;
         if (out_depth) out_depth[g] = depth;
     }
 }
@@ -169,16 +100,8 @@ __global__ void k_expand_commit(mz_pool p, const int32_t *__restrict__ leaf, con
     const int base = p.n_nodes[g];
     const int lf = leaf[g];
     const bool ok = lf >= 0 && lf < base && base + p.A <= p.cap && p.first_child[o + lf] < 0;
-    if (ok && a < p.A) {
-        size_t c = o + base + a;
-        p.visit[c] = 0;
-        p.value_sum[c] = 0.0;
-        p.prior[c] = (double)prior[(size_t)g * p.A + a];
-        p.reward[c] = reward[(size_t)g * p.A + a];
-        p.parent[c] = lf;
-        p.first_child[c] = -1;
-        p.to_play[c] = (int8_t)(-p.to_play[o + lf]);
-    }
+    if (ok && a < p.A)
+        mzt::write_child(p, o, base, a, lf, prior[(size_t)g * p.A + a], reward[(size_t)g * p.A + a], p.to_play[o + lf]);
     // every lane of the group has read n_nodes / first_child before lane 0 rewrites them
     __builtin_amdgcn_wave_barrier();
     if (a == 0) {
@@ -201,12 +124,7 @@ __global__ void k_root_noise(mz_pool p, const float *__restrict__ eta, double no
     size_t o = (size_t)g * p.cap;
     int fc = p.first_child[o];
     if (fc < 0) return;
-    double pr = p.prior[o + fc + a];
-    float keep = (float)((1.0 - noise_frac) * pr);
-    float mix = (float)noise_frac * eta[(size_t)g * p.A + a];
-    float add = keep + mix;
-    float out = (float)pr + add;
-    p.prior[o + fc + a] = (double)out;
+    p.prior[o + fc + a] = (double)mzt::noisy_prior(p.prior[o + fc + a], eta[(size_t)g * p.A + a], noise_frac);
 }
 
 // src/search/backpropagation.py:9-18.  One lane per tree: the path is a pointer chase of
@@ -219,19 +137,8 @@ __global__ void k_backup(mz_pool p, const int32_t *__restrict__ child, const int
     int lf = leaf[g];
     if (node < 0 || lf < 0) return;
     size_t o = (size_t)g * p.cap;
-    double ret = 0.0;
-    for (int i = n_rollout - 1; i >= 0; --i) {
-        double m = discount * ret;
-        ret = (double)rollout[(size_t)g * n_rollout + i] + m;
-    }
-    const int8_t leaf_tp = p.to_play[o + lf];
-    for (int steps = 0; node >= 0 && steps < p.cap; ++steps) {
-        size_t c = o + node;
-        p.visit[c] += 1;
-        double add = (p.to_play[c] == leaf_tp) ? ret : -ret;
-        p.value_sum[c] = p.value_sum[c] + add;
-        node = p.parent[c];
-    }
+    const double ret = mzt::discounted_return(rollout + (size_t)g * n_rollout, n_rollout, discount);
+    mzt::backup_path(p, o, node, p.to_play[o + lf], ret);
 }
 
 // src/search/mcts.py:71-72,97-103.
@@ -239,18 +146,7 @@ __global__ void k_result(mz_pool p, double *__restrict__ policy, float *__restri
                          double *__restrict__ value, int32_t *__restrict__ visits) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.G) return;
-    size_t o = (size_t)g * p.cap;
-    int fc = p.first_child[o];
-    if (value) value[g] = p.value_sum[o] / (double)p.visit[o];
-    if (fc < 0) return;
-    double s = 0.0;
-    for (int a = 0; a < p.A; ++a) s = s + exp(p.value_sum[o + fc + a]);
-    for (int a = 0; a < p.A; ++a) {
-        double e = exp(p.value_sum[o + fc + a]) / s;
-        if (policy) policy[(size_t)g * p.A + a] = e;
-        if (policy32) policy32[(size_t)g * p.A + a] = (float)e;
-        if (visits) visits[(size_t)g * p.A + a] = p.visit[o + fc + a];
-    }
+    mzt::tree_result(p, g, policy, policy32, value, visits);
 }
 
 template <typename F>

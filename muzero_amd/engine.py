@@ -203,6 +203,7 @@ class BatchedMCTS:
         self.rollout_t = torch.zeros((self.depth + 1, G), **f32)
         self.act = torch.zeros(G, **i32)
         self.tmp = [torch.zeros((G, D), **f32) for _ in range(2)]
+        self.stamps = None  # set to an int64[24] device tensor to collect per-stage cycle counts
         self.tree_base = (torch.arange(G, **i32) * self.pool.cap)
         self.arange_a = torch.arange(A, **i32)
 
@@ -259,12 +260,53 @@ class BatchedMCTS:
         return SearchResult(*self.pool.result())
 
     def run(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
-            rand_child: torch.Tensor, trace: dict | None = None) -> SearchResult:
-        """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1]."""
+            rand_child: torch.Tensor, trace: dict | None = None, fused: bool | None = None) -> SearchResult:
+        """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1].
+
+        `fused` (default: whenever A <= 32) runs the whole search as ONE kernel launch
+        (mz_search_run); otherwise the per-stage kernels are driven in lock step.  Both leave
+        bit-identical pools."""
         assert rand_child.shape == (self.G, self.S + 1) and rand_child.dtype == torch.int32
+        if fused is None:
+            fused = self.A <= 32
+        if fused:
+            return self.run_fused(root_latent, root_to_play, eta, rand_child, trace)
         self.begin(root_latent, root_to_play, eta, rand_child[:, 0])
         self.advance(rand_child[:, 1:], trace)
         return self.finish()
+
+    def run_fused(self, root_latent, root_to_play, eta, rand_child, trace: dict | None = None) -> SearchResult:
+        pool, G, A, S, D = self.pool, self.G, self.A, self.S, self.D
+        dev = pool.device
+        root_latent = root_latent.reshape(G, D).contiguous()
+        rand_child = rand_child.contiguous()
+        eta = eta.contiguous()
+        assert root_latent.dtype == torch.float32 and eta.dtype == torch.float32 and root_to_play.dtype == torch.int8
+        assert eta.numel() == G * A and root_to_play.numel() == G
+        t_leaf = t_child = t_roll = t_prior = None
+        if trace is not None:
+            t_leaf = torch.zeros((G, S), dtype=torch.int32, device=dev)
+            t_child = torch.zeros((G, S), dtype=torch.int32, device=dev)
+            t_roll = torch.zeros((G, S, self.depth + 1), dtype=torch.float32, device=dev)
+            t_prior = torch.zeros((G, S + 1, A), dtype=torch.float32, device=dev)
+        prm = _hip.SearchParams(S, self.depth, pool.tab_len, 0, float(self.discount), float(self.noise_frac),
+                                ptr(pool.sqrt_tab), ptr(pool.log_tab), ptr(root_latent), ptr(root_to_play), ptr(eta),
+                                ptr(rand_child), ptr(t_leaf), ptr(t_child), ptr(t_roll), ptr(t_prior),
+                                ptr(self.stamps))
+        policy = torch.empty((G, A), dtype=torch.float64, device=dev)
+        policy32 = torch.empty((G, A), dtype=torch.float32, device=dev)
+        value = torch.empty(G, dtype=torch.float64, device=dev)
+        visits = torch.empty((G, A), dtype=torch.int32, device=dev)
+        _hip.check(_hip.lib().mz_search_run(C.byref(pool.c), C.byref(self.nets.plan), ptr(self.nets.blob), C.byref(prm),
+                                            ptr(policy), ptr(policy32), ptr(value), ptr(visits), _stream()),
+                   "mz_search_run")
+        if trace is not None:
+            trace["leaf"] = [t_leaf[:, s].contiguous() for s in range(S)]
+            trace["child"] = [t_child[:, s].contiguous() for s in range(S)]
+            trace["rollout"] = [t_roll[:, s].contiguous() for s in range(S)]
+            trace["prior"] = [t_prior[:, s + 1].contiguous() for s in range(S)]
+            trace["root_prior"] = t_prior[:, 0].contiguous()
+        return SearchResult(policy, policy32, value, visits)
 
 
 def run_recorded(pool: TreePool, root_to_play, prior_stream, reward_stream, rand_stream, sim_stream, eta,

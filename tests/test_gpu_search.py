@@ -26,8 +26,9 @@ def _inputs(G, A, S, D, seed):
     return lat, eta.astype(np.float32), rand, to_play
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "lockstep"])
 @pytest.mark.parametrize("which,G,S,depth,noise", [("c4", 64, 50, 1, 0.25), ("c4", 9, 20, 2, 0.0), ("tiny", 40, 30, 3, 0.25)])
-def test_search_replays_bit_exact_through_oracle(which, G, S, depth, noise):
+def test_search_replays_bit_exact_through_oracle(which, G, S, depth, noise, fused):
     from muzero_amd.engine import BatchedMCTS, PackedNetworks
     if which == "c4":
         _, g, f = _c4_nets(0)
@@ -41,7 +42,7 @@ def test_search_replays_bit_exact_through_oracle(which, G, S, depth, noise):
     mcts = BatchedMCTS(nets, G, S, depth, discount=0.998, noise_frac=noise)
     trace = {}
     res = mcts.run(torch.from_numpy(lat).cuda(), torch.from_numpy(to_play).cuda(), torch.from_numpy(eta).cuda(),
-                   torch.from_numpy(rand).cuda(), trace=trace)
+                   torch.from_numpy(rand).cuda(), trace=trace, fused=fused)
     torch.cuda.synchronize()
     pool = mcts.pool
     # --- 1. replay the GPU's own network outputs through the oracle
@@ -108,3 +109,37 @@ def test_search_replays_bit_exact_through_oracle(which, G, S, depth, noise):
     # fp32 rounding differences between MFMA and the CPU GEMM may flip a near-tie argmax in a
     # few trees; the bulk must agree exactly
     assert same >= int(0.75 * n_cmp), f"only {same}/{n_cmp} trees identical to the CPU port"
+
+
+@pytest.mark.parametrize("which,G,S,depth", [("c4", 100, 50, 1), ("c4", 16, 5, 0), ("tiny", 33, 25, 2), ("odd", 21, 12, 1),
+                                             ("wide", 19, 6, 2)])
+def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
+    """One launch for the whole search vs the per-stage kernels: identical pools (every
+    statistic and every latent), identical results."""
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    if which == "c4":
+        _, g, f = _c4_nets(2)
+        latent_shape = (4, 6, 7)
+    elif which == "tiny":
+        g, f = _custom_nets((2, 3, 3), 5, [16], [16], [16])
+        latent_shape = (2, 3, 3)
+    elif which == "odd":  # reward head without hidden layer, deep policy, mixed activations, A = 3
+        g, f = _custom_nets((1, 1, 8), 3, [], [33], [17, 9, 40], ("tanh", "sigmoid", "relu"))
+        latent_shape = (1, 1, 8)
+    else:  # 18 actions (32 lanes per tree, three reward chunks), two hidden reward layers
+        g, f = _custom_nets((2, 4, 4), 18, [24, 12], [8], [24], ("relu",))
+        latent_shape = (2, 4, 4)
+    A, D = g.num_actions, int(np.prod(latent_shape))
+    nets = PackedNetworks(g, f)
+    lat, eta, rand, to_play = _inputs(G, A, S, D, seed=7 * G + S)
+    args = (torch.from_numpy(lat).cuda(), torch.from_numpy(to_play).cuda(), torch.from_numpy(eta).cuda(),
+            torch.from_numpy(rand).cuda())
+    a = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25)
+    b = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25)
+    ra = a.run(*args, fused=True)
+    rb = b.run(*args, fused=False)
+    torch.cuda.synchronize()
+    for name in ("visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes", "latent"):
+        assert torch.equal(getattr(a.pool, name), getattr(b.pool, name)), name
+    assert torch.equal(ra.policy, rb.policy) and torch.equal(ra.value, rb.value) and torch.equal(ra.visits, rb.visits)
+    assert torch.equal(ra.policy32, rb.policy32)

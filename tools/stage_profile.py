@@ -1,0 +1,31 @@
+"""Diagnostic: per-stage shader-clock cycles of the fused search kernel (workgroup 0)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+
+NAMES = ["staging", "select", "leaf gather", "E policy1|merge", "E policy rest", "E softmax/priors", "E child store",
+         "E reward L1 (children)", "E reward rest", "commit", "S next latent", "S reward head", "S policy1|merge",
+         "S policy rest", "S argmax", "S value head", "backup", "result"]
+
+def main():
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    cfg, h, g, f = bench.build_networks()
+    G, S = 4096, 50
+    nets = PackedNetworks(g, f)
+    mcts = BatchedMCTS(nets, G, S, 1, 0.998, 0.25)
+    latent, to_play = bench.synthetic_roots(h, G, 100, torch.device("cuda"))
+    eta = torch.from_numpy(np.random.default_rng(7).dirichlet(np.full(7, 0.3), size=G).astype(np.float32)).cuda()
+    rand = torch.from_numpy(bench.child_choice_streams(G, S, 0)).cuda()
+    for _ in range(2):
+        mcts.run(latent, to_play, eta, rand)
+    mcts.stamps = torch.zeros(24, dtype=torch.int64, device="cuda")
+    mcts.run(latent, to_play, eta, rand)
+    torch.cuda.synchronize()
+    st = mcts.stamps.cpu().numpy()
+    tot = st.sum()
+    for n, v in zip(NAMES, st):
+        print(f"{n:28s} {v:12d} cycles  {100*v/tot:5.1f}%   {v/(S+1):9.0f} /round")
+    print("total", tot)
+
+main()
