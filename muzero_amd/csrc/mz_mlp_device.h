@@ -29,6 +29,15 @@
 
 #include "muzero_hip.h"
 
+#ifdef MZ_EXP_STAMPS
+__device__ unsigned long long mz_dbg[64];
+#define MZ_DBG_T(var) unsigned long long var = 0; if (blockIdx.x == 0 && threadIdx.x == 0) var = clock64();
+#define MZ_DBG_ADD(slot, t0) if (blockIdx.x == 0 && threadIdx.x == 0) { mz_dbg[slot] += clock64() - (t0); mz_dbg[slot + 1] += 1; }
+#else
+#define MZ_DBG_T(var)
+#define MZ_DBG_ADD(slot, t0)
+#endif
+
 namespace mzd {
 
 constexpr int kWaves = 8;
@@ -121,7 +130,11 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float
 struct LdsRows {  // activations resident in LDS
     const lds_f *x;
     int ld;
-    __device__ __forceinline__ LdsRows uniform() const { return LdsRows{uni_lds(x), uni(ld)}; }
+    static __device__ __forceinline__ LdsRows from(const lds_f *a, int b, const lds_f *, int) { return LdsRows{a, b}; }
+    __device__ __forceinline__ const lds_f *s0() const { return x; }
+    __device__ __forceinline__ int s1() const { return ld; }
+    __device__ __forceinline__ const lds_f *s2() const { return nullptr; }
+    __device__ __forceinline__ int s3() const { return 0; }
     __device__ __forceinline__ f32x4 operator()(int mt, int m, int koff) const {
         return *reinterpret_cast<const lds_f4 *>(x + (mt * 16 + m) * ld + koff);
     }
@@ -134,7 +147,11 @@ struct ChildRows {
     int ldz;
     const lds_f *table;
     int ldt;
-    __device__ __forceinline__ ChildRows uniform() const { return ChildRows{uni_lds(z), uni(ldz), uni_lds(table), uni(ldt)}; }
+    static __device__ __forceinline__ ChildRows from(const lds_f *a, int b, const lds_f *c, int d) { return ChildRows{a, b, c, d}; }
+    __device__ __forceinline__ const lds_f *s0() const { return z; }
+    __device__ __forceinline__ int s1() const { return ldz; }
+    __device__ __forceinline__ const lds_f *s2() const { return table; }
+    __device__ __forceinline__ int s3() const { return ldt; }
     __device__ __forceinline__ f32x4 operator()(int mt, int m, int koff) const {
         const f32x4 a = *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff);
         const f32x4 b = *reinterpret_cast<const lds_f4 *>(table + mt * ldt + koff);
@@ -157,6 +174,17 @@ struct ChildRows {
 // (global_load_dwordx4, 1 KiB per tile and k-step) while the MFMAs of batch i issue, and the
 // stream runs on from one tile group into the next without draining.  Every loop bound below
 // is wave-uniform (the wave index goes through readfirstlane), so control flow is scalar.
+// parts[part] without indexing the array by a run-time value (which would force the array
+// into per-lane stack memory): scalar selects over the compile-time positions instead.
+template <int NPARTS>
+__device__ __forceinline__ DensePart pick_part(const DensePart (&parts)[NPARTS], int part) {
+    DensePart r = parts[0];
+#pragma unroll
+    for (int i = 1; i < NPARTS; ++i)
+        if (part == i) r = parts[i];
+    return r;
+}
+
 template <int MT, int NTW, int NPARTS, typename Rows>
 __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__restrict__ packed,
                                              const DensePart (&parts)[NPARTS], int KT, int first_tile, int ngroups) {
@@ -187,7 +215,7 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         for (int t = 0; t < NTW; ++t) {
             int part, nt;
             locate(first_tile + fg * NTW + t, part, nt);
-            fbase[t] = (glb_f4 *)(packed + parts[part].w_off) + (size_t)nt * KT * 64;
+            fbase[t] = (glb_f4 *)(packed + pick_part(parts, part).w_off) + (size_t)nt * KT * 64;
         }
     };
     fetch_bases();
@@ -220,7 +248,7 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
             for (int t = 0; t < NTW; ++t) {
                 locate(first_tile + cg * NTW + t, c_part[t], c_nt[t]);
                 // requested now, needed only by the epilogue after the last batch
-                bias[t] = ((glb_f *)packed)[parts[c_part[t]].b_off + c_nt[t] * 16 + m];
+                bias[t] = ((glb_f *)packed)[pick_part(parts, c_part[t]).b_off + c_nt[t] * 16 + m];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -280,21 +308,30 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
 #ifdef MZ_EXP_NOEPI
-                if (acc[t][0].x == 123.456f) store_tile<MT>(acc[t], c_nt[t], bias[t], parts[c_part[t]]);
+                if (acc[t][0].x == 123.456f) store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]));
 #else
-                store_tile<MT>(acc[t], c_nt[t], bias[t], parts[c_part[t]]);
+                store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]));
 #endif
             }
         }
     };
     f32x4 wa[NTW][kPrefetch], wb[NTW][kPrefetch];
+    constexpr int DB = (MT == 1 ? 0 : 16) + (NTW == 2 ? 0 : 8);
+    MZ_DBG_T(t_all)
     fetch(wa);
     for (int i = 0; i < total; i += 2) {
+        MZ_DBG_T(t_f)
         if (i + 1 < total) fetch(wb);
+        MZ_DBG_ADD(DB + 0, t_f)
+        MZ_DBG_T(t_c)
         compute(wa);
+        MZ_DBG_ADD(DB + 2, t_c)
         if (i + 2 < total) fetch(wa);
+        MZ_DBG_T(t_c2)
         if (i + 1 < total) compute(wb);
+        MZ_DBG_ADD(DB + 4, t_c2)
     }
+    MZ_DBG_ADD(DB + 6, t_all)
 }
 
 // Entry points (not inlined: own register allocation).  Kp is shared by all parts.  No
@@ -317,29 +354,51 @@ __device__ __forceinline__ void dense_group_body(const Rows &rows, const float *
     if (pairs > 0) stream_tiles<MT, 2, NPARTS>(rows, packed, parts, KT, first, pairs);
     if (count & 1) stream_tiles<MT, 1, NPARTS>(rows, packed, parts, KT, first + 2 * pairs, 1);
 }
+// Out-of-line entry points.  Every argument is a scalar: aggregates would be passed through
+// per-lane stack memory (written 64 times per wave and eventually to HBM), scalars travel in
+// registers.  `Rows` is rebuilt from four scalars (see LdsRows / ChildRows ::from).
 template <int MT, typename Rows>
-__device__ __noinline__ void dense_group1(Rows rows, const float *packed, int Kp, DensePart p0) {
-    const DensePart parts[1] = {p0.uniform()};
-    dense_group_body<MT, 1>(rows.uniform(), uni_ptr(packed), uni(Kp), parts);
+__device__ __noinline__ void dense_group1_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const float *packed,
+                                               int Kp, int w_off, int b_off, int N, int Np, int act, lds_f *Ys, int ldy,
+                                               const lds_f *row_add, int row_add_ld, const lds_i *row_sel) {
+    const DensePart parts[1] = {DensePart{w_off, b_off, N, Np, act, Ys, ldy, row_add, row_add_ld, row_sel}.uniform()};
+    dense_group_body<MT, 1>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts);
 }
 template <int MT, typename Rows>
-__device__ __noinline__ void dense_group2(Rows rows, const float *packed, int Kp, DensePart p0, DensePart p1) {
-    const DensePart parts[2] = {p0.uniform(), p1.uniform()};
-    dense_group_body<MT, 2>(rows.uniform(), uni_ptr(packed), uni(Kp), parts);
+__device__ __noinline__ void dense_group2_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const float *packed,
+                                               int Kp, int w0, int b0, int N0, int Np0, int act0, lds_f *Y0, int ldy0,
+                                               int w1, int b1, int N1, int Np1, int act1, lds_f *Y1, int ldy1) {
+    const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, nullptr, 0, nullptr}.uniform(),
+                                DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, nullptr, 0, nullptr}.uniform()};
+    dense_group_body<MT, 2>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts);
+}
+template <int MT, typename Rows>
+__device__ __forceinline__ void dense_group1(const Rows &rows, const float *packed, int Kp, const DensePart &p) {
+    dense_group1_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act,
+                                p.Ys, p.ldy, p.row_add, p.row_add_ld, p.row_sel);
+}
+template <int MT, typename Rows>
+__device__ __forceinline__ void dense_group2(const Rows &rows, const float *packed, int Kp, const DensePart &p,
+                                             const DensePart &q) {
+    dense_group2_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act,
+                                p.Ys, p.ldy, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys, q.ldy);
 }
 
 // Weight sources of dense_narrow: chunk q (4 consecutive k) of output column `col`.
 struct PackedNarrowWeights {  // straight from the packed blob in global memory
-    const f32x4 *wp;
-    const float *bias;
-    __device__ __forceinline__ PackedNarrowWeights uniform() const { return PackedNarrowWeights{uni_ptr(wp), uni_ptr(bias)}; }
+    const float *wp, *bias;
+    static __device__ __forceinline__ PackedNarrowWeights from(const float *w, const float *b, const lds_f *, int, int) {
+        return PackedNarrowWeights{uni_ptr(w), uni_ptr(b)};
+    }
     __device__ __forceinline__ f32x4 operator()(int q, int col) const { return ((glb_f4 *)wp)[(size_t)(q >> 2) * 64 + (q & 3) * 16 + col]; }
     __device__ __forceinline__ float b(int col) const { return ((glb_f *)bias)[col]; }
 };
 struct LdsNarrowWeights {  // compact copy [Kp/4][N] of float4 + 8 bias floats staged in LDS
     const lds_f *wl;
     int N, quads;
-    __device__ __forceinline__ LdsNarrowWeights uniform() const { return LdsNarrowWeights{uni_lds(wl), uni(N), uni(quads)}; }
+    static __device__ __forceinline__ LdsNarrowWeights from(const float *, const float *, const lds_f *w, int n, int q) {
+        return LdsNarrowWeights{uni_lds(w), n, q};
+    }
     __device__ __forceinline__ f32x4 operator()(int q, int col) const {
         return *reinterpret_cast<const lds_f4 *>(wl + (q * N + col) * 4);
     }
@@ -351,13 +410,14 @@ struct LdsNarrowWeights {  // compact copy [Kp/4][N] of float4 + 8 bias floats s
 // output (row, col), each summing a quarter of K as float4 dot products, then a lane
 // exchange adds the quarters.  The summation order is fixed by this function alone, so the
 // result does not depend on where the weights are fetched from.  No trailing barrier.
+// Scalar arguments only (see dense_group1_impl); gw/gb or lw is unused depending on Weights.
 template <typename Weights>
-__device__ __noinline__ void dense_narrow(const lds_f *Xs_, int ldx_, int rows_, Weights wf_, int Kp_, int N_, int act_,
-                                          lds_f *Ys_, int ldy_) {
+__device__ __noinline__ void dense_narrow(const lds_f *Xs_, int ldx_, int rows_, const float *gw, const float *gb,
+                                          const lds_f *lw, int Kp_, int N_, int act_, lds_f *Ys_, int ldy_) {
     const lds_f *Xs = uni_lds(Xs_);
     lds_f *Ys = uni_lds(Ys_);
     const int ldx = uni(ldx_), rows = uni(rows_), Kp = uni(Kp_), N = uni(N_), act = uni(act_), ldy = uni(ldy_);
-    const Weights wf = wf_.uniform();
+    const Weights wf = Weights::from(gw, gb, lw, N, Kp >> 2);
     const int quads = Kp >> 2;  // float4 chunks along K
     const int outputs = rows * N;
     for (int o0 = 0; o0 < outputs; o0 += kThreads / 4) {
@@ -417,11 +477,10 @@ __device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float
                                            const lds_f *narrow_lds = nullptr) {
     if (L.N <= 8 && row_add == nullptr) {
         if (narrow_lds)
-            dense_narrow(Xs, ldx, 16 * MT, LdsNarrowWeights{narrow_lds, L.N, L.Kp >> 2}, L.Kp, L.N, L.act, Ys, ldy);
+            dense_narrow<LdsNarrowWeights>(Xs, ldx, 16 * MT, nullptr, nullptr, narrow_lds, L.Kp, L.N, L.act, Ys, ldy);
         else
-            dense_narrow(Xs, ldx, 16 * MT,
-                         PackedNarrowWeights{reinterpret_cast<const f32x4 *>(packed + L.w_off), packed + L.b_off}, L.Kp,
-                         L.N, L.act, Ys, ldy);
+            dense_narrow<PackedNarrowWeights>(Xs, ldx, 16 * MT, packed + L.w_off, packed + L.b_off, nullptr, L.Kp, L.N,
+                                              L.act, Ys, ldy);
         __syncthreads();
         return;
     }

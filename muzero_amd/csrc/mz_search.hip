@@ -281,11 +281,13 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
                 const int a = r % A, t = r / A;
                 const f32x4 z = *reinterpret_cast<const lds_f4 *>(Z + t * ld_d + c);
                 const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + a * ld_d + c);
-                float *dst = p.latent + ((size_t)(g0 + t) * p.cap + base + a) * D + c;
-                __builtin_nontemporal_store(fmaxf(z.x + b.x, 0.f), dst);
-                __builtin_nontemporal_store(fmaxf(z.y + b.y, 0.f), dst + 1);
-                __builtin_nontemporal_store(fmaxf(z.z + b.z, 0.f), dst + 2);
-                __builtin_nontemporal_store(fmaxf(z.w + b.w, 0.f), dst + 3);
+                f32x4 *dst = reinterpret_cast<f32x4 *>(p.latent + ((size_t)(g0 + t) * p.cap + base + a) * D + c);
+                const f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
+#ifdef MZ_EXP_PLAINSTORE
+                *dst = v;
+#else
+                __builtin_nontemporal_store(v, dst);  // one 16-byte streaming store per lane
+#endif
             }
         } else {
             for (int i = tid; i < trees * A * D; i += kThreads) {
@@ -452,6 +454,17 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
 }  // namespace
 
 extern "C" {
+
+#ifdef MZ_EXP_STAMPS
+int mz_debug_read(unsigned long long *h_out, int clear) {
+    hipMemcpyFromSymbol(h_out, HIP_SYMBOL(mz_dbg), sizeof(unsigned long long) * 64);
+    if (clear) {
+        unsigned long long z[64] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(mz_dbg), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
                   double *policy, float *policy32, double *value, int32_t *visits, void *stream) {

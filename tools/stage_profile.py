@@ -27,5 +27,17 @@ def main():
     for n, v in zip(NAMES, st):
         print(f"{n:28s} {v:12d} cycles  {100*v/tot:5.1f}%   {v/(S+1):9.0f} /round")
     print("total", tot)
+    import ctypes
+    from muzero_amd import _hip
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    if hasattr(lib, "mz_debug_read"):
+        buf = (ctypes.c_ulonglong * 64)()
+        lib.mz_debug_read(buf, 0)
+        names = ["fetch(wb)", "compute(wa)", "compute(wb)", "whole call"]
+        for base, tag in ((0, "MT=1 NTW=2"), (8, "MT=1 NTW=1"), (16, "MT>1 NTW=2"), (24, "MT>1 NTW=1")):
+            for k, n in enumerate(names):
+                c, cnt = buf[base + 2 * k], buf[base + 2 * k + 1]
+                if cnt:
+                    print(f"{tag:12s} {n:12s} cycles {c:10d} calls {cnt:7d} avg {c / cnt:9.0f}")
 
 main()
