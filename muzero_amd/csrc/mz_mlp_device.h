@@ -29,6 +29,13 @@
 
 #include "muzero_hip.h"
 
+#ifdef MZ_EXP_TIMELINE
+// diagnostic: per-wave time stamps of the most recent dense call, slot-indexed
+__shared__ unsigned long long mz_tl[8][16];
+#define MZ_TL(slot) if ((threadIdx.x & 63) == 0) mz_tl[threadIdx.x >> 6][slot] = clock64();
+#else
+#define MZ_TL(slot)
+#endif
 #ifdef MZ_EXP_STAMPS
 __device__ unsigned long long mz_dbg[64];
 #define MZ_DBG_T(var) unsigned long long var = 0; if (blockIdx.x == 0 && threadIdx.x == 0) var = clock64();
@@ -114,6 +121,23 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float
     const int m = lane & 15, kq = lane >> 4;
     const int col = nt * 16 + m;
     const bool real_col = col < P.N;
+    // the common cases (plain relu / identity layers) take a branch-free path; the branches
+    // here are wave-uniform
+    if (P.row_add == nullptr && (P.act == MZ_ACT_RELU || P.act == MZ_ACT_NONE)) {
+        const float floor = P.act == MZ_ACT_RELU ? 0.0f : -__builtin_inff();
+        lds_f *y = P.Ys + (kq * 4) * P.ldy + col;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[mt][r] + b;
+                // v > floor ? v : floor reproduces activate() for relu (NaN -> 0) and is the
+                // identity for floor = -inf except NaN -> -inf, which no finite network produces
+                y[(mt * 16 + r) * P.ldy] = real_col ? (v > floor ? v : floor) : 0.0f;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -241,6 +265,9 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     f32x4 acc[NTW][MT];
     float bias[NTW];
     int c_part[NTW], c_nt[NTW];
+    f32x4 xc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xc[mt] = rows(mt, m, 4 * kq);
     auto compute = [&](const f32x4 (&w)[NTW][kPrefetch]) {
         const int kt0 = cb * kPrefetch;
         if (cb == 0) {
@@ -253,58 +280,41 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
                 for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if constexpr (MT <= 2) {
-            // few row tiles: fetch the A operands of the whole batch first so their LDS
-            // latency overlaps the MFMAs instead of preceding every k-step
-            f32x4 x[kPrefetch][MT];
+        // The A operands run one k-step ahead of the MFMAs that consume them (xc: current,
+        // xn: next; the sequence wraps to k = 0 at the end of a tile group), so their LDS
+        // latency and, for ChildRows, the vector work forming them hide behind the MFMAs.
 #pragma unroll
-            for (int j = 0; j < kPrefetch; ++j)
+        for (int j = 0; j < kPrefetch; ++j) {
+            if (kt0 + j < KT) {
+                const int kn = (kt0 + j + 1 < KT) ? kt0 + j + 1 : 0;
+                f32x4 xn[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) x[j][mt] = rows(mt, m, min(kt0 + j, KT - 1) * 16 + 4 * kq);
-#pragma unroll
-            for (int j = 0; j < kPrefetch; ++j) {
-                if (kt0 + j < KT) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int t = 0; t < NTW; ++t) {
-#ifdef MZ_EXP_NOMFMA
-                            acc[t][mt] += x[j][mt] * w[t][j];
+                for (int mt = 0; mt < MT; ++mt) {
+#ifdef MZ_EXP_NOLDS
+                    xn[mt] = f32x4{1.f, 2.f, 3.f, (float)(kn + mt + (threadIdx.x & 63))};
 #else
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
+                    xn[mt] = rows(mt, m, kn * 16 + 4 * kq);
 #endif
-                        }
-                }
-            }
-        } else {
 #pragma unroll
-            for (int j = 0; j < kPrefetch; ++j) {
-                if (kt0 + j < KT) {
-                    f32x4 x[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) x[mt] = rows(mt, m, (kt0 + j) * 16 + 4 * kq);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int t = 0; t < NTW; ++t) {
+                    for (int t = 0; t < NTW; ++t) {
 #ifdef MZ_EXP_NOMFMA
-                            acc[t][mt] += x[mt] * w[t][j];
+                        acc[t][mt] += xc[mt] * w[t][j];
 #else
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
 #endif
-                        }
+                    }
                 }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
             }
         }
         if (++cb == nb) {
             cb = 0;
             ++cg;
+            if (cg == ngroups) { MZ_TL(6) }
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
 #ifdef MZ_EXP_NOEPI
@@ -318,19 +328,24 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     f32x4 wa[NTW][kPrefetch], wb[NTW][kPrefetch];
     constexpr int DB = (MT == 1 ? 0 : 16) + (NTW == 2 ? 0 : 8);
     MZ_DBG_T(t_all)
+    MZ_TL(1)
     fetch(wa);
+    MZ_TL(2)
     for (int i = 0; i < total; i += 2) {
         MZ_DBG_T(t_f)
         if (i + 1 < total) fetch(wb);
         MZ_DBG_ADD(DB + 0, t_f)
         MZ_DBG_T(t_c)
         compute(wa);
+        if (i == 0) { MZ_TL(3) }
         MZ_DBG_ADD(DB + 2, t_c)
         if (i + 2 < total) fetch(wa);
         MZ_DBG_T(t_c2)
         if (i + 1 < total) compute(wb);
+        if (i == 0) { MZ_TL(4) }
         MZ_DBG_ADD(DB + 4, t_c2)
     }
+    MZ_TL(5)
     MZ_DBG_ADD(DB + 6, t_all)
 }
 

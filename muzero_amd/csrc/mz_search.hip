@@ -283,7 +283,9 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
                 const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + a * ld_d + c);
                 f32x4 *dst = reinterpret_cast<f32x4 *>(p.latent + ((size_t)(g0 + t) * p.cap + base + a) * D + c);
                 const f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
-#ifdef MZ_EXP_PLAINSTORE
+#if defined(MZ_EXP_NOSTORE)
+                if (v.x == 123.456f) *dst = v;
+#elif defined(MZ_EXP_PLAINSTORE)
                 *dst = v;
 #else
                 __builtin_nontemporal_store(v, dst);  // one 16-byte streaming store per lane
