@@ -291,7 +291,7 @@ typedef struct mz_search_params {
     int32_t *child_trace;       /* optional i32[G][S]: child the simulation started from       */
     float *rollout_trace;       /* optional f32[G][S][depth+1]: [r_1..r_depth, v] per simulation */
     float *prior_trace;         /* optional f32[G][S+1][A]: priors written by each expansion   */
-    unsigned long long *stamps; /* optional u64[24]: shader-clock cycles workgroup 0 spent per
+    unsigned long long *stamps; /* optional u64[32]: shader-clock cycles workgroup 0 spent per
                                    stage (diagnostics; leave NULL in production)               */
 } mz_search_params;
 

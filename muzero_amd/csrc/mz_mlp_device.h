@@ -93,6 +93,39 @@ __device__ __forceinline__ lds_i *uni_lds(const lds_i *p) {
     return (lds_i *)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)p);
 }
 
+// A team is a contiguous range of a workgroup's waves that runs one routine together; two
+// teams of one workgroup may run different routines at the same time.  nwaves must be a power
+// of two.  The whole workgroup synchronises with s_barrier; a partial team with an arrival
+// counter in LDS (one increment per wave and sync, never reset while the team runs) that its
+// waves poll, so the teams never wait for each other.  The poll is bounded: a team whose wave
+// never arrives sets *err instead of hanging the GPU.
+struct Team {
+    int wave0, nwaves;
+    lds_i *ctr;   // partial teams: arrival counter, err = ctr + 1
+    int arrived;  // arrivals expected after this wave's latest sync
+    __device__ __forceinline__ int tid() const { return (int)threadIdx.x - 64 * wave0; }
+    __device__ __forceinline__ int nthreads() const { return 64 * nwaves; }
+    __device__ __forceinline__ void sync() {
+        if (nwaves == kWaves) {
+            __syncthreads();
+            return;
+        }
+        arrived += nwaves;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int polls = 0;
+        while (uni(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < arrived) {
+            if (++polls > (1 << 19)) {
+                ctr[1] = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+__device__ __forceinline__ Team whole_workgroup() { return Team{0, kWaves, nullptr, 0}; }
+
 // One output of a group of layers that read the same input rows (passed by value).
 struct DensePart {
     int w_off, b_off;  // float offsets of the packed tiles / padded bias inside the blob
@@ -285,31 +318,30 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         // latency and, for ChildRows, the vector work forming them hide behind the MFMAs.
 #pragma unroll
         for (int j = 0; j < kPrefetch; ++j) {
-            if (kt0 + j < KT) {
-                const int kn = (kt0 + j + 1 < KT) ? kt0 + j + 1 : 0;
-                f32x4 xn[MT];
+            // steps past the end of K (last batch of a group) skip their MFMAs only; the
+            // operand pipeline advances unconditionally so that it is pure register renaming
+            const bool valid = kt0 + j < KT;
+            const int kn = (kt0 + j + 1 < KT) ? kt0 + j + 1 : 0;
+            f32x4 xn[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
 #ifdef MZ_EXP_NOLDS
-                    xn[mt] = f32x4{1.f, 2.f, 3.f, (float)(kn + mt + (threadIdx.x & 63))};
+                xn[mt] = f32x4{1.f, 2.f, 3.f, (float)(kn + mt + (threadIdx.x & 63))};
 #else
-                    xn[mt] = rows(mt, m, kn * 16 + 4 * kq);
+                xn[mt] = rows(mt, m, kn * 16 + 4 * kq);
 #endif
+                if (valid) {
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
-#ifdef MZ_EXP_NOMFMA
-                        acc[t][mt] += xc[mt] * w[t][j];
-#else
                         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
                         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
                         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
                         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
-#endif
                     }
                 }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
         }
         if (++cb == nb) {
             cb = 0;
@@ -353,15 +385,16 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
 // trailing barrier.
 template <int MT, int NPARTS, typename Rows>
 __device__ __forceinline__ void dense_group_body(const Rows &rows, const float *packed, int Kp,
-                                                 const DensePart (&parts)[NPARTS]) {
-    const int wave = uni(threadIdx.x >> 6);
+                                                 const DensePart (&parts)[NPARTS], int wave0, int nwaves) {
+    const int wave = uni(threadIdx.x >> 6) - wave0;
     const int KT = Kp >> 4;
     int total = 0;
 #pragma unroll
     for (int i = 0; i < NPARTS; ++i) total += parts[i].Np >> 4;
     // tiles are dealt as evenly as possible: waves w and w+4 usually share a SIMD, so the
     // larger shares go to the first waves and every SIMD ends up with nearly the same count
-    const int share = total / kWaves, extra = total - share * kWaves;
+    const int lg = 31 - __builtin_clz(nwaves);
+    const int share = total >> lg, extra = total - (share << lg);
     const int first = wave * share + min(wave, extra);
     const int count = share + (wave < extra ? 1 : 0);
     if (count <= 0) return;
@@ -375,28 +408,33 @@ __device__ __forceinline__ void dense_group_body(const Rows &rows, const float *
 template <int MT, typename Rows>
 __device__ __noinline__ void dense_group1_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const float *packed,
                                                int Kp, int w_off, int b_off, int N, int Np, int act, lds_f *Ys, int ldy,
-                                               const lds_f *row_add, int row_add_ld, const lds_i *row_sel) {
+                                               const lds_f *row_add, int row_add_ld, const lds_i *row_sel, int wave0,
+                                               int nwaves) {
     const DensePart parts[1] = {DensePart{w_off, b_off, N, Np, act, Ys, ldy, row_add, row_add_ld, row_sel}.uniform()};
-    dense_group_body<MT, 1>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts);
+    dense_group_body<MT, 1>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts,
+                            uni(wave0), uni(nwaves));
 }
 template <int MT, typename Rows>
 __device__ __noinline__ void dense_group2_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const float *packed,
                                                int Kp, int w0, int b0, int N0, int Np0, int act0, lds_f *Y0, int ldy0,
-                                               int w1, int b1, int N1, int Np1, int act1, lds_f *Y1, int ldy1) {
+                                               int w1, int b1, int N1, int Np1, int act1, lds_f *Y1, int ldy1, int wave0,
+                                               int nwaves) {
     const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, nullptr, 0, nullptr}.uniform(),
                                 DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, nullptr, 0, nullptr}.uniform()};
-    dense_group_body<MT, 2>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts);
+    dense_group_body<MT, 2>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts,
+                            uni(wave0), uni(nwaves));
 }
 template <int MT, typename Rows>
-__device__ __forceinline__ void dense_group1(const Rows &rows, const float *packed, int Kp, const DensePart &p) {
+__device__ __forceinline__ void dense_group1(const Rows &rows, const float *packed, int Kp, const DensePart &p,
+                                             const Team &tm = whole_workgroup()) {
     dense_group1_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act,
-                                p.Ys, p.ldy, p.row_add, p.row_add_ld, p.row_sel);
+                                p.Ys, p.ldy, p.row_add, p.row_add_ld, p.row_sel, tm.wave0, tm.nwaves);
 }
 template <int MT, typename Rows>
 __device__ __forceinline__ void dense_group2(const Rows &rows, const float *packed, int Kp, const DensePart &p,
-                                             const DensePart &q) {
+                                             const DensePart &q, const Team &tm = whole_workgroup()) {
     dense_group2_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act,
-                                p.Ys, p.ldy, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys, q.ldy);
+                                p.Ys, p.ldy, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys, q.ldy, tm.wave0, tm.nwaves);
 }
 
 // Weight sources of dense_narrow: chunk q (4 consecutive k) of output column `col`.
@@ -428,16 +466,18 @@ struct LdsNarrowWeights {  // compact copy [Kp/4][N] of float4 + 8 bias floats s
 // Scalar arguments only (see dense_group1_impl); gw/gb or lw is unused depending on Weights.
 template <typename Weights>
 __device__ __noinline__ void dense_narrow(const lds_f *Xs_, int ldx_, int rows_, const float *gw, const float *gb,
-                                          const lds_f *lw, int Kp_, int N_, int act_, lds_f *Ys_, int ldy_) {
+                                          const lds_f *lw, int Kp_, int N_, int act_, lds_f *Ys_, int ldy_, int wave0_,
+                                          int nwaves_) {
+    const int tid = (int)threadIdx.x - 64 * uni(wave0_), nthreads = 64 * uni(nwaves_);
     const lds_f *Xs = uni_lds(Xs_);
     lds_f *Ys = uni_lds(Ys_);
     const int ldx = uni(ldx_), rows = uni(rows_), Kp = uni(Kp_), N = uni(N_), act = uni(act_), ldy = uni(ldy_);
     const Weights wf = Weights::from(gw, gb, lw, N, Kp >> 2);
     const int quads = Kp >> 2;  // float4 chunks along K
     const int outputs = rows * N;
-    for (int o0 = 0; o0 < outputs; o0 += kThreads / 4) {
-        const int o = o0 + (threadIdx.x >> 2);
-        const int part = threadIdx.x & 3;
+    for (int o0 = 0; o0 < outputs; o0 += nthreads / 4) {
+        const int o = o0 + (tid >> 2);
+        const int part = tid & 3;
         float s = 0.0f;
         int row = 0, col = 0;
         if (o < outputs) {
@@ -460,7 +500,7 @@ __device__ __noinline__ void dense_narrow(const lds_f *Xs_, int ldx_, int rows_,
     }
     // zero the padding columns so a following layer may read whole 16-float chunks
     const int pad = ceil16(N) - N;
-    for (int i = threadIdx.x; i < rows * pad; i += kThreads) {
+    for (int i = tid; i < rows * pad; i += nthreads) {
         const int r = i / pad, c = N + i % pad;
         Ys[r * ldy + c] = 0.0f;
     }
@@ -484,44 +524,76 @@ __device__ __forceinline__ void stage_narrow(const float *__restrict__ packed, c
 // `row_add` (optional, LDS): per-row additive table row_add[row_sel[r]][n] added before the
 // activation (the action-embedding contribution of the dynamics merge layer).
 // `narrow_lds` (optional): LDS copy of a narrow layer's weights made by stage_narrow.
-// Ends with __syncthreads(): Ys is complete and Xs may be overwritten afterwards.
+// Ends with a team sync: Ys is complete and Xs may be overwritten afterwards.
+template <int MT>
+__device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float *__restrict__ packed,
+                                           const mz_packed_layer &L, lds_f *Ys, int ldy, const lds_f *row_add,
+                                           int row_add_ld, const lds_i *row_sel, const lds_f *narrow_lds, Team &tm) {
+    if (L.N <= 8 && row_add == nullptr) {
+        if (narrow_lds)
+            dense_narrow<LdsNarrowWeights>(Xs, ldx, 16 * MT, nullptr, nullptr, narrow_lds, L.Kp, L.N, L.act, Ys, ldy,
+                                           tm.wave0, tm.nwaves);
+        else
+            dense_narrow<PackedNarrowWeights>(Xs, ldx, 16 * MT, packed + L.w_off, packed + L.b_off, nullptr, L.Kp, L.N,
+                                              L.act, Ys, ldy, tm.wave0, tm.nwaves);
+        tm.sync();
+        return;
+    }
+    dense_group1<MT>(LdsRows{Xs, ldx}, packed, L.Kp, make_part(L, Ys, ldy, L.act, row_add, row_add_ld, row_sel), tm);
+    tm.sync();
+}
 template <int MT>
 __device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float *__restrict__ packed,
                                            const mz_packed_layer &L, lds_f *Ys, int ldy, const lds_f *row_add = nullptr,
                                            int row_add_ld = 0, const lds_i *row_sel = nullptr,
                                            const lds_f *narrow_lds = nullptr) {
-    if (L.N <= 8 && row_add == nullptr) {
-        if (narrow_lds)
-            dense_narrow<LdsNarrowWeights>(Xs, ldx, 16 * MT, nullptr, nullptr, narrow_lds, L.Kp, L.N, L.act, Ys, ldy);
-        else
-            dense_narrow<PackedNarrowWeights>(Xs, ldx, 16 * MT, packed + L.w_off, packed + L.b_off, nullptr, L.Kp, L.N,
-                                              L.act, Ys, ldy);
-        __syncthreads();
-        return;
-    }
-    dense_group1<MT>(LdsRows{Xs, ldx}, packed, L.Kp, make_part(L, Ys, ldy, L.act, row_add, row_add_ld, row_sel));
-    __syncthreads();
+    Team tm = whole_workgroup();
+    dense_tile<MT>(Xs, ldx, packed, L, Ys, ldy, row_add, row_add_ld, row_sel, narrow_lds, tm);
 }
 
 // In-place softmax over the first N columns of each of `rows` LDS rows, applied `times`
-// times (torch.softmax semantics: subtract the row maximum, exp, normalise).  One lane per
-// row; N is the action count (small).  Ends with __syncthreads().
-__device__ __forceinline__ void softmax_rows(lds_f *Ys, int ldy, int rows, int N, int times) {
-    if ((int)threadIdx.x < rows) {
-        lds_f *y = Ys + threadIdx.x * ldy;
-        for (int t = 0; t < times; ++t) {
-            float mx = y[0];
-            for (int i = 1; i < N; ++i) mx = fmaxf(mx, y[i]);
-            float s = 0.0f;
-            for (int i = 0; i < N; ++i) {
-                float e = expf(y[i] - mx);
-                y[i] = e;
-                s += e;
+// times (torch.softmax semantics: subtract the row maximum, exp, normalise; the sum runs over
+// the columns in ascending order).  N <= 8 (action logits): eight lanes per row, one column
+// each, the row-wide maximum and sum formed by lane exchanges in that same order.  Wider rows:
+// one lane per row.  Ends with a team sync.
+__device__ __forceinline__ void softmax_rows(lds_f *Ys, int ldy, int rows, int N, int times, Team &tm) {
+    const int tid = tm.tid(), nthreads = tm.nthreads();
+    if (N <= 8) {
+        for (int r0 = 0; r0 < rows; r0 += nthreads >> 3) {
+            const int row = r0 + (tid >> 3), j = tid & 7;
+            const bool live = row < rows && j < N;
+            float v = live ? Ys[row * ldy + j] : 0.0f;
+            for (int t = 0; t < times; ++t) {
+                float mx = __shfl(v, 0, 8);
+                for (int i = 1; i < N; ++i) mx = fmaxf(mx, __shfl(v, i, 8));
+                const float e = expf(v - mx);
+                float s = 0.0f;
+                for (int i = 0; i < N; ++i) s += __shfl(e, i, 8);
+                v = e / s;
             }
-            for (int i = 0; i < N; ++i) y[i] = y[i] / s;
+            if (live) Ys[row * ldy + j] = v;
+        }
+    } else {
+        for (int row = tid; row < rows; row += nthreads) {
+            lds_f *y = Ys + row * ldy;
+            for (int t = 0; t < times; ++t) {
+                float mx = y[0];
+                for (int i = 1; i < N; ++i) mx = fmaxf(mx, y[i]);
+                float s = 0.0f;
+                for (int i = 0; i < N; ++i) {
+                    float e = expf(y[i] - mx);
+                    y[i] = e;
+                    s += e;
+                }
+                for (int i = 0; i < N; ++i) y[i] = y[i] / s;
+            }
         }
     }
-    __syncthreads();
+    tm.sync();
+}
+__device__ __forceinline__ void softmax_rows(lds_f *Ys, int ldy, int rows, int N, int times) {
+    Team tm = whole_workgroup();
+    softmax_rows(Ys, ldy, rows, N, times, tm);
 }
 
 // Runs every layer of `M` over the row tile, ping-ponging between two LDS buffers.

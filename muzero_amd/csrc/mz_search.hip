@@ -33,9 +33,15 @@ constexpr int kPathCap = 16;  // select records the first kPathCap levels of its
 
 struct Lds {
     int ld_d, ld_h, ld_r, rows_r, tab_rows;
-    size_t x, z, tab, h1, h2, r1, r2, rout, prior, rew, roll, ints, path, tabs, total;  // byte offsets
+    // byte offsets.  x: leaf latents, later the simulation's current latent; z: merge
+    // pre-activation of the leaf; zs: merge pre-activation along the simulation; he1/he2: hidden
+    // activations of the expansion; hs1/hs2: of the simulation; r1/r2/rout: reward head over the
+    // children
+    size_t x, z, zs, tab, he1, he2, hs1, hs2, r1, r2, rout, prior, rew, roll, ints, path, tabs, total;
     int narrow[3][MZ_MAX_LAYERS];  // byte offset of a narrow layer's LDS weight copy (policy, value, reward), or -1
 };
+
+constexpr int kIntsPerTree = 6;  // s_leaf, s_child, s_act, s_leaf_tp, s_depth, s_root
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -54,16 +60,20 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     L.x = take(sizeof(float) * kTrees * L.ld_d);
     L.z = take(sizeof(float) * kTrees * L.ld_d);
+    L.zs = take(sizeof(float) * kTrees * L.ld_d);
     L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
-    L.h1 = take(sizeof(float) * kTrees * L.ld_h);
-    L.h2 = take(sizeof(float) * kTrees * L.ld_h);
+    const int ld_he = lds_stride(P.policy.max_width);
+    L.he1 = take(sizeof(float) * kTrees * ld_he);
+    L.he2 = take(P.policy.n_layers >= 2 ? sizeof(float) * kTrees * ld_he : 0);
+    L.hs1 = take(sizeof(float) * kTrees * L.ld_h);
+    L.hs2 = take(sizeof(float) * kTrees * L.ld_h);
     L.r1 = take(sizeof(float) * L.rows_r * L.ld_r);
     L.r2 = take(P.reward.n_layers >= 3 ? sizeof(float) * L.rows_r * L.ld_r : 0);
     L.rout = take(sizeof(float) * L.rows_r * lds_stride(1));
     L.prior = take(sizeof(float) * kTrees * A);
     L.rew = take(sizeof(float) * kTrees * L.tab_rows);
     L.roll = take(sizeof(float) * kTrees * (depth + 1));
-    L.ints = take(sizeof(int) * kTrees * 6);
+    L.ints = take(sizeof(int) * (kTrees * kIntsPerTree + 4));
     L.path = take(sizeof(int) * kTrees * kPathCap);
     L.tabs = take(sizeof(double) * 2 * tab_len);
     const mz_packed_mlp *mlps[3] = {&P.policy, &P.value, &P.reward};
@@ -77,17 +87,18 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
     return L;
 }
 
-// Layers [first, n) of an MLP over the workgroup's 16 rows, ping-ponging h1/h2.
-__device__ __forceinline__ lds_f *mlp16(const mz_packed_mlp &M, int first, const float *__restrict__ blob, lds_f *src,
-                                        int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
+// Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2.  Every layer ends
+// with a team sync.
+__device__ __forceinline__ lds_f *mlp16(Team &tm, const mz_packed_mlp &M, int first, const float *__restrict__ blob,
+                                        lds_f *src, int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
                                         const int (&narrow)[MZ_MAX_LAYERS]) {
     for (int i = first; i < M.n_layers; ++i) {
         const mz_packed_layer &L = M.layer[i];
         lds_f *dst = (src == h1) ? h2 : h1;
         const int ldo = lds_stride(L.N);
         const lds_f *nw = narrow[i] >= 0 ? to_lds(smem + narrow[i]) : nullptr;
-        dense_tile<1>(src, ld, blob, L, dst, ldo, nullptr, 0, nullptr, nw);
-        if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, kTrees, L.N, 1);
+        dense_tile<1>(src, ld, blob, L, dst, ldo, nullptr, 0, nullptr, nw, tm);
+        if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, kTrees, L.N, 1, tm);
         src = dst;
         ld = ldo;
     }
@@ -95,6 +106,17 @@ __device__ __forceinline__ lds_f *mlp16(const mz_packed_mlp &M, int first, const
     return src;
 }
 
+// After the leaf's first layers, a simulation round splits the workgroup into two teams of
+// four waves (one wave per SIMD each) that run concurrently and never wait for each other:
+//   expansion team   rest of the leaf's policy head -> priors; child latents to the pool; reward
+//                    head over the 16*A children; child records
+//   simulation team  the greedy rollout from the drawn child (which needs only the leaf's merge
+//                    pre-activation and the drawn action) and the value head
+// The two chains share no buffer that either writes, so a wave stalled on LDS, memory, a short
+// serial step or its team's sync leaves its SIMD to the other team's wave instead of idling
+// it: f32 MFMAs and vector-ALU work of one SIMD do not overlap, but waiting and issuing do.
+// Inside a team the waves synchronise through an LDS arrival counter (Team::sync); the teams
+// meet again at the workgroup barrier before the backup.
 template <int MTC>
 __global__ void __launch_bounds__(kThreads)
 k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_params q, Lds L,
@@ -103,9 +125,12 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     extern __shared__ __align__(16) unsigned char smem_raw[];
     lds_f *X = to_lds(smem_raw + L.x);
     lds_f *Z = to_lds(smem_raw + L.z);
+    lds_f *Zs = to_lds(smem_raw + L.zs);
     lds_f *Tab = to_lds(smem_raw + L.tab);
-    lds_f *H1 = to_lds(smem_raw + L.h1);
-    lds_f *H2 = to_lds(smem_raw + L.h2);
+    lds_f *He1 = to_lds(smem_raw + L.he1);
+    lds_f *He2 = to_lds(smem_raw + L.he2);
+    lds_f *Hs1 = to_lds(smem_raw + L.hs1);
+    lds_f *Hs2 = to_lds(smem_raw + L.hs2);
     lds_f *R1 = to_lds(smem_raw + L.r1);
     lds_f *R2 = to_lds(smem_raw + L.r2);
     lds_f *Rout = to_lds(smem_raw + L.rout);
@@ -117,21 +142,23 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     lds_i *s_act = s_child + kTrees;
     lds_i *s_leaf_tp = s_act + kTrees;
     lds_i *s_depth = s_leaf_tp + kTrees;
-    lds_i *s_root = s_depth + kTrees;  // root to_play per tree
+    lds_i *s_root = s_depth + kTrees;   // root to_play per tree
+    lds_i *s_team = s_root + kTrees;    // [4] per team: arrival counter, error flag
     int *s_path = reinterpret_cast<int *>(smem_raw + L.path);
     double *s_tab = reinterpret_cast<double *>(smem_raw + L.tabs);
 
-    // optional cycle stamps per stage (diagnostics: q.stamps == NULL in production)
-    __shared__ unsigned long long s_stamp[24];
+    // optional cycle stamps per stage (diagnostics: q.stamps == NULL in production); slots
+    // 0..15 are stamped by thread 0 (expansion team), 16..31 by the simulation team's first thread
+    __shared__ unsigned long long s_stamp[32];
     unsigned long long t_prev = 0;
     const bool stamping = q.stamps != nullptr && blockIdx.x == 0;
-    if (stamping && threadIdx.x < 24) s_stamp[threadIdx.x] = 0;
-    if (stamping && threadIdx.x == 0) t_prev = clock64();
-#define MZ_STAMP(slot)                                 \
-    if (stamping && threadIdx.x == 0) {                \
-        const unsigned long long t_now = clock64();    \
-        s_stamp[slot] += t_now - t_prev;               \
-        t_prev = t_now;                                \
+    if (stamping && threadIdx.x < 32) s_stamp[threadIdx.x] = 0;
+    if (stamping && (threadIdx.x == 0 || threadIdx.x == kThreads / 2)) t_prev = clock64();
+#define MZ_STAMP(slot)                                             \
+    if (stamping && (int)threadIdx.x == ((slot) < 16 ? 0 : kThreads / 2)) { \
+        const unsigned long long t_now = clock64();                \
+        s_stamp[slot] += t_now - t_prev;                           \
+        t_prev = t_now;                                            \
     }
 
     const int A = P.A, D = P.D, S = q.S, depth = q.depth;
@@ -141,18 +168,193 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     const int trees = min(kTrees, p.G - g0);
     const int lpt = q.lanes_per_tree;
     const int ld_p1 = lds_stride(P.policy.layer[0].N);
-    // policy layer 1 -> H1 and merge pre-activation W[:, :D] x -> Z, from the same input rows
-    auto first_layers = [&](const lds_f *in) {
+    const int half = uni(tid >> 6) >= kWaves / 2 ? 1 : 0;
+    int team_arrived = 0;  // arrivals this wave's team counter shows after the wave's latest team sync
+
+    // policy layer 1 -> h_out and merge pre-activation W[:, :D] x -> z_out, from the same
+    // input rows; ends with a barrier.  (The merge layer's stored epilogue is a relu for the
+    // stand-alone kernel; here its pre-activation is kept and the per-action table is added
+    // where a child latent is formed.)
+    auto first_layers = [&](Team &tm, const lds_f *in, lds_f *h_out, lds_f *z_out) {
         const lds_f *nw = L.narrow[0][0] >= 0 ? to_lds(smem_raw + L.narrow[0][0]) : nullptr;
         if (P.policy.layer[0].N > 8 && P.policy.layer[0].Kp == P.merge.layer[0].Kp) {
             dense_group2<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp,
-                            make_part(P.policy.layer[0], H1, ld_p1, P.policy.layer[0].act),
-                            make_part(P.merge.layer[0], Z, ld_d, MZ_ACT_NONE));
-            __syncthreads();
+                            make_part(P.policy.layer[0], h_out, ld_p1, P.policy.layer[0].act),
+                            make_part(P.merge.layer[0], z_out, ld_d, MZ_ACT_NONE), tm);
+            tm.sync();
         } else {
-            dense_tile<1>(in, ld_d, blob, P.policy.layer[0], H1, ld_p1, nullptr, 0, nullptr, nw);
-            dense_group1<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp, make_part(P.merge.layer[0], Z, ld_d, MZ_ACT_NONE));
-            __syncthreads();
+            dense_tile<1>(in, ld_d, blob, P.policy.layer[0], h_out, ld_p1, nullptr, 0, nullptr, nw, tm);
+            dense_group1<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp,
+                            make_part(P.merge.layer[0], z_out, ld_d, MZ_ACT_NONE), tm);
+            tm.sync();
+        }
+    };
+
+    // ---- the expansion after the leaf's first layers (He1, Z valid) ---------------------------
+    auto expand_tail = [&](Team &tm, int e, int base) {
+        const int ttid = tm.tid(), tn = tm.nthreads();
+        int ld_p;
+        lds_f *pol = mlp16(tm, P.policy, 1, blob, He1, ld_p1, He1, He2, &ld_p, smem_raw, L.narrow[0]);
+        MZ_STAMP(4)  // expand: remaining policy layers
+        if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pol, ld_p, kTrees, A, 1, tm);
+        softmax_rows(pol, ld_p, kTrees, A, 1, tm);  // expand_node's extra softmax (expansion.py:27)
+        for (int i = ttid; i < kTrees * A; i += tn) {
+            const int t = i / A, a = i - t * A;
+            const float pr = pol[t * ld_p + a];
+            s_prior[i] = pr;
+            if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + a] = pr;
+        }
+        MZ_STAMP(5)  // expand: softmax + priors
+        // child latents -> pool (coalesced along the latent).  Written once, read back at most a
+        // few times much later: streaming (non-temporal) stores keep them from displacing the
+        // weights and tree statistics in L2
+        if ((D & 3) == 0) {
+            // one (tree, action) row per wave and pass, lanes along the latent: the row index is
+            // wave-uniform, so the index arithmetic stays on the scalar unit
+            const int q4 = D >> 2;
+            const int wv = uni(ttid >> 6), lane = ttid & 63;
+            const int nrows = trees * A;
+            const int inv_a = (65536 + A - 1) / A;  // r / A == (r * inv_a) >> 16 for r * A < 65536
+            for (int c4 = lane; c4 < q4; c4 += 64) {
+                // four rows at a time: their LDS reads are in flight together
+                for (int r0 = 4 * wv; r0 < nrows; r0 += 4 * tm.nwaves) {
+                    f32x4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = min(r0 + u, nrows - 1);
+                        const int t = (r * inv_a) >> 16, a = r - t * A;
+                        const f32x4 z = *reinterpret_cast<const lds_f4 *>(Z + t * ld_d + 4 * c4);
+                        const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + a * ld_d + 4 * c4);
+                        v[u] = f32x4{fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u;
+                        if (r < nrows) {
+                            const int t = (r * inv_a) >> 16, a = r - t * A;
+                            f32x4 *dst = reinterpret_cast<f32x4 *>(p.latent + ((size_t)(g0 + t) * p.cap + base + a) * D) + c4;
+                            __builtin_nontemporal_store(v[u], dst);  // one 16-byte streaming store per lane
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int i = ttid; i < trees * A * D; i += tn) {
+                const int c = i % D, r = i / D;
+                const int a = r % A, t = r / A;
+                p.latent[((size_t)(g0 + t) * p.cap + base + a) * D + c] = fmaxf(Z[t * ld_d + c] + Tab[a * ld_d + c], 0.0f);
+            }
+        }
+        MZ_STAMP(6)  // expand: child latents to the pool
+        // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time
+        for (int a0 = 0; a0 < A; a0 += MTC) {
+            lds_f *src;
+            int ld, first;
+            if (P.reward.layer[0].N > 8) {
+                const mz_packed_layer &L0 = P.reward.layer[0];
+                dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp,
+                                  make_part(L0, R1, lds_stride(L0.N), L0.act), tm);
+                tm.sync();
+                MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
+                src = R1, ld = lds_stride(L0.N), first = 1;
+            } else {  // a reward head without hidden layers: materialise the child rows
+                for (int i = ttid; i < kTrees * MTC * ld_d; i += tn) {
+                    const int r = i / ld_d, c = i - r * ld_d;
+                    R1[r * L.ld_r + c] = fmaxf(Z[(r % kTrees) * ld_d + c] + Tab[(a0 + r / kTrees) * ld_d + c], 0.0f);
+                }
+                tm.sync();
+                src = R1, ld = L.ld_r, first = 0;
+            }
+            for (int i = first; i < P.reward.n_layers; ++i) {
+                const mz_packed_layer &Li = P.reward.layer[i];
+                const bool last = i == P.reward.n_layers - 1;
+                lds_f *dst = last ? Rout : (src == R1 ? R2 : R1);
+                const int ldo = lds_stride(Li.N);
+                dense_tile<MTC>(src, ld, blob, Li, dst, ldo, nullptr, 0, nullptr,
+                                L.narrow[2][i] >= 0 ? to_lds(smem_raw + L.narrow[2][i]) : nullptr, tm);
+                src = dst, ld = ldo;
+            }
+            for (int i = ttid; i < kTrees * MTC; i += tn) {
+                const int al = i / kTrees, t = i % kTrees;
+                s_rew[t * L.tab_rows + a0 + al] = src[i * ld];
+            }
+            tm.sync();
+        }
+        MZ_STAMP(8)  // expand: remaining reward layers
+        // ---- commit child records ------------------------------------------------------------
+        for (int i = ttid; i < trees * A; i += tn) {
+            const int t = i / A, a = i - t * A;
+            const size_t o = (size_t)(g0 + t) * p.cap;
+            float pr = s_prior[t * A + a];
+            if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
+            mzt::write_child(p, o, base, a, s_leaf[t], pr, s_rew[t * L.tab_rows + a], (int8_t)s_leaf_tp[t]);
+            if (a == 0) p.first_child[o + s_leaf[t]] = base;
+        }
+        MZ_STAMP(9)  // commit
+    };
+
+    // ---- the simulation from the drawn child (Z valid; writes X, Zs, Hs1, Hs2) -----------------
+    auto simulate = [&](Team &tm, int e, int base) {
+        const int ttid = tm.tid(), tn = tm.nthreads();
+        if (ttid < kTrees) {
+            int rc = 0;
+            if (ttid < trees) rc = q.rand_child[(size_t)(g0 + ttid) * (S + 1) + e];
+            rc = min(max(rc, 0), A - 1);
+            s_act[ttid] = rc;
+            s_child[ttid] = base + rc;
+            if (q.child_trace && ttid < trees) q.child_trace[(size_t)(g0 + ttid) * S + (e - 1)] = base + rc;
+        }
+        tm.sync();
+        for (int d = 0; d <= depth; ++d) {
+            // X <- relu(z + table[action]): the drawn child of the leaf for d = 0 (z = Z), the
+            // greedy step afterwards (z = Zs).  Columns [D, Dp) of z and the table are zero, so
+            // whole float4s can be processed.
+            {
+                const lds_f *zsrc = d == 0 ? Z : Zs;
+                const int q4 = ld_d >> 2, dp4 = P.Dp >> 2;
+                const int wv = uni(ttid >> 6), lane = ttid & 63;
+                for (int t = wv; t < kTrees; t += tm.nwaves) {
+                    const lds_f *trow = Tab + s_act[t] * ld_d;
+                    for (int c4 = lane; c4 < q4; c4 += 64) {
+                        const f32x4 z = *reinterpret_cast<const lds_f4 *>(zsrc + t * ld_d + 4 * c4);
+                        const f32x4 b = *reinterpret_cast<const lds_f4 *>(trow + 4 * c4);
+                        f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
+                        if (c4 >= dp4) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<lds_f4 *>(X + t * ld_d + 4 * c4) = v;
+                    }
+                }
+            }
+            tm.sync();
+            MZ_STAMP(16)  // simulate: next latent
+            if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
+                int ld_o;
+                const lds_f *r = mlp16(tm, P.reward, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, L.narrow[2]);
+                if (ttid < kTrees) s_roll[ttid * (depth + 1) + (d - 1)] = r[ttid * ld_o];
+                tm.sync();
+                MZ_STAMP(17)  // simulate: reward head
+            }
+            if (d == depth) break;
+            first_layers(tm, X, Hs1, Zs);
+            MZ_STAMP(18)  // simulate: policy layer 1 | merge
+            int ld_q;
+            lds_f *pq = mlp16(tm, P.policy, 1, blob, Hs1, ld_p1, Hs1, Hs2, &ld_q, smem_raw, L.narrow[0]);
+            MZ_STAMP(19)  // simulate: remaining policy layers
+            if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pq, ld_q, kTrees, A, 1, tm);
+            if (ttid < kTrees) {  // first maximum of the network's policy (simulation.py:36)
+                const lds_f *row = pq + ttid * ld_q;
+                int best = 0;
+                for (int a = 1; a < A; ++a)
+                    if (row[a] > row[best]) best = a;
+                s_act[ttid] = best;
+            }
+            tm.sync();
+            MZ_STAMP(20)  // simulate: argmax
+        }
+        {
+            int ld_o;
+            const lds_f *v = mlp16(tm, P.value, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, L.narrow[1]);
+            if (ttid < kTrees) s_roll[ttid * (depth + 1) + depth] = v[ttid * ld_o];
+            MZ_STAMP(21)  // simulate: value head
         }
     };
 
@@ -199,6 +401,7 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
         s_root[tid] = tp;
         s_depth[tid] = 0;
     }
+    if (tid < 4) s_team[tid] = 0;
     __syncthreads();
     MZ_STAMP(0)  // staging
 
@@ -235,14 +438,16 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             }
             __syncthreads();
             MZ_STAMP(1)  // select
-            if ((D & 3) == 0) {  // 16-byte rows: one float4 per lane
-                const int q4 = ld_d >> 2;
-                for (int i = tid; i < kTrees * q4; i += kThreads) {
-                    const int t = i / q4, c = (i - t * q4) * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (t < trees && c < D)
-                        v = *reinterpret_cast<const float4 *>(p.latent + ((size_t)(g0 + t) * p.cap + s_leaf[t]) * D + c);
-                    *reinterpret_cast<lds_f4 *>(X + t * ld_d + c) = f32x4{v.x, v.y, v.z, v.w};
+            if ((D & 3) == 0) {  // 16-byte rows: one tree per wave and pass, one float4 per lane
+                const int q4 = ld_d >> 2, d4 = D >> 2;
+                const int wv = uni(tid >> 6), lane = tid & 63;
+                for (int t = wv; t < kTrees; t += kWaves) {
+                    const float4 *src = reinterpret_cast<const float4 *>(p.latent + ((size_t)(g0 + t) * p.cap + s_leaf[t]) * D);
+                    for (int c4 = lane; c4 < q4; c4 += 64) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (t < trees && c4 < d4) v = src[c4];
+                        *reinterpret_cast<lds_f4 *>(X + t * ld_d + 4 * c4) = f32x4{v.x, v.y, v.z, v.w};
+                    }
                 }
             } else {
                 for (int i = tid; i < kTrees * ld_d; i += kThreads) {
@@ -254,158 +459,34 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             MZ_STAMP(2)  // leaf latent gather
         }
 
-        // ---- expand: policy layer 1 and merge layer share the input ------------------------
-        // (the merge layer's stored epilogue is a relu for the stand-alone kernel; here its
-        // pre-activation is kept and the per-action table is added afterwards)
-        first_layers(X);
+        // ---- the leaf's policy layer 1 and merge layer share the input: whole workgroup --------
+        Team all = whole_workgroup();
+        first_layers(all, X, He1, Z);
         MZ_STAMP(3)  // expand: policy layer 1 | merge
-        int ld_p;
-        lds_f *pol = mlp16(P.policy, 1, blob, H1, ld_p1, H1, H2, &ld_p, smem_raw, L.narrow[0]);
-        MZ_STAMP(4)  // expand: remaining policy layers
-        if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pol, ld_p, kTrees, A, 1);
-        softmax_rows(pol, ld_p, kTrees, A, 1);  // expand_node's extra softmax (expansion.py:27)
-        for (int i = tid; i < kTrees * A; i += kThreads) {
-            const int t = i / A, a = i - t * A;
-            const float pr = pol[t * ld_p + a];
-            s_prior[i] = pr;
-            if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + a] = pr;
+
+        // the root expansion has no simulation: the whole workgroup expands
+        const bool sim = e > 0;
+        Team tm = all;
+        if (sim) {
+            // the arrival counters are monotonic over the whole search: a team has synced
+            // team_syncs times so far (the same number in every wave of the team)
+            tm = half ? Team{kWaves / 2, kWaves / 2, s_team + 2, team_arrived} : Team{0, kWaves / 2, s_team, team_arrived};
         }
-        MZ_STAMP(5)  // expand: softmax + priors
-        // child latents -> pool (coalesced along the latent)
-        // written once, read back at most a few times much later: streaming (non-temporal) stores
-        // keep them from displacing the weights and tree statistics in L2
-        if ((D & 3) == 0) {
-            const int q4 = D >> 2;
-            for (int i = tid; i < trees * A * q4; i += kThreads) {
-                const int c = (i % q4) * 4, r = i / q4;
-                const int a = r % A, t = r / A;
-                const f32x4 z = *reinterpret_cast<const lds_f4 *>(Z + t * ld_d + c);
-                const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + a * ld_d + c);
-                f32x4 *dst = reinterpret_cast<f32x4 *>(p.latent + ((size_t)(g0 + t) * p.cap + base + a) * D + c);
-                const f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
-#if defined(MZ_EXP_NOSTORE)
-                if (v.x == 123.456f) *dst = v;
-#elif defined(MZ_EXP_PLAINSTORE)
-                *dst = v;
-#else
-                __builtin_nontemporal_store(v, dst);  // one 16-byte streaming store per lane
-#endif
-            }
+        if (stamping && tid == kThreads / 2) t_prev = clock64();
+        if (!sim || half == 0) {
+            expand_tail(tm, e, base);
         } else {
-            for (int i = tid; i < trees * A * D; i += kThreads) {
-                const int c = i % D, r = i / D;
-                const int a = r % A, t = r / A;
-                p.latent[((size_t)(g0 + t) * p.cap + base + a) * D + c] = fmaxf(Z[t * ld_d + c] + Tab[a * ld_d + c], 0.0f);
-            }
+            // the simulation is the longer chain: its waves issue first whenever both teams'
+            // waves of a SIMD are ready
+            __builtin_amdgcn_s_setprio(3);
+            simulate(tm, e, base);
+            __builtin_amdgcn_s_setprio(0);
         }
-        MZ_STAMP(6)  // expand: child latents to the pool
-        // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time
-        for (int a0 = 0; a0 < A; a0 += MTC) {
-            lds_f *src;
-            int ld, first;
-            if (P.reward.layer[0].N > 8) {
-                const mz_packed_layer &L0 = P.reward.layer[0];
-                dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp,
-                                  make_part(L0, R1, lds_stride(L0.N), L0.act));
-                __syncthreads();
-                MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
-                src = R1, ld = lds_stride(L0.N), first = 1;
-            } else {  // a reward head without hidden layers: materialise the child rows
-                for (int i = tid; i < kTrees * MTC * ld_d; i += kThreads) {
-                    const int r = i / ld_d, c = i - r * ld_d;
-                    R1[r * L.ld_r + c] = fmaxf(Z[(r % kTrees) * ld_d + c] + Tab[(a0 + r / kTrees) * ld_d + c], 0.0f);
-                }
-                __syncthreads();
-                src = R1, ld = L.ld_r, first = 0;
-            }
-            for (int i = first; i < P.reward.n_layers; ++i) {
-                const mz_packed_layer &Li = P.reward.layer[i];
-                const bool last = i == P.reward.n_layers - 1;
-                lds_f *dst = last ? Rout : (src == R1 ? R2 : R1);
-                const int ldo = lds_stride(Li.N);
-                dense_tile<MTC>(src, ld, blob, Li, dst, ldo, nullptr, 0, nullptr,
-                                L.narrow[2][i] >= 0 ? to_lds(smem_raw + L.narrow[2][i]) : nullptr);
-                src = dst, ld = ldo;
-            }
-            for (int i = tid; i < kTrees * MTC; i += kThreads) {
-                const int al = i / kTrees, t = i % kTrees;
-                s_rew[t * L.tab_rows + a0 + al] = src[i * ld];
-            }
-            __syncthreads();
-        }
-
-        MZ_STAMP(8)  // expand: remaining reward layers
-        // ---- commit child records ------------------------------------------------------------
-        for (int i = tid; i < trees * A; i += kThreads) {
-            const int t = i / A, a = i - t * A;
-            const size_t o = (size_t)(g0 + t) * p.cap;
-            float pr = s_prior[t * A + a];
-            if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
-            mzt::write_child(p, o, base, a, s_leaf[t], pr, s_rew[t * L.tab_rows + a], (int8_t)s_leaf_tp[t]);
-            if (a == 0) p.first_child[o + s_leaf[t]] = base;
-        }
-        if (e == 0) {
-            __syncthreads();
-            continue;
-        }
-
-        MZ_STAMP(9)  // commit
-        // ---- simulate from the drawn child ---------------------------------------------------
-        if (tid < kTrees) {
-            int rc = 0;
-            if (tid < trees) rc = q.rand_child[(size_t)(g0 + tid) * (S + 1) + e];
-            rc = min(max(rc, 0), A - 1);
-            s_act[tid] = rc;
-            s_child[tid] = base + rc;
-            if (q.child_trace && tid < trees) q.child_trace[(size_t)(g0 + tid) * S + (e - 1)] = base + rc;
-        }
-        __syncthreads();
-        for (int d = 0; d <= depth; ++d) {
-            // X <- relu(Z + table[action]): the drawn child for d = 0, the greedy step afterwards
-            {   // columns [D, Dp) of Z and the table are zero, so whole float4s can be processed
-                const int q4 = ld_d >> 2;
-                for (int i = tid; i < kTrees * q4; i += kThreads) {
-                    const int t = i / q4, c = (i - t * q4) * 4;
-                    const f32x4 z = *reinterpret_cast<const lds_f4 *>(Z + t * ld_d + c);
-                    const f32x4 b = *reinterpret_cast<const lds_f4 *>(Tab + s_act[t] * ld_d + c);
-                    f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
-                    if (c >= P.Dp) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<lds_f4 *>(X + t * ld_d + c) = v;
-                }
-            }
-            __syncthreads();
-            MZ_STAMP(10)  // simulate: next latent
-            if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
-                int ld_o;
-                const lds_f *r = mlp16(P.reward, 0, blob, X, ld_d, H1, H2, &ld_o, smem_raw, L.narrow[2]);
-                if (tid < kTrees) s_roll[tid * (depth + 1) + (d - 1)] = r[tid * ld_o];
-                __syncthreads();
-                MZ_STAMP(11)  // simulate: reward head
-            }
-            if (d == depth) break;
-            first_layers(X);
-            MZ_STAMP(12)  // simulate: policy layer 1 | merge
-            int ld_q;
-            lds_f *pq = mlp16(P.policy, 1, blob, H1, ld_p1, H1, H2, &ld_q, smem_raw, L.narrow[0]);
-            MZ_STAMP(13)  // simulate: remaining policy layers
-            if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pq, ld_q, kTrees, A, 1);
-            if (tid < kTrees) {  // first maximum of the network's policy (simulation.py:36)
-                const lds_f *row = pq + tid * ld_q;
-                int best = 0;
-                for (int a = 1; a < A; ++a)
-                    if (row[a] > row[best]) best = a;
-                s_act[tid] = best;
-            }
-            __syncthreads();
-            MZ_STAMP(14)  // simulate: argmax
-        }
-        {
-            int ld_o;
-            const lds_f *v = mlp16(P.value, 0, blob, X, ld_d, H1, H2, &ld_o, smem_raw, L.narrow[1]);
-            if (tid < kTrees) s_roll[tid * (depth + 1) + depth] = v[tid * ld_o];
-            __syncthreads();
-            MZ_STAMP(15)  // simulate: value head
-        }
+        if (sim) team_arrived = tm.arrived;
+        __syncthreads();  // the teams meet
+        if (!sim) continue;
+        MZ_STAMP(10)  // waiting for the other team
+        MZ_STAMP(22)
 
         // ---- backup --------------------------------------------------------------------------
         // The path root .. leaf was recorded by select, so its nodes are updated by independent
@@ -437,18 +518,20 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             }
         }
         __syncthreads();
-        MZ_STAMP(16)  // backup
+        MZ_STAMP(11)  // backup
     }
 
     // ---- result -------------------------------------------------------------------------------
     if (tid < trees) {
         p.n_nodes[g0 + tid] = 1 + (S + 1) * A;
         mzt::tree_result(p, g0 + tid, policy, policy32, value, visits);
+        // a team sync that gave up waiting (never expected) must not pass for a result
+        if ((s_team[1] | s_team[3]) != 0 && value) value[g0 + tid] = __builtin_nan("");
     }
-    MZ_STAMP(17)  // result
+    MZ_STAMP(12)  // result
     if (stamping) {
         __syncthreads();
-        if (threadIdx.x < 24) q.stamps[threadIdx.x] = s_stamp[threadIdx.x];
+        if (threadIdx.x < 32) q.stamps[threadIdx.x] = s_stamp[threadIdx.x];
     }
 #undef MZ_STAMP
 }
@@ -456,17 +539,6 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
 }  // namespace
 
 extern "C" {
-
-#ifdef MZ_EXP_STAMPS
-int mz_debug_read(unsigned long long *h_out, int clear) {
-    hipMemcpyFromSymbol(h_out, HIP_SYMBOL(mz_dbg), sizeof(unsigned long long) * 64);
-    if (clear) {
-        unsigned long long z[64] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(mz_dbg), z, sizeof(z));
-    }
-    return 0;
-}
-#endif
 
 int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
                   double *policy, float *policy32, double *value, int32_t *visits, void *stream) {

@@ -203,7 +203,7 @@ class BatchedMCTS:
         self.rollout_t = torch.zeros((self.depth + 1, G), **f32)
         self.act = torch.zeros(G, **i32)
         self.tmp = [torch.zeros((G, D), **f32) for _ in range(2)]
-        self.stamps = None  # set to an int64[24] device tensor to collect per-stage cycle counts
+        self.stamps = None  # set to an int64[32] device tensor to collect per-stage cycle counts
         self.tree_base = (torch.arange(G, **i32) * self.pool.cap)
         self.arange_a = torch.arange(A, **i32)
 
