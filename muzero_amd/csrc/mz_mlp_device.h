@@ -135,39 +135,85 @@ struct DensePart {
     const lds_f *row_add;  // optional additive table in LDS, indexed [row_sel[row]][col]
     int row_add_ld;
     const lds_i *row_sel;
+    // Optional folded scalar layer: instead of storing Y, the epilogue multiplies act(Y) by the
+    // weights of a following one-output layer (packed tiles at dot_w_off) and leaves the sum
+    // over this tile's 16 columns in dot_out[tile][row] (row stride 16*MT); finish_dot() adds
+    // the tiles.  dot_w_off < 0: plain layer.
+    int dot_w_off;
+    lds_f *dot_out;
     __device__ __forceinline__ DensePart uniform() const {
         return DensePart{uni(w_off), uni(b_off), uni(N), uni(Np), uni(act), uni_lds(Ys), uni(ldy),
-                         uni_lds(row_add), uni(row_add_ld), uni_lds(row_sel)};
+                         uni_lds(row_add), uni(row_add_ld), uni_lds(row_sel), uni(dot_w_off), uni_lds(dot_out)};
     }
 };
 __device__ __forceinline__ DensePart make_part(const mz_packed_layer &L, lds_f *Ys, int ldy, int act,
                                                const lds_f *row_add = nullptr, int row_add_ld = 0,
                                                const lds_i *row_sel = nullptr) {
-    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, act, Ys, ldy, row_add, row_add_ld, row_sel};
+    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, act, Ys, ldy, row_add, row_add_ld, row_sel, -1, nullptr};
+}
+// Layer L followed by the one-output layer L1, folded (see DensePart::dot_out).
+__device__ __forceinline__ DensePart make_dot_part(const mz_packed_layer &L, const mz_packed_layer &L1, lds_f *dot_out) {
+    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, L.act, nullptr, 0, nullptr, 0, nullptr, (int)L1.w_off, dot_out};
+}
+// Sum over the 16 lanes of a DPP row (every lane receives it; the association is fixed).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror
+    v += dpp_f32<0x140>(v);  // row_mirror
+    return v;
 }
 
 // Epilogue of one 16-column tile: bias, optional per-row additive table, activation, store.
 // C layout of the MFMA: column = lane & 15, row = 4*(lane >> 4) + reg.
 template <int MT>
-__device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float b, const DensePart &P) {
+__device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float b, const DensePart &P, glb_f *packed_f) {
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kq = lane >> 4;
     const int col = nt * 16 + m;
     const bool real_col = col < P.N;
-    // the common cases (plain relu / identity layers) take a branch-free path; the branches
-    // here are wave-uniform
-    if (P.row_add == nullptr && (P.act == MZ_ACT_RELU || P.act == MZ_ACT_NONE)) {
-        const float floor = P.act == MZ_ACT_RELU ? 0.0f : -__builtin_inff();
-        lds_f *y = P.Ys + (kq * 4) * P.ldy + col;
+    if (P.dot_w_off >= 0) {
+        // weight of column `col` in the packed one-output layer: tile kt = nt, row 0 of the
+        // tile lives in lanes 16*q, element j, with col = 16*nt + 4*q + j
+        const float w2 = real_col ? packed_f[P.dot_w_off + (nt * 64 + 16 * (m >> 2)) * 4 + (m & 3)] : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = acc[mt][r] + b;
-                // v > floor ? v : floor reproduces activate() for relu (NaN -> 0) and is the
-                // identity for floor = -inf except NaN -> -inf, which no finite network produces
-                y[(mt * 16 + r) * P.ldy] = real_col ? (v > floor ? v : floor) : 0.0f;
+                const float h = real_col ? activate(acc[mt][r] + b, P.act) : 0.0f;
+                // __fmul_rn: never contracted into the following add, whatever the file's
+                // -ffp-contract setting, so every kernel forms the same sums
+                const float sum = row16_sum(__fmul_rn(h, w2));
+                if (m == 0) P.dot_out[nt * (16 * MT) + mt * 16 + kq * 4 + r] = sum;
             }
+        }
+        return;
+    }
+    // the common cases (plain relu / identity layers) take a branch-free path; the branches
+    // here are wave-uniform
+    if (P.row_add == nullptr && (P.act == MZ_ACT_RELU || P.act == MZ_ACT_NONE)) {
+        // padded columns need no select here: their packed weights and bias are zero, so the
+        // accumulator holds 0 and relu / identity keep it.  Address arithmetic is scalar: one
+        // base per lane, the row step added per store.
+        lds_f *y = P.Ys + (kq * 4) * P.ldy + col;
+        const int step = P.ldy;
+        if (P.act == MZ_ACT_RELU) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][r] + b;
+                    y[(mt * 16 + r) * step] = v > 0.0f ? v : 0.0f;  // activate(): NaN -> 0
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[(mt * 16 + r) * step] = acc[mt][r] + b;
         }
         return;
     }
@@ -183,19 +229,33 @@ __device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float
     }
 }
 
-// A-operand sources.  operator()(mt, m, koff) returns X[row 16*mt + m][koff .. koff+3].
+// A-operand sources.  X[row 16*mt + m][koff .. koff+3] = form(shared(m, koff), raw(mt, m, koff)):
+// `shared` and `raw` are the LDS reads (shared: common to all row tiles of one k-step), `form`
+// the vector work on them, so a caller can issue every read of a k-step first and form the
+// operands later, between MFMAs.
 struct LdsRows {  // activations resident in LDS
     const lds_f *x;
     int ld;
-    static __device__ __forceinline__ LdsRows from(const lds_f *a, int b, const lds_f *, int) { return LdsRows{a, b}; }
+    static __device__ __forceinline__ LdsRows from(const lds_f *a, int b, const lds_f *, int, const lds_i *) { return LdsRows{a, b}; }
+    __device__ __forceinline__ const lds_i *s4() const { return nullptr; }
     __device__ __forceinline__ const lds_f *s0() const { return x; }
     __device__ __forceinline__ int s1() const { return ld; }
     __device__ __forceinline__ const lds_f *s2() const { return nullptr; }
     __device__ __forceinline__ int s3() const { return 0; }
-    __device__ __forceinline__ f32x4 operator()(int mt, int m, int koff) const {
+    __device__ __forceinline__ f32x4 shared(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 raw(int mt, int m, int koff) const {
         return *reinterpret_cast<const lds_f4 *>(x + (mt * 16 + m) * ld + koff);
     }
+    static __device__ __forceinline__ f32x4 form(const f32x4 &, const f32x4 &r) { return r; }
 };
+__device__ __forceinline__ f32x4 relu_sum(const f32x4 &a, const f32x4 &b) {
+    f32x4 r;
+    r.x = fmaxf(a.x + b.x, 0.f);
+    r.y = fmaxf(a.y + b.y, 0.f);
+    r.z = fmaxf(a.z + b.z, 0.f);
+    r.w = fmaxf(a.w + b.w, 0.f);
+    return r;
+}
 // Rows of the expansion: row (mt = action a, m = tree t) = relu(z[t][:] + table[a][:]), formed
 // on the fly from the merge pre-activation z (LDS, 16 rows) and the per-action table (LDS), so
 // the A*16 child latents never need an LDS image of their own.
@@ -204,21 +264,37 @@ struct ChildRows {
     int ldz;
     const lds_f *table;
     int ldt;
-    static __device__ __forceinline__ ChildRows from(const lds_f *a, int b, const lds_f *c, int d) { return ChildRows{a, b, c, d}; }
+    static __device__ __forceinline__ ChildRows from(const lds_f *a, int b, const lds_f *c, int d, const lds_i *) { return ChildRows{a, b, c, d}; }
+    __device__ __forceinline__ const lds_i *s4() const { return nullptr; }
     __device__ __forceinline__ const lds_f *s0() const { return z; }
     __device__ __forceinline__ int s1() const { return ldz; }
     __device__ __forceinline__ const lds_f *s2() const { return table; }
     __device__ __forceinline__ int s3() const { return ldt; }
-    __device__ __forceinline__ f32x4 operator()(int mt, int m, int koff) const {
-        const f32x4 a = *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff);
-        const f32x4 b = *reinterpret_cast<const lds_f4 *>(table + mt * ldt + koff);
-        f32x4 r;
-        r.x = fmaxf(a.x + b.x, 0.f);
-        r.y = fmaxf(a.y + b.y, 0.f);
-        r.z = fmaxf(a.z + b.z, 0.f);
-        r.w = fmaxf(a.w + b.w, 0.f);
-        return r;
+    __device__ __forceinline__ f32x4 shared(int m, int koff) const { return *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff); }
+    __device__ __forceinline__ f32x4 raw(int mt, int, int koff) const { return *reinterpret_cast<const lds_f4 *>(table + mt * ldt + koff); }
+    static __device__ __forceinline__ f32x4 form(const f32x4 &sh, const f32x4 &r) { return relu_sum(sh, r); }
+};
+
+// Sixteen rows, row m = relu(z[m][:] + table[sel[m]][:]): the child of row m's tree reached by
+// action sel[m], formed on the fly (one row tile only).
+struct PickedRows {
+    const lds_f *z;
+    int ldz;
+    const lds_f *table;
+    int ldt;
+    const lds_i *sel;
+    const lds_f *trow;  // per lane: table row of this lane's A-operand row (lane & 15)
+    static __device__ __forceinline__ PickedRows from(const lds_f *a, int b, const lds_f *c, int d, const lds_i *e) {
+        return PickedRows{a, b, c, d, e, c + e[threadIdx.x & 15] * d};
     }
+    __device__ __forceinline__ const lds_f *s0() const { return z; }
+    __device__ __forceinline__ int s1() const { return ldz; }
+    __device__ __forceinline__ const lds_f *s2() const { return table; }
+    __device__ __forceinline__ int s3() const { return ldt; }
+    __device__ __forceinline__ const lds_i *s4() const { return sel; }
+    __device__ __forceinline__ f32x4 shared(int m, int koff) const { return *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff); }
+    __device__ __forceinline__ f32x4 raw(int, int, int koff) const { return *reinterpret_cast<const lds_f4 *>(trow + koff); }
+    static __device__ __forceinline__ f32x4 form(const f32x4 &sh, const f32x4 &r) { return relu_sum(sh, r); }
 };
 
 // Several dense layers over the SAME input rows in one pass (e.g. the policy head's first
@@ -248,9 +324,12 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
 #ifdef MZ_EXP_EMPTY
     return;
 #endif
+    // tall row tiles keep many accumulators and operands: their weight batches are shorter (a
+    // batch still covers >= 100 MFMAs), which keeps the routine out of the callee-saved registers
+    constexpr int KP = MT >= 4 ? 2 : kPrefetch;
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kq = lane >> 4;
-    const int nb = (KT + kPrefetch - 1) / kPrefetch;  // batches per tile group
+    const int nb = (KT + KP - 1) / KP;  // batches per tile group
     const int total = ngroups * nb;
     auto locate = [&](int tl, int &part, int &nt) {
         part = 0;
@@ -276,12 +355,12 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         }
     };
     fetch_bases();
-    auto fetch = [&](f32x4 (&w)[NTW][kPrefetch]) {
-        const int kt0 = fb * kPrefetch;
+    auto fetch = [&](f32x4 (&w)[NTW][KP]) {
+        const int kt0 = fb * KP;
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int j = 0; j < kPrefetch; ++j) {
+            for (int j = 0; j < KP; ++j) {
 #ifdef MZ_EXP_NOLOAD
                 w[t][j] = f32x4{1.f, 2.f, 3.f, (float)(kt0 + j + lane)};
 #else
@@ -299,10 +378,8 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     float bias[NTW];
     int c_part[NTW], c_nt[NTW];
     f32x4 xc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xc[mt] = rows(mt, m, 4 * kq);
-    auto compute = [&](const f32x4 (&w)[NTW][kPrefetch]) {
-        const int kt0 = cb * kPrefetch;
+    auto compute = [&](const f32x4 (&w)[NTW][KP]) {
+        const int kt0 = cb * KP;
         if (cb == 0) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -317,19 +394,18 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         // xn: next; the sequence wraps to k = 0 at the end of a tile group), so their LDS
         // latency and, for ChildRows, the vector work forming them hide behind the MFMAs.
 #pragma unroll
-        for (int j = 0; j < kPrefetch; ++j) {
+        for (int j = 0; j < KP; ++j) {
             // steps past the end of K (last batch of a group) skip their MFMAs only; the
             // operand pipeline advances unconditionally so that it is pure register renaming
             const bool valid = kt0 + j < KT;
             const int kn = (kt0 + j + 1 < KT) ? kt0 + j + 1 : 0;
+            // every LDS read of the next k-step is issued before this k-step's MFMAs ...
             f32x4 xn[MT];
+            const f32x4 sh = rows.shared(m, kn * 16 + 4 * kq);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xn[mt] = rows.raw(mt, m, kn * 16 + 4 * kq);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-#ifdef MZ_EXP_NOLDS
-                xn[mt] = f32x4{1.f, 2.f, 3.f, (float)(kn + mt + (threadIdx.x & 63))};
-#else
-                xn[mt] = rows(mt, m, kn * 16 + 4 * kq);
-#endif
                 if (valid) {
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
@@ -339,6 +415,8 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
                         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
                     }
                 }
+                // ... and formed into operands behind the MFMAs of one row tile each
+                xn[mt] = Rows::form(sh, xn[mt]);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
@@ -350,19 +428,24 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
 #ifdef MZ_EXP_NOEPI
-                if (acc[t][0].x == 123.456f) store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]));
+                if (acc[t][0].x == 123.456f) store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
 #else
-                store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]));
+                store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
 #endif
             }
         }
     };
-    f32x4 wa[NTW][kPrefetch], wb[NTW][kPrefetch];
+    f32x4 wa[NTW][KP], wb[NTW][KP];
     constexpr int DB = (MT == 1 ? 0 : 16) + (NTW == 2 ? 0 : 8);
     MZ_DBG_T(t_all)
     MZ_TL(1)
-    fetch(wa);
+    fetch(wa);  // the weights have the longest way: requested before the operand pipeline is primed
     MZ_TL(2)
+    {
+        const f32x4 sh = rows.shared(m, 4 * kq);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xc[mt] = Rows::form(sh, rows.raw(mt, m, 4 * kq));
+    }
     for (int i = 0; i < total; i += 2) {
         MZ_DBG_T(t_f)
         if (i + 1 < total) fetch(wb);
@@ -406,35 +489,50 @@ __device__ __forceinline__ void dense_group_body(const Rows &rows, const float *
 // per-lane stack memory (written 64 times per wave and eventually to HBM), scalars travel in
 // registers.  `Rows` is rebuilt from four scalars (see LdsRows / ChildRows ::from).
 template <int MT, typename Rows>
-__device__ __noinline__ void dense_group1_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const float *packed,
-                                               int Kp, int w_off, int b_off, int N, int Np, int act, lds_f *Ys, int ldy,
-                                               const lds_f *row_add, int row_add_ld, const lds_i *row_sel, int wave0,
-                                               int nwaves) {
-    const DensePart parts[1] = {DensePart{w_off, b_off, N, Np, act, Ys, ldy, row_add, row_add_ld, row_sel}.uniform()};
-    dense_group_body<MT, 1>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts,
-                            uni(wave0), uni(nwaves));
+__device__ __noinline__ void dense_group1_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const lds_i *r4,
+                                               const float *packed, int Kp, int w_off, int b_off, int N, int Np, int act,
+                                               lds_f *Ys, int ldy, const lds_f *row_add, int row_add_ld,
+                                               const lds_i *row_sel, int dot_w, lds_f *dot_out, int wave0, int nwaves) {
+    const DensePart parts[1] = {
+        DensePart{w_off, b_off, N, Np, act, Ys, ldy, row_add, row_add_ld, row_sel, dot_w, dot_out}.uniform()};
+    dense_group_body<MT, 1>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3), uni_lds(r4)), uni_ptr(packed), uni(Kp),
+                            parts, uni(wave0), uni(nwaves));
 }
 template <int MT, typename Rows>
-__device__ __noinline__ void dense_group2_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const float *packed,
-                                               int Kp, int w0, int b0, int N0, int Np0, int act0, lds_f *Y0, int ldy0,
-                                               int w1, int b1, int N1, int Np1, int act1, lds_f *Y1, int ldy1, int wave0,
-                                               int nwaves) {
-    const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, nullptr, 0, nullptr}.uniform(),
-                                DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, nullptr, 0, nullptr}.uniform()};
-    dense_group_body<MT, 2>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3)), uni_ptr(packed), uni(Kp), parts,
-                            uni(wave0), uni(nwaves));
+__device__ __noinline__ void dense_group2_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const lds_i *r4,
+                                               const float *packed, int Kp, int w0, int b0, int N0, int Np0, int act0,
+                                               lds_f *Y0, int ldy0, int dw0, lds_f *do0, int w1, int b1, int N1, int Np1,
+                                               int act1, lds_f *Y1, int ldy1, int dw1, lds_f *do1, int wave0, int nwaves) {
+    const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, nullptr, 0, nullptr, dw0, do0}.uniform(),
+                                DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, nullptr, 0, nullptr, dw1, do1}.uniform()};
+    dense_group_body<MT, 2>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3), uni_lds(r4)), uni_ptr(packed), uni(Kp),
+                            parts, uni(wave0), uni(nwaves));
 }
 template <int MT, typename Rows>
 __device__ __forceinline__ void dense_group1(const Rows &rows, const float *packed, int Kp, const DensePart &p,
                                              const Team &tm = whole_workgroup()) {
-    dense_group1_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act,
-                                p.Ys, p.ldy, p.row_add, p.row_add_ld, p.row_sel, tm.wave0, tm.nwaves);
+    dense_group1_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), rows.s4(), packed, Kp, p.w_off, p.b_off, p.N,
+                                p.Np, p.act, p.Ys, p.ldy, p.row_add, p.row_add_ld, p.row_sel, p.dot_w_off, p.dot_out,
+                                tm.wave0, tm.nwaves);
 }
 template <int MT, typename Rows>
 __device__ __forceinline__ void dense_group2(const Rows &rows, const float *packed, int Kp, const DensePart &p,
                                              const DensePart &q, const Team &tm = whole_workgroup()) {
-    dense_group2_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act,
-                                p.Ys, p.ldy, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys, q.ldy, tm.wave0, tm.nwaves);
+    dense_group2_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), rows.s4(), packed, Kp, p.w_off, p.b_off, p.N,
+                                p.Np, p.act, p.Ys, p.ldy, p.dot_w_off, p.dot_out, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys,
+                                q.ldy, q.dot_w_off, q.dot_out, tm.wave0, tm.nwaves);
+}
+
+// Second half of a folded scalar layer: out[row * out_ld] = act(bias + sum over the tiles of
+// dot[tile][row]), tiles in ascending order.  `rows` = 16*MT of the producing call.  No sync.
+__device__ __forceinline__ void finish_dot(const lds_f *dot, int tiles, int rows, const float *__restrict__ packed,
+                                           const mz_packed_layer &L1, lds_f *out, int out_ld, const Team &tm) {
+    const float b = packed[L1.b_off];
+    for (int r = tm.tid(); r < rows; r += tm.nthreads()) {
+        float s = 0.0f;
+        for (int t = 0; t < tiles; ++t) s += dot[t * rows + r];
+        out[r * out_ld] = activate(s + b, L1.act);
+    }
 }
 
 // Weight sources of dense_narrow: chunk q (4 consecutive k) of output column `col`.
@@ -596,26 +694,52 @@ __device__ __forceinline__ void softmax_rows(lds_f *Ys, int ldy, int rows, int N
     softmax_rows(Ys, ldy, rows, N, times, tm);
 }
 
-// Runs every layer of `M` over the row tile, ping-ponging between two LDS buffers.
-// Returns the buffer that holds the output.  A final MZ_ACT_SOFTMAX layer is computed as a
-// linear layer followed by softmax_rows.
+// A head that ends in [wide layer, one-output layer] has that pair folded: the wide layer's
+// epilogue forms the dot products with the output layer's weights (DensePart::dot_out).
+__host__ __device__ inline bool tail_foldable(const mz_packed_mlp &M) {
+    return M.n_layers >= 2 && M.layer[M.n_layers - 1].N == 1 && M.layer[M.n_layers - 2].N > 8 &&
+           M.layer[M.n_layers - 1].K == M.layer[M.n_layers - 2].N;
+}
+
+// Runs layers [first, n) of `M` over the team's row tile (input `src`, row stride `ld`),
+// ping-ponging between two LDS buffers.  Returns the buffer that holds the output, row stride
+// *out_ld.  A MZ_ACT_SOFTMAX layer is a linear layer followed by softmax_rows.  `narrow`
+// (optional): byte offsets into `smem` of LDS copies of narrow layers' weights, or -1.
+// Every layer ends with a team sync.
 template <int MT>
-__device__ __forceinline__ lds_f *mlp_tile(const mz_packed_mlp &M, const float *__restrict__ packed, lds_f *in_buf,
-                                           int in_ld, lds_f *buf_a, lds_f *buf_b, int *out_ld) {
-    lds_f *src = in_buf;
-    int ld = in_ld;
-    lds_f *dst = buf_a;
-    for (int i = 0; i < M.n_layers; ++i) {
+__device__ __forceinline__ lds_f *mlp_tile(Team &tm, const mz_packed_mlp &M, int first, const float *__restrict__ packed,
+                                           lds_f *src, int ld, lds_f *buf_a, lds_f *buf_b, int *out_ld,
+                                           unsigned char *smem = nullptr, const int *narrow = nullptr) {
+    const bool fold = tail_foldable(M) && first <= M.n_layers - 2;
+    const int plain_end = fold ? M.n_layers - 2 : M.n_layers;
+    for (int i = first; i < plain_end; ++i) {
         const mz_packed_layer &L = M.layer[i];
+        lds_f *dst = (src == buf_a) ? buf_b : buf_a;
         const int ldo = lds_stride(L.N);
-        dense_tile<MT>(src, ld, packed, L, dst, ldo);
-        if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, 16 * MT, L.N, 1);
+        const lds_f *nw = (narrow && narrow[i] >= 0) ? to_lds(smem + narrow[i]) : nullptr;
+        dense_tile<MT>(src, ld, packed, L, dst, ldo, nullptr, 0, nullptr, nw, tm);
+        if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, 16 * MT, L.N, 1, tm);
         src = dst;
         ld = ldo;
-        dst = (dst == buf_a) ? buf_b : buf_a;
+    }
+    if (fold) {
+        const mz_packed_layer &L = M.layer[M.n_layers - 2], &L1 = M.layer[M.n_layers - 1];
+        lds_f *dst = (src == buf_a) ? buf_b : buf_a;
+        dense_group1<MT>(LdsRows{src, ld}, packed, L.Kp, make_dot_part(L, L1, dst), tm);
+        tm.sync();
+        finish_dot(dst, L.Np >> 4, 16 * MT, packed, L1, dst, 1, tm);  // in place: row r ends in dst[r]
+        tm.sync();
+        src = dst;
+        ld = 1;
     }
     *out_ld = ld;
     return src;
+}
+template <int MT>
+__device__ __forceinline__ lds_f *mlp_tile(const mz_packed_mlp &M, const float *__restrict__ packed, lds_f *in_buf,
+                                           int in_ld, lds_f *buf_a, lds_f *buf_b, int *out_ld) {
+    Team tm = whole_workgroup();
+    return mlp_tile<MT>(tm, M, 0, packed, in_buf, in_ld, buf_a, buf_b, out_ld);
 }
 
 // Cooperative load of up to `rows` global rows (row r from src + row_index(r)*src_ld) into

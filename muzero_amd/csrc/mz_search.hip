@@ -33,11 +33,12 @@ constexpr int kPathCap = 16;  // select records the first kPathCap levels of its
 
 struct Lds {
     int ld_d, ld_h, ld_r, rows_r, tab_rows;
+    int fold_reward;  // reward head = [wide, one-output]: folded over the children, no r1/r2/rout
     // byte offsets.  x: leaf latents, later the simulation's current latent; z: merge
     // pre-activation of the leaf; zs: merge pre-activation along the simulation; he1/he2: hidden
     // activations of the expansion; hs1/hs2: of the simulation; r1/r2/rout: reward head over the
     // children
-    size_t x, z, zs, tab, he1, he2, hs1, hs2, r1, r2, rout, prior, rew, roll, ints, path, tabs, total;
+    size_t x, z, zs, tab, he1, he2, hs1, hs2, r1, r2, rout, dot, prior, rew, roll, ints, path, tabs, total;
     int narrow[3][MZ_MAX_LAYERS];  // byte offset of a narrow layer's LDS weight copy (policy, value, reward), or -1
 };
 
@@ -67,9 +68,11 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
     L.he2 = take(P.policy.n_layers >= 2 ? sizeof(float) * kTrees * ld_he : 0);
     L.hs1 = take(sizeof(float) * kTrees * L.ld_h);
     L.hs2 = take(sizeof(float) * kTrees * L.ld_h);
-    L.r1 = take(sizeof(float) * L.rows_r * L.ld_r);
-    L.r2 = take(P.reward.n_layers >= 3 ? sizeof(float) * L.rows_r * L.ld_r : 0);
-    L.rout = take(sizeof(float) * L.rows_r * lds_stride(1));
+    L.fold_reward = (P.reward.n_layers == 2 && tail_foldable(P.reward)) ? 1 : 0;
+    L.r1 = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * L.ld_r);
+    L.r2 = take(!L.fold_reward && P.reward.n_layers >= 3 ? sizeof(float) * L.rows_r * L.ld_r : 0);
+    L.rout = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * lds_stride(1));
+    L.dot = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * L.rows_r : 0);
     L.prior = take(sizeof(float) * kTrees * A);
     L.rew = take(sizeof(float) * kTrees * L.tab_rows);
     L.roll = take(sizeof(float) * kTrees * (depth + 1));
@@ -87,23 +90,11 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
     return L;
 }
 
-// Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2.  Every layer ends
-// with a team sync.
+// Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2.
 __device__ __forceinline__ lds_f *mlp16(Team &tm, const mz_packed_mlp &M, int first, const float *__restrict__ blob,
                                         lds_f *src, int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
                                         const int (&narrow)[MZ_MAX_LAYERS]) {
-    for (int i = first; i < M.n_layers; ++i) {
-        const mz_packed_layer &L = M.layer[i];
-        lds_f *dst = (src == h1) ? h2 : h1;
-        const int ldo = lds_stride(L.N);
-        const lds_f *nw = narrow[i] >= 0 ? to_lds(smem + narrow[i]) : nullptr;
-        dense_tile<1>(src, ld, blob, L, dst, ldo, nullptr, 0, nullptr, nw, tm);
-        if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, kTrees, L.N, 1, tm);
-        src = dst;
-        ld = ldo;
-    }
-    *out_ld = ld;
-    return src;
+    return mlp_tile<1>(tm, M, first, blob, src, ld, h1, h2, out_ld, smem, narrow);
 }
 
 // After the leaf's first layers, a simulation round splits the workgroup into two teams of
@@ -134,6 +125,7 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     lds_f *R1 = to_lds(smem_raw + L.r1);
     lds_f *R2 = to_lds(smem_raw + L.r2);
     lds_f *Rout = to_lds(smem_raw + L.rout);
+    lds_f *DotE = to_lds(smem_raw + L.dot);
     lds_f *s_prior = to_lds(smem_raw + L.prior);
     lds_f *s_rew = to_lds(smem_raw + L.rew);
     lds_f *s_roll = to_lds(smem_raw + L.roll);
@@ -248,6 +240,22 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
         MZ_STAMP(6)  // expand: child latents to the pool
         // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time
         for (int a0 = 0; a0 < A; a0 += MTC) {
+            if (L.fold_reward) {
+                // hidden layer over the children with the output layer folded into its epilogue
+                const mz_packed_layer &L0 = P.reward.layer[0], &L1 = P.reward.layer[1];
+                dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp, make_dot_part(L0, L1, DotE), tm);
+                tm.sync();
+                MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
+                const float b2 = blob[L1.b_off];
+                const int tiles = L0.Np >> 4;
+                for (int r = ttid; r < kTrees * MTC; r += tn) {
+                    float sum = 0.0f;
+                    for (int k = 0; k < tiles; ++k) sum += DotE[k * (kTrees * MTC) + r];
+                    s_rew[(r % kTrees) * L.tab_rows + a0 + r / kTrees] = activate(sum + b2, L1.act);
+                }
+                tm.sync();
+                continue;
+            }
             lds_f *src;
             int ld, first;
             if (P.reward.layer[0].N > 8) {
@@ -265,14 +273,11 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
                 tm.sync();
                 src = R1, ld = L.ld_r, first = 0;
             }
-            for (int i = first; i < P.reward.n_layers; ++i) {
-                const mz_packed_layer &Li = P.reward.layer[i];
-                const bool last = i == P.reward.n_layers - 1;
-                lds_f *dst = last ? Rout : (src == R1 ? R2 : R1);
-                const int ldo = lds_stride(Li.N);
-                dense_tile<MTC>(src, ld, blob, Li, dst, ldo, nullptr, 0, nullptr,
-                                L.narrow[2][i] >= 0 ? to_lds(smem_raw + L.narrow[2][i]) : nullptr, tm);
-                src = dst, ld = ldo;
+            {
+                int ldo;
+                src = mlp_tile<MTC>(tm, P.reward, first, blob, src, ld, R1, P.reward.n_layers >= 3 ? R2 : Rout, &ldo, smem_raw,
+                                    L.narrow[2]);
+                ld = ldo;
             }
             for (int i = ttid; i < kTrees * MTC; i += tn) {
                 const int al = i / kTrees, t = i % kTrees;

@@ -30,16 +30,34 @@ __global__ void __launch_bounds__(kThreads) k_mb(const float *__restrict__ blob,
 #else
             dense_group1<7>(ChildRows{Z, ld_d, Tab, ld_d}, blob,
 #endif
- 176, DensePart{0, 22528, 128, 128, MZ_ACT_RELU, R1, ld_r, nullptr, 0, nullptr});
+ 176, DensePart{0, 22528, 128, 128, MZ_ACT_RELU, R1, ld_r, nullptr, 0, nullptr, -1, nullptr});
         } else if (VARIANT == 1) {  // policy layer 1 | merge: K=176, N=256+168
-            dense_group2<1>(LdsRows{Z, ld_d}, blob, 176, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H1, ld_h, nullptr, 0, nullptr},
-                            DensePart{45056, 90300, 168, 176, MZ_ACT_NONE, R1, ld_d, nullptr, 0, nullptr});
+            dense_group2<1>(LdsRows{Z, ld_d}, blob, 176, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H1, ld_h, nullptr, 0, nullptr, -1, nullptr},
+                            DensePart{45056, 90300, 168, 176, MZ_ACT_NONE, R1, ld_d, nullptr, 0, nullptr, -1, nullptr});
         } else if (VARIANT == 2) {  // policy layer 2: K=256, N=256
-            dense_group1<1>(LdsRows{H1, ld_h}, blob, 256, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr});
+            dense_group1<1>(LdsRows{H1, ld_h}, blob, 256, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr, -1, nullptr});
         } else if (VARIANT == 3) {  // value layer 2: K=256, N=128
-            dense_group1<1>(LdsRows{H1, ld_h}, blob, 256, DensePart{0, 90000, 128, 128, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr});
+            dense_group1<1>(LdsRows{H1, ld_h}, blob, 256, DensePart{0, 90000, 128, 128, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr, -1, nullptr});
+        } else if (VARIANT == 13) {  // reward layer 1 over 112 child rows on a team of 4 waves
+            if (uni(threadIdx.x >> 6) < 4) {
+                Team te{0, 4, nullptr, 0};
+                dense_group1<7>(ChildRows{Z, ld_d, Tab, ld_d}, blob, 176, DensePart{0, 22528, 128, 128, MZ_ACT_RELU, R1, ld_r, nullptr, 0, nullptr, -1, nullptr}, te);
+            }
+        } else if (VARIANT >= 10) {
+            const int half = uni(threadIdx.x >> 6) >= 4;
+            Team te{0, 4, nullptr, 0}, ts{4, 4, nullptr, 0};
+            if (!half && (VARIANT == 10 || VARIANT == 12)) {
+                for (int pass = 0; pass < 2; ++pass)
+                    dense_group1<4>(ChildRows{Z, ld_d, Tab, ld_d}, blob, 176, DensePart{0, 22528, 128, 128, MZ_ACT_RELU, R1, ld_r, nullptr, 0, nullptr, -1, nullptr}, te);
+            }
+            if (half && (VARIANT == 11 || VARIANT == 12)) {
+                dense_group2<1>(LdsRows{Z + 16 * ld_d, ld_d}, blob, 176, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H1, ld_h, nullptr, 0, nullptr, -1, nullptr},
+                                DensePart{45056, 90300, 168, 176, MZ_ACT_NONE, H2, ld_d, nullptr, 0, nullptr, -1, nullptr}, ts);
+                dense_group1<1>(LdsRows{H1, ld_h}, blob, 256, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr, -1, nullptr}, ts);
+                dense_group1<1>(LdsRows{H1, ld_h}, blob, 256, DensePart{0, 90000, 256, 256, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr, -1, nullptr}, ts);
+            }
         } else if (VARIANT == 4) {  // reward layer 1 on 16 rows: K=176, N=128
-            dense_group1<1>(LdsRows{Z, ld_d}, blob, 176, DensePart{0, 90000, 128, 128, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr});
+            dense_group1<1>(LdsRows{Z, ld_d}, blob, 176, DensePart{0, 90000, 128, 128, MZ_ACT_RELU, H2, ld_h, nullptr, 0, nullptr, -1, nullptr});
         }
 #ifdef MZ_EXP_TIMELINE
         if ((threadIdx.x & 63) == 0) mz_tl[threadIdx.x >> 6][7] = clock64();
@@ -69,6 +87,10 @@ extern "C" int mb_run(int variant, int iters, const float *blob, unsigned long l
         case 1: return go(k_mb<1>);
         case 2: return go(k_mb<2>);
         case 3: return go(k_mb<3>);
+        case 10: return go(k_mb<10>);
+        case 11: return go(k_mb<11>);
+        case 12: return go(k_mb<12>);
+        case 13: return go(k_mb<13>);
         default: return go(k_mb<4>);
     }
 }
