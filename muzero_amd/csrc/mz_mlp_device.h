@@ -694,11 +694,29 @@ __device__ __forceinline__ void softmax_rows(lds_f *Ys, int ldy, int rows, int N
     softmax_rows(Ys, ldy, rows, N, times, tm);
 }
 
+// Layer descriptors may live in kernel arguments or in LDS (a kernel that holds many of them
+// copies them to LDS to keep them out of scalar registers between uses): these helpers accept
+// either, and return wave-uniform values.
+template <typename LayerRef>
+__device__ __forceinline__ mz_packed_layer load_layer(const LayerRef &s) {
+    mz_packed_layer L;
+    L.K = uni(s.K);
+    L.N = uni(s.N);
+    L.Kp = uni(s.Kp);
+    L.Np = uni(s.Np);
+    L.act = uni(s.act);
+    L._pad = 0;
+    L.w_off = uni((int)s.w_off);
+    L.b_off = uni((int)s.b_off);
+    return L;
+}
+
 // A head that ends in [wide layer, one-output layer] has that pair folded: the wide layer's
 // epilogue forms the dot products with the output layer's weights (DensePart::dot_out).
-__host__ __device__ inline bool tail_foldable(const mz_packed_mlp &M) {
-    return M.n_layers >= 2 && M.layer[M.n_layers - 1].N == 1 && M.layer[M.n_layers - 2].N > 8 &&
-           M.layer[M.n_layers - 1].K == M.layer[M.n_layers - 2].N;
+template <typename MLP>
+__host__ __device__ inline bool tail_foldable(const MLP &M) {
+    const int n = M.n_layers;
+    return n >= 2 && M.layer[n - 1].N == 1 && M.layer[n - 2].N > 8 && M.layer[n - 1].K == M.layer[n - 2].N;
 }
 
 // Runs layers [first, n) of `M` over the team's row tile (input `src`, row stride `ld`),
@@ -706,24 +724,26 @@ __host__ __device__ inline bool tail_foldable(const mz_packed_mlp &M) {
 // *out_ld.  A MZ_ACT_SOFTMAX layer is a linear layer followed by softmax_rows.  `narrow`
 // (optional): byte offsets into `smem` of LDS copies of narrow layers' weights, or -1.
 // Every layer ends with a team sync.
-template <int MT>
-__device__ __forceinline__ lds_f *mlp_tile(Team &tm, const mz_packed_mlp &M, int first, const float *__restrict__ packed,
+template <int MT, typename MLP, typename NarrowPtr = const int *>
+__device__ __forceinline__ lds_f *mlp_tile(Team &tm, const MLP &M, int first, const float *__restrict__ packed,
                                            lds_f *src, int ld, lds_f *buf_a, lds_f *buf_b, int *out_ld,
-                                           unsigned char *smem = nullptr, const int *narrow = nullptr) {
-    const bool fold = tail_foldable(M) && first <= M.n_layers - 2;
-    const int plain_end = fold ? M.n_layers - 2 : M.n_layers;
+                                           unsigned char *smem = nullptr, NarrowPtr narrow = nullptr) {
+    const int n = uni(M.n_layers);
+    const bool fold = uni((int)tail_foldable(M)) && first <= n - 2;
+    const int plain_end = fold ? n - 2 : n;
     for (int i = first; i < plain_end; ++i) {
-        const mz_packed_layer &L = M.layer[i];
+        const mz_packed_layer L = load_layer(M.layer[i]);
         lds_f *dst = (src == buf_a) ? buf_b : buf_a;
         const int ldo = lds_stride(L.N);
-        const lds_f *nw = (narrow && narrow[i] >= 0) ? to_lds(smem + narrow[i]) : nullptr;
+        const int nwo = narrow ? uni(narrow[i]) : -1;
+        const lds_f *nw = nwo >= 0 ? to_lds(smem + nwo) : nullptr;
         dense_tile<MT>(src, ld, packed, L, dst, ldo, nullptr, 0, nullptr, nw, tm);
         if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, 16 * MT, L.N, 1, tm);
         src = dst;
         ld = ldo;
     }
     if (fold) {
-        const mz_packed_layer &L = M.layer[M.n_layers - 2], &L1 = M.layer[M.n_layers - 1];
+        const mz_packed_layer L = load_layer(M.layer[n - 2]), L1 = load_layer(M.layer[n - 1]);
         lds_f *dst = (src == buf_a) ? buf_b : buf_a;
         dense_group1<MT>(LdsRows{src, ld}, packed, L.Kp, make_dot_part(L, L1, dst), tm);
         tm.sync();

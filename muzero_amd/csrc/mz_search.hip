@@ -38,7 +38,7 @@ struct Lds {
     // pre-activation of the leaf; zs: merge pre-activation along the simulation; he1/he2: hidden
     // activations of the expansion; hs1/hs2: of the simulation; r1/r2/rout: reward head over the
     // children
-    size_t x, z, zs, tab, he1, he2, hs1, hs2, r1, r2, rout, dot, prior, rew, roll, ints, path, tabs, total;
+    size_t x, z, zs, tab, he1, he2, hs1, hs2, r1, r2, rout, dot, dots, dotv, nets, prior, rew, roll, ints, path, tabs, total;
     int narrow[3][MZ_MAX_LAYERS];  // byte offset of a narrow layer's LDS weight copy (policy, value, reward), or -1
 };
 
@@ -73,6 +73,9 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
     L.r2 = take(!L.fold_reward && P.reward.n_layers >= 3 ? sizeof(float) * L.rows_r * L.ld_r : 0);
     L.rout = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * lds_stride(1));
     L.dot = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * L.rows_r : 0);
+    L.dots = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * kTrees : 0);
+    L.dotv = take(P.value.n_layers == 2 && tail_foldable(P.value) ? sizeof(float) * (P.value.layer[0].Np >> 4) * kTrees : 0);
+    L.nets = take(sizeof(mz_packed_nets) + sizeof(int) * 3 * MZ_MAX_LAYERS);  // plan + narrow-layer offsets
     L.prior = take(sizeof(float) * kTrees * A);
     L.rew = take(sizeof(float) * kTrees * L.tab_rows);
     L.roll = take(sizeof(float) * kTrees * (depth + 1));
@@ -91,9 +94,10 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
 }
 
 // Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2.
-__device__ __forceinline__ lds_f *mlp16(Team &tm, const mz_packed_mlp &M, int first, const float *__restrict__ blob,
-                                        lds_f *src, int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
-                                        const int (&narrow)[MZ_MAX_LAYERS]) {
+template <typename MLP>
+__device__ __forceinline__ lds_f *mlp16(Team &tm, const MLP &M, int first, const float *__restrict__ blob, lds_f *src,
+                                        int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
+                                        const lds_i *narrow) {
     return mlp_tile<1>(tm, M, first, blob, src, ld, h1, h2, out_ld, smem, narrow);
 }
 
@@ -110,7 +114,7 @@ __device__ __forceinline__ lds_f *mlp16(Team &tm, const mz_packed_mlp &M, int fi
 // meet again at the workgroup barrier before the backup.
 template <int MTC>
 __global__ void __launch_bounds__(kThreads)
-k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_params q, Lds L,
+k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q, Lds L,
          double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
          int32_t *__restrict__ visits) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -126,6 +130,8 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     lds_f *R2 = to_lds(smem_raw + L.r2);
     lds_f *Rout = to_lds(smem_raw + L.rout);
     lds_f *DotE = to_lds(smem_raw + L.dot);
+    lds_f *DotS = to_lds(smem_raw + L.dots);
+    lds_f *DotV = to_lds(smem_raw + L.dotv);
     lds_f *s_prior = to_lds(smem_raw + L.prior);
     lds_f *s_rew = to_lds(smem_raw + L.rew);
     lds_f *s_roll = to_lds(smem_raw + L.roll);
@@ -136,6 +142,24 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     lds_i *s_depth = s_leaf_tp + kTrees;
     lds_i *s_root = s_depth + kTrees;   // root to_play per tree
     lds_i *s_team = s_root + kTrees;    // [4] per team: arrival counter, error flag
+    // The network plan (over a kilobyte of layer descriptors) and the narrow-layer offsets are
+    // copied to LDS once and read from there where a layer is run: as kernel arguments they
+    // would sit in scalar registers for the whole kernel and spill.
+    typedef __attribute__((address_space(3))) const mz_packed_nets lds_nets;
+    const lds_nets &P = *reinterpret_cast<lds_nets *>((lds_i *)to_lds_i(smem_raw + L.nets));
+    const lds_i *s_narrow = to_lds_i(smem_raw + L.nets + sizeof(mz_packed_nets));  // [3][MZ_MAX_LAYERS]
+    {
+        const int words = (int)(sizeof(mz_packed_nets) / sizeof(int));
+        lds_i *dst = to_lds_i(smem_raw + L.nets);
+        const int *src = reinterpret_cast<const int *>(&Pk);
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (int i = 0; i < words; ++i) dst[i] = src[i];
+            for (int m = 0; m < 3; ++m)
+                for (int i = 0; i < MZ_MAX_LAYERS; ++i) dst[words + m * MZ_MAX_LAYERS + i] = L.narrow[m][i];
+        }
+    }
+    __syncthreads();
     int *s_path = reinterpret_cast<int *>(smem_raw + L.path);
     double *s_tab = reinterpret_cast<double *>(smem_raw + L.tabs);
 
@@ -153,13 +177,23 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
         t_prev = t_now;                                            \
     }
 
-    const int A = P.A, D = P.D, S = q.S, depth = q.depth;
+    const int A = Pk.A, D = Pk.D, Dp = Pk.Dp, S = q.S, depth = q.depth;
+    // small facts about the heads, kept in registers; everything else about a layer is read from
+    // the LDS copy where the layer runs
+    const int pol_layers = Pk.policy.n_layers, val_layers = Pk.value.n_layers, rew_layers = Pk.reward.n_layers;
+    const bool pol0_softmax_only = Pk.policy.layer[0].act == MZ_ACT_SOFTMAX && pol_layers == 1;
+    const bool rew0_wide = Pk.reward.layer[0].N > 8;
+    const bool grouped_first = Pk.policy.layer[0].N > 8 && Pk.policy.layer[0].Kp == Pk.merge.layer[0].Kp;
+    const bool fold_value2 = val_layers == 2 && tail_foldable(Pk.value);
+    const bool grouped_last = L.fold_reward && val_layers >= 2 && Pk.value.layer[0].N > 8 &&
+                              Pk.value.layer[0].Kp == Pk.reward.layer[0].Kp;
+    (void)val_layers;
     const int ld_d = L.ld_d;
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * kTrees;
     const int trees = min(kTrees, p.G - g0);
     const int lpt = q.lanes_per_tree;
-    const int ld_p1 = lds_stride(P.policy.layer[0].N);
+    const int ld_p1 = lds_stride(Pk.policy.layer[0].N);
     const int half = uni(tid >> 6) >= kWaves / 2 ? 1 : 0;
     int team_arrived = 0;  // arrivals this wave's team counter shows after the wave's latest team sync
 
@@ -167,17 +201,16 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     // input rows; ends with a barrier.  (The merge layer's stored epilogue is a relu for the
     // stand-alone kernel; here its pre-activation is kept and the per-action table is added
     // where a child latent is formed.)
-    auto first_layers = [&](Team &tm, const lds_f *in, lds_f *h_out, lds_f *z_out) {
-        const lds_f *nw = L.narrow[0][0] >= 0 ? to_lds(smem_raw + L.narrow[0][0]) : nullptr;
-        if (P.policy.layer[0].N > 8 && P.policy.layer[0].Kp == P.merge.layer[0].Kp) {
-            dense_group2<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp,
-                            make_part(P.policy.layer[0], h_out, ld_p1, P.policy.layer[0].act),
-                            make_part(P.merge.layer[0], z_out, ld_d, MZ_ACT_NONE), tm);
+    auto first_layers = [&](Team &tm, const auto &rows, const lds_f *in, lds_f *h_out, lds_f *z_out) {
+        const mz_packed_layer Lp0 = load_layer(P.policy.layer[0]), Lm0 = load_layer(P.merge.layer[0]);
+        if (grouped_first) {
+            dense_group2<1>(rows, blob, Lm0.Kp, make_part(Lp0, h_out, ld_p1, Lp0.act), make_part(Lm0, z_out, ld_d, MZ_ACT_NONE), tm);
             tm.sync();
-        } else {
-            dense_tile<1>(in, ld_d, blob, P.policy.layer[0], h_out, ld_p1, nullptr, 0, nullptr, nw, tm);
-            dense_group1<1>(LdsRows{in, ld_d}, blob, P.merge.layer[0].Kp,
-                            make_part(P.merge.layer[0], z_out, ld_d, MZ_ACT_NONE), tm);
+        } else {  // `in`: the same rows materialised in LDS
+            const int nwo = uni(s_narrow[0]);
+            const lds_f *nw = nwo >= 0 ? to_lds(smem_raw + nwo) : nullptr;
+            dense_tile<1>(in, ld_d, blob, Lp0, h_out, ld_p1, nullptr, 0, nullptr, nw, tm);
+            dense_group1<1>(LdsRows{in, ld_d}, blob, Lm0.Kp, make_part(Lm0, z_out, ld_d, MZ_ACT_NONE), tm);
             tm.sync();
         }
     };
@@ -186,9 +219,9 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     auto expand_tail = [&](Team &tm, int e, int base) {
         const int ttid = tm.tid(), tn = tm.nthreads();
         int ld_p;
-        lds_f *pol = mlp16(tm, P.policy, 1, blob, He1, ld_p1, He1, He2, &ld_p, smem_raw, L.narrow[0]);
+        lds_f *pol = mlp16(tm, P.policy, 1, blob, He1, ld_p1, He1, He2, &ld_p, smem_raw, s_narrow);
         MZ_STAMP(4)  // expand: remaining policy layers
-        if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pol, ld_p, kTrees, A, 1, tm);
+        if (pol0_softmax_only) softmax_rows(pol, ld_p, kTrees, A, 1, tm);
         softmax_rows(pol, ld_p, kTrees, A, 1, tm);  // expand_node's extra softmax (expansion.py:27)
         for (int i = ttid; i < kTrees * A; i += tn) {
             const int t = i / A, a = i - t * A;
@@ -242,7 +275,7 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
         for (int a0 = 0; a0 < A; a0 += MTC) {
             if (L.fold_reward) {
                 // hidden layer over the children with the output layer folded into its epilogue
-                const mz_packed_layer &L0 = P.reward.layer[0], &L1 = P.reward.layer[1];
+                const mz_packed_layer L0 = load_layer(P.reward.layer[0]), L1 = load_layer(P.reward.layer[1]);
                 dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp, make_dot_part(L0, L1, DotE), tm);
                 tm.sync();
                 MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
@@ -258,8 +291,8 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             }
             lds_f *src;
             int ld, first;
-            if (P.reward.layer[0].N > 8) {
-                const mz_packed_layer &L0 = P.reward.layer[0];
+            if (rew0_wide) {
+                const mz_packed_layer L0 = load_layer(P.reward.layer[0]);
                 dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp,
                                   make_part(L0, R1, lds_stride(L0.N), L0.act), tm);
                 tm.sync();
@@ -275,8 +308,8 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             }
             {
                 int ldo;
-                src = mlp_tile<MTC>(tm, P.reward, first, blob, src, ld, R1, P.reward.n_layers >= 3 ? R2 : Rout, &ldo, smem_raw,
-                                    L.narrow[2]);
+                src = mlp_tile<MTC>(tm, P.reward, first, blob, src, ld, R1, rew_layers >= 3 ? R2 : Rout, &ldo, smem_raw,
+                                    s_narrow + 2 * MZ_MAX_LAYERS);
                 ld = ldo;
             }
             for (int i = ttid; i < kTrees * MTC; i += tn) {
@@ -298,53 +331,48 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
         MZ_STAMP(9)  // commit
     };
 
-    // ---- the simulation from the drawn child (Z valid; writes X, Zs, Hs1, Hs2) -----------------
+    // ---- the simulation from the drawn child (Z, s_act valid; writes X, Zs, Hs1, Hs2) ---------
+    // A latent along the rollout is relu(z + table[action]) with z the merge pre-activation of
+    // the previous latent (Z for the drawn child, Zs afterwards).  Where the layers that consume
+    // it are wide, they read it through PickedRows and it is never materialised; otherwise it is
+    // formed in X first.
     auto simulate = [&](Team &tm, int e, int base) {
-        const int ttid = tm.tid(), tn = tm.nthreads();
-        if (ttid < kTrees) {
-            int rc = 0;
-            if (ttid < trees) rc = q.rand_child[(size_t)(g0 + ttid) * (S + 1) + e];
-            rc = min(max(rc, 0), A - 1);
-            s_act[ttid] = rc;
-            s_child[ttid] = base + rc;
-            if (q.child_trace && ttid < trees) q.child_trace[(size_t)(g0 + ttid) * S + (e - 1)] = base + rc;
-        }
-        tm.sync();
-        for (int d = 0; d <= depth; ++d) {
-            // X <- relu(z + table[action]): the drawn child of the leaf for d = 0 (z = Z), the
-            // greedy step afterwards (z = Zs).  Columns [D, Dp) of z and the table are zero, so
-            // whole float4s can be processed.
-            {
-                const lds_f *zsrc = d == 0 ? Z : Zs;
-                const int q4 = ld_d >> 2, dp4 = P.Dp >> 2;
-                const int wv = uni(ttid >> 6), lane = ttid & 63;
-                for (int t = wv; t < kTrees; t += tm.nwaves) {
-                    const lds_f *trow = Tab + s_act[t] * ld_d;
-                    for (int c4 = lane; c4 < q4; c4 += 64) {
-                        const f32x4 z = *reinterpret_cast<const lds_f4 *>(zsrc + t * ld_d + 4 * c4);
-                        const f32x4 b = *reinterpret_cast<const lds_f4 *>(trow + 4 * c4);
-                        f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
-                        if (c4 >= dp4) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<lds_f4 *>(X + t * ld_d + 4 * c4) = v;
-                    }
+        const int ttid = tm.tid();
+        auto form_x = [&](const lds_f *zsrc) {
+            const int q4 = ld_d >> 2, dp4 = Dp >> 2;
+            const int wv = uni(ttid >> 6), lane = ttid & 63;
+            for (int t = wv; t < kTrees; t += tm.nwaves) {
+                const lds_f *trow = Tab + s_act[t] * ld_d;
+                for (int c4 = lane; c4 < q4; c4 += 64) {
+                    const f32x4 z = *reinterpret_cast<const lds_f4 *>(zsrc + t * ld_d + 4 * c4);
+                    const f32x4 b = *reinterpret_cast<const lds_f4 *>(trow + 4 * c4);
+                    f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
+                    if (c4 >= dp4) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<lds_f4 *>(X + t * ld_d + 4 * c4) = v;
                 }
             }
             tm.sync();
-            MZ_STAMP(16)  // simulate: next latent
-            if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
-                int ld_o;
-                const lds_f *r = mlp16(tm, P.reward, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, L.narrow[2]);
-                if (ttid < kTrees) s_roll[ttid * (depth + 1) + (d - 1)] = r[ttid * ld_o];
-                tm.sync();
-                MZ_STAMP(17)  // simulate: reward head
+        };
+        for (int d = 0; d < depth; ++d) {
+            if (d == 0 && grouped_first) {
+                first_layers(tm, PickedRows::from(Z, ld_d, Tab, ld_d, s_act), X, Hs1, Zs);
+            } else {
+                form_x(d == 0 ? Z : Zs);
+                MZ_STAMP(16)  // simulate: next latent
+                if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
+                    int ld_o;
+                    const lds_f *r = mlp16(tm, P.reward, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + 2 * MZ_MAX_LAYERS);
+                    if (ttid < kTrees) s_roll[ttid * (depth + 1) + (d - 1)] = r[ttid * ld_o];
+                    tm.sync();
+                    MZ_STAMP(17)  // simulate: reward head
+                }
+                first_layers(tm, LdsRows{X, ld_d}, X, Hs1, Zs);
             }
-            if (d == depth) break;
-            first_layers(tm, X, Hs1, Zs);
             MZ_STAMP(18)  // simulate: policy layer 1 | merge
             int ld_q;
-            lds_f *pq = mlp16(tm, P.policy, 1, blob, Hs1, ld_p1, Hs1, Hs2, &ld_q, smem_raw, L.narrow[0]);
+            lds_f *pq = mlp16(tm, P.policy, 1, blob, Hs1, ld_p1, Hs1, Hs2, &ld_q, smem_raw, s_narrow);
             MZ_STAMP(19)  // simulate: remaining policy layers
-            if (P.policy.layer[0].act == MZ_ACT_SOFTMAX && P.policy.n_layers == 1) softmax_rows(pq, ld_q, kTrees, A, 1, tm);
+            if (pol0_softmax_only) softmax_rows(pq, ld_q, kTrees, A, 1, tm);
             if (ttid < kTrees) {  // first maximum of the network's policy (simulation.py:36)
                 const lds_f *row = pq + ttid * ld_q;
                 int best = 0;
@@ -355,9 +383,41 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             tm.sync();
             MZ_STAMP(20)  // simulate: argmax
         }
-        {
+        // the last latent: reward of the last step (depth >= 1) and value
+        const lds_f *zfin = depth == 0 ? Z : Zs;
+        if (depth >= 1 && grouped_last) {
+            const mz_packed_layer R0 = load_layer(P.reward.layer[0]), R1l = load_layer(P.reward.layer[1]),
+                                  V0 = load_layer(P.value.layer[0]);
+            const int ld_v = lds_stride(V0.N);
+            // a two-layer value head is folded like the reward head (as every kernel does)
+            const bool fold_v = fold_value2;
+            const mz_packed_layer V1l = load_layer(P.value.layer[1]);
+            dense_group2<1>(PickedRows::from(zfin, ld_d, Tab, ld_d, s_act), blob, V0.Kp,
+                            fold_v ? make_dot_part(V0, V1l, DotV) : make_part(V0, Hs1, ld_v, V0.act),
+                            make_dot_part(R0, R1l, DotS), tm);
+            tm.sync();
+            finish_dot(DotS, R0.Np >> 4, kTrees, blob, R1l, s_roll + (depth - 1), depth + 1, tm);
+            MZ_STAMP(17)  // simulate: reward head | value layer 1
+            if (fold_v) {
+                finish_dot(DotV, V0.Np >> 4, kTrees, blob, V1l, s_roll + depth, depth + 1, tm);
+            } else {
+                int ld_o;
+                const lds_f *v = mlp16(tm, P.value, 1, blob, Hs1, ld_v, Hs1, Hs2, &ld_o, smem_raw, s_narrow + MZ_MAX_LAYERS);
+                if (ttid < kTrees) s_roll[ttid * (depth + 1) + depth] = v[ttid * ld_o];
+            }
+            MZ_STAMP(21)  // simulate: value head
+        } else {
+            form_x(zfin);
+            MZ_STAMP(16)  // simulate: next latent
+            if (depth >= 1) {
+                int ld_o;
+                const lds_f *r = mlp16(tm, P.reward, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + 2 * MZ_MAX_LAYERS);
+                if (ttid < kTrees) s_roll[ttid * (depth + 1) + (depth - 1)] = r[ttid * ld_o];
+                tm.sync();
+                MZ_STAMP(17)  // simulate: reward head
+            }
             int ld_o;
-            const lds_f *v = mlp16(tm, P.value, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, L.narrow[1]);
+            const lds_f *v = mlp16(tm, P.value, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + MZ_MAX_LAYERS);
             if (ttid < kTrees) s_roll[ttid * (depth + 1) + depth] = v[ttid * ld_o];
             MZ_STAMP(21)  // simulate: value head
         }
@@ -370,10 +430,10 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
     }
     for (int i = tid; i < L.tab_rows * ld_d; i += kThreads) {
         const int a = i / ld_d, c = i - a * ld_d;
-        Tab[i] = (a < A && c < P.Dp) ? blob[P.action_table_off + (size_t)a * P.Dp + c] : 0.0f;
+        Tab[i] = (a < A && c < Dp) ? blob[Pk.action_table_off + (size_t)a * Dp + c] : 0.0f;
     }
     {  // narrow layers (scalar heads, policy logits) keep their weights in LDS for the whole search
-        const mz_packed_mlp *mlps[3] = {&P.policy, &P.value, &P.reward};
+        const mz_packed_mlp *mlps[3] = {&Pk.policy, &Pk.value, &Pk.reward};
         for (int m = 0; m < 3; ++m)
             for (int i = 0; i < mlps[m]->n_layers; ++i)
                 if (L.narrow[m][i] >= 0)
@@ -443,6 +503,15 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
             }
             __syncthreads();
             MZ_STAMP(1)  // select
+            if (tid >= kThreads - kTrees) {  // the child each simulation starts from (src/search/mcts.py:64-66)
+                const int t = tid - (kThreads - kTrees);
+                int rc = 0;
+                if (t < trees) rc = q.rand_child[(size_t)(g0 + t) * (S + 1) + e];
+                rc = min(max(rc, 0), A - 1);
+                s_act[t] = rc;
+                s_child[t] = base + rc;
+                if (q.child_trace && t < trees) q.child_trace[(size_t)(g0 + t) * S + (e - 1)] = base + rc;
+            }
             if ((D & 3) == 0) {  // 16-byte rows: one tree per wave and pass, one float4 per lane
                 const int q4 = ld_d >> 2, d4 = D >> 2;
                 const int wv = uni(tid >> 6), lane = tid & 63;
@@ -466,7 +535,7 @@ k_search(mz_pool p, mz_packed_nets P, const float *__restrict__ blob, mz_search_
 
         // ---- the leaf's policy layer 1 and merge layer share the input: whole workgroup --------
         Team all = whole_workgroup();
-        first_layers(all, X, He1, Z);
+        first_layers(all, LdsRows{X, ld_d}, X, He1, Z);
         MZ_STAMP(3)  // expand: policy layer 1 | merge
 
         // the root expansion has no simulation: the whole workgroup expands
