@@ -18,7 +18,11 @@
 // is the "GEMV-like" regime: weights go straight from L2 to registers (no LDS staging),
 // kPrefetch k-steps ahead, a wave keeps two column tiles in flight so that the MFMA pipe
 // always has an independent accumulator to issue into, and the weight stream of a wave runs
-// on across its consecutive tiles.
+// on across its consecutive tiles.  On gfx950 an f32 MFMA and vector-ALU instructions of the
+// same SIMD do not execute concurrently (measured: a wave of independent v_fma makes no
+// progress while another wave issues v_mfma_f32_16x16x4_f32 back to back), so every vector
+// instruction in these routines is paid for in MFMA time: operands are formed with as few of
+// them as possible, addresses stay scalar, and the epilogues are branch-free.
 //
 // The layer functions are deliberately NOT inlined into their callers: each gets its own
 // register allocation (the fused search kernel calls them ~15 times per simulation round and
@@ -35,14 +39,6 @@ __shared__ unsigned long long mz_tl[8][16];
 #define MZ_TL(slot) if ((threadIdx.x & 63) == 0) mz_tl[threadIdx.x >> 6][slot] = clock64();
 #else
 #define MZ_TL(slot)
-#endif
-#ifdef MZ_EXP_STAMPS
-__device__ unsigned long long mz_dbg[64];
-#define MZ_DBG_T(var) unsigned long long var = 0; if (blockIdx.x == 0 && threadIdx.x == 0) var = clock64();
-#define MZ_DBG_ADD(slot, t0) if (blockIdx.x == 0 && threadIdx.x == 0) { mz_dbg[slot] += clock64() - (t0); mz_dbg[slot + 1] += 1; }
-#else
-#define MZ_DBG_T(var)
-#define MZ_DBG_ADD(slot, t0)
 #endif
 
 namespace mzd {
@@ -297,16 +293,6 @@ struct PickedRows {
     static __device__ __forceinline__ f32x4 form(const f32x4 &sh, const f32x4 &r) { return relu_sum(sh, r); }
 };
 
-// Several dense layers over the SAME input rows in one pass (e.g. the policy head's first
-// layer and the dynamics merge layer both read the latent): their column tiles form one list
-// that is split evenly over the waves, so narrow layers do not leave waves idle and the
-// workgroup pays one barrier for all of them.  All parts must share Kp.
-//
-// A wave walks its tiles NTW at a time.  The weights of those tiles are consumed as a stream
-// of batches of kPrefetch k-steps; two register sets alternate so that batch i+1 is in flight
-// (global_load_dwordx4, 1 KiB per tile and k-step) while the MFMAs of batch i issue, and the
-// stream runs on from one tile group into the next without draining.  Every loop bound below
-// is wave-uniform (the wave index goes through readfirstlane), so control flow is scalar.
 // parts[part] without indexing the array by a run-time value (which would force the array
 // into per-lane stack memory): scalar selects over the compile-time positions instead.
 template <int NPARTS>
@@ -318,12 +304,19 @@ __device__ __forceinline__ DensePart pick_part(const DensePart (&parts)[NPARTS],
     return r;
 }
 
+// Several dense layers over the SAME input rows in one pass (e.g. the policy head's first
+// layer and the dynamics merge layer both read the latent): their column tiles form one list
+// that is split evenly over the waves, so narrow layers do not leave waves idle and the
+// workgroup pays one barrier for all of them.  All parts must share Kp.
+//
+// A wave walks its tiles NTW at a time.  The weights of those tiles are consumed as a stream
+// of batches of kPrefetch k-steps; two register sets alternate so that batch i+1 is in flight
+// (global_load_dwordx4, 1 KiB per tile and k-step) while the MFMAs of batch i issue, and the
+// stream runs on from one tile group into the next without draining.  Every loop bound below
+// is wave-uniform (the wave index goes through readfirstlane), so control flow is scalar.
 template <int MT, int NTW, int NPARTS, typename Rows>
 __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__restrict__ packed,
                                              const DensePart (&parts)[NPARTS], int KT, int first_tile, int ngroups) {
-#ifdef MZ_EXP_EMPTY
-    return;
-#endif
     // tall row tiles keep many accumulators and operands: their weight batches are shorter (a
     // batch still covers >= 100 MFMAs), which keeps the routine out of the callee-saved registers
     constexpr int KP = MT >= 4 ? 2 : kPrefetch;
@@ -361,11 +354,7 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int j = 0; j < KP; ++j) {
-#ifdef MZ_EXP_NOLOAD
-                w[t][j] = f32x4{1.f, 2.f, 3.f, (float)(kt0 + j + lane)};
-#else
                 w[t][j] = fbase[t][(size_t)min(kt0 + j, KT - 1) * 64 + lane];
-#endif
             }
         if (++fb == nb) {
             fb = 0;
@@ -427,17 +416,11 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
             if (cg == ngroups) { MZ_TL(6) }
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-#ifdef MZ_EXP_NOEPI
-                if (acc[t][0].x == 123.456f) store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
-#else
                 store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
-#endif
             }
         }
     };
     f32x4 wa[NTW][KP], wb[NTW][KP];
-    constexpr int DB = (MT == 1 ? 0 : 16) + (NTW == 2 ? 0 : 8);
-    MZ_DBG_T(t_all)
     MZ_TL(1)
     fetch(wa);  // the weights have the longest way: requested before the operand pipeline is primed
     MZ_TL(2)
@@ -447,21 +430,14 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         for (int mt = 0; mt < MT; ++mt) xc[mt] = Rows::form(sh, rows.raw(mt, m, 4 * kq));
     }
     for (int i = 0; i < total; i += 2) {
-        MZ_DBG_T(t_f)
         if (i + 1 < total) fetch(wb);
-        MZ_DBG_ADD(DB + 0, t_f)
-        MZ_DBG_T(t_c)
         compute(wa);
         if (i == 0) { MZ_TL(3) }
-        MZ_DBG_ADD(DB + 2, t_c)
         if (i + 2 < total) fetch(wa);
-        MZ_DBG_T(t_c2)
         if (i + 1 < total) compute(wb);
         if (i == 0) { MZ_TL(4) }
-        MZ_DBG_ADD(DB + 4, t_c2)
     }
     MZ_TL(5)
-    MZ_DBG_ADD(DB + 6, t_all)
 }
 
 // Entry points (not inlined: own register allocation).  Kp is shared by all parts.  No

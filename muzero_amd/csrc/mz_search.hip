@@ -1,22 +1,24 @@
 // Fused search kernel for gfx950: one launch runs a whole MCTS.run (src/search/mcts.py:44-74)
 // for G trees.  A 512-thread workgroup owns 16 trees for all S simulations -- trees never
-// interact, so there is no inter-workgroup communication and no grid-wide barrier; the only
-// synchronisation is __syncthreads() between the stages of one simulation round.
+// interact, so there is no inter-workgroup communication and no grid-wide barrier.
 //
 // Per round and workgroup (16 trees = one MFMA row tile):
-//   select      16 lane groups walk their trees (DPP/ballot argmax, tables in LDS)
-//   expand      leaf latents -> LDS; {policy layer 1 | merge layer W[:, :D]} in one MFMA pass,
-//               remaining policy layers, softmax twice -> priors; child latents
-//               relu(z + table[a]) streamed to the node pool; reward MLP over all 16*A children
-//               with the child rows formed on the fly from z and the per-action table
-//   commit      child records written to the pool (root: priors perturbed by eta)
-//   simulate    depth x {policy -> first-max action -> merge -> reward}, then value
-//   backup      one lane per tree: discounted return, path update
+//   select        16 lane groups walk their trees (DPP/ballot argmax, tables in LDS); the leaf
+//                 latents are gathered into LDS and the child each simulation starts from is drawn
+//   first layers  {policy layer 1 | merge layer W[:, :D]} of the leaf in one MFMA pass
+//   then two teams of four waves run concurrently (see k_search):
+//     expansion   remaining policy layers, softmax twice -> priors; child latents
+//                 relu(z + table[a]) streamed to the node pool; reward head over all 16*A
+//                 children with the child rows formed on the fly from z and the per-action table
+//                 and its scalar output layer folded into the hidden layer's epilogue; child records
+//     simulation  depth x {policy -> first-max action -> merge -> reward}, then value, the
+//                 rollout latents read on the fly as relu(z + table[action])
+//   backup        the recorded path is updated by independent lanes
 // Weights are read from L2 in the packed MFMA layout (mz_mlp_device.h); activations, priors,
 // rewards and rollouts stay in LDS; the node pool in HBM receives exactly the records the
-// stand-alone kernels would write, so both paths are interchangeable and comparable.
+// stand-alone kernels would write, so both paths are interchangeable and comparable bit for bit.
 //
-// Compiled with -ffp-contract=off (tree arithmetic is bit-exact by contract).
+// Compiled with -ffp-contract=off (every rounding is part of the contract).
 #include <algorithm>
 
 #include "mz_common.h"
