@@ -153,6 +153,17 @@ def cpu_baseline(g, f, budget_s=12.0):
             "env_steps_per_s": moves / dt}
 
 
+def pmc_traffic(G, S):
+    """HBM bytes per launch of the search kernel from the committed counter passes (FETCH_SIZE and
+    WRITE_SIZE need separate profiler runs, so they cannot be collected inside this process);
+    None when the workload differs from the profiled one."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_d_pmc_traffic.json")
+    if not os.path.exists(path) or (G, S) != (4096, 50):
+        return None
+    with open(path) as fh:
+        return json.load(fh)["hbm_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,13 +173,15 @@ def main():
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--selfplay-moves", type=int, default=8, help="timed self-play moves per game (0 = skip)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from muzero_amd import sharding
+    shard = sharding.shard_from_env(args.games)
+    rank, world, local = shard.rank, shard.world, shard.local_rank
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
@@ -180,47 +193,52 @@ def main():
     mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev)
     latent, to_play = synthetic_roots(h, G, seed=100 + rank, device=dev)
     eta = torch.from_numpy(np.random.default_rng(7 + rank).dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).to(dev)
-    rand = torch.from_numpy(child_choice_streams(G, S, base_seed=rank * G)).to(dev)
+    rand = torch.from_numpy(child_choice_streams(G, S, base_seed=shard.first_game)).to(dev)
 
     def step():
         return mcts.run(latent, to_play, eta, rand)
 
     def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.fence(dist)
 
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.timed_steps(step, args.steps, dist, device=dev)  # barrier + sync both sides, max over ranks
+    res = mcts.finish()
     assert int(res.visits.sum().item()) == G * S, "search did not complete every simulation"
 
-    sims_total = world * G * S * args.steps
     line = {
-        "metric": "mcts_simulations_per_sec", "value": sims_total / dt, "unit": "sims/s", "n_gpus": world,
+        "metric": "mcts_simulations_per_sec", "value": sharding.whole_job_rate(G * S, args.steps, world, dt),
+        "unit": "sims/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
         "config": {"workload": f"c4_mlp: {G} Connect-Four games per GPU x {S} sims/move, A=7, D=168, "
                                "model_look_ahead=1, noise_frac=0.25 (fixed eta), MT19937 child-choice streams",
                    "games_per_gpu": G, "sims_per_move": S, "parallelism": f"games sharded x{world}, no collective"},
-        "env_steps_per_sec": world * G * args.steps / dt,
+        "searches_per_sec": world * G * args.steps / dt,
     }
+    if args.selfplay_moves > 0:
+        # whole self-play moves: observe -> history -> h -> MCTS.run -> action pick -> env step ->
+        # restart of finished games, for G games per GPU; includes the host-side generation and
+        # upload of the per-move Dirichlet and child-choice streams
+        from muzero_amd.selfplay import SelfPlayEngine
+        sp = SelfPlayEngine(h, g, f, G, cfg.training_data_generator, device=dev, seed=rank)
+        for _ in range(2):
+            sp.move()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.selfplay_moves):
+            sp.move()
+        fence()
+        dts = sharding.max_over_ranks(time.perf_counter() - t0, dist, dev)
+        line["selfplay_env_steps_per_sec"] = world * G * args.selfplay_moves / dts
+        line["selfplay_ms_per_move"] = dts / args.selfplay_moves * 1e3
     if rank == 0 and not args.no_roofline:
         ks = kernel_rooflines(mcts, nets.plan, step)
         dom = "k_search[fused MCTS.run]"
         tf = ks[dom]["flop"] / ks[dom]["s"] / 1e12
         line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                            "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(G, S),
                             "avg_launch_us": ks[dom]["s"] * 1e6, "flop_per_launch": ks[dom]["flop"]}
         line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
