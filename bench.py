@@ -197,7 +197,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -268,7 +268,7 @@ def main():
         line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(g, f)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

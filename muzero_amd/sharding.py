@@ -46,7 +46,7 @@ def fence(dist=None, cuda: bool = True):
     """Device sync + barrier + device sync: brackets a timed region on every rank."""
     if cuda:
         torch.cuda.synchronize()
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.barrier()
         if cuda:
             torch.cuda.synchronize()
@@ -65,7 +65,7 @@ def timed_steps(step, steps: int, dist=None, cuda: bool = True, device=None) -> 
 
 
 def max_over_ranks(value: float, dist=None, device=None) -> float:
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
