@@ -143,3 +143,85 @@ def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
         assert torch.equal(getattr(a.pool, name), getattr(b.pool, name)), name
     assert torch.equal(ra.policy, rb.policy) and torch.equal(ra.value, rb.value) and torch.equal(ra.visits, rb.visits)
     assert torch.equal(ra.policy32, rb.policy32)
+
+
+def _replay_through_oracle(mcts, nets, res, trace, lat, eta, rand, to_play, depth, noise, discount):
+    """Feeds the network outputs the GPU search itself used back through the CPU oracle and
+    demands identical trees (every node of every tree)."""
+    pool, G, A, S = mcts.pool, mcts.G, mcts.A, mcts.S
+    prior_s = np.stack([p.cpu().numpy() for p in trace["prior"]], axis=1)
+    rollout = np.stack([r.cpu().numpy() for r in trace["rollout"]], axis=1)
+    reward_nodes = pool.reward.cpu().numpy()
+    root_prior = torch.empty(G, A, device="cuda")
+    nets.prediction(torch.from_numpy(lat).cuda(), G, softmax_times=1, policy=root_prior)
+    prior_stream = np.concatenate([root_prior.cpu().numpy()[:, None], prior_s], axis=1)
+    reward_stream = np.zeros((G, S + 1, A), np.float32)
+    for e in range(S + 1):
+        base = 1 + e * A
+        reward_stream[:, e] = reward_nodes[:, base:base + A]
+    ref = otree.run_batch(A, S, depth, to_play, prior_stream, reward_stream, rand, rollout, eta, noise, discount)
+    leaf = np.stack([l.cpu().numpy() for l in trace["leaf"]], axis=1)
+    child = np.stack([c.cpu().numpy() for c in trace["child"]], axis=1)
+    assert np.array_equal(leaf, ref["leaf"]) and np.array_equal(child, ref["child"])
+    for name in ("visit", "value_sum", "prior", "first_child", "parent", "to_play"):
+        assert np.array_equal(getattr(pool, name).cpu().numpy(), ref[name]), name
+    np.testing.assert_allclose(res.policy.cpu().numpy(), ref["policy"], rtol=1e-12)
+    assert np.array_equal(res.value.cpu().numpy(), ref["utility"])
+    return ref
+
+
+def test_full_size_search_replays_and_is_deterministic():
+    """The benchmark configuration itself (4096 games x 50 simulations, c4_mlp): every one of the
+    4096 trees replays bit for bit through the oracle, the structural invariants of a finished
+    search hold, and a second launch reproduces the first bit for bit."""
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    _, g, f = _c4_nets(0)
+    G, S, depth, A, D = 4096, 50, 1, 7, 168
+    nets = PackedNetworks(g, f)
+    lat, eta, rand, to_play = _inputs(G, A, S, D, seed=99)
+    dev = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
+    a = BatchedMCTS(nets, G, S, depth, discount=0.998, noise_frac=0.25)
+    trace = {}
+    res = a.run(*dev, trace=trace)
+    torch.cuda.synchronize()
+    _replay_through_oracle(a, nets, res, trace, lat, eta, rand, to_play, depth, 0.25, 0.998)
+    visit = a.pool.visit.cpu().numpy()
+    assert (visit[:, 0] == S).all() and (visit[:, 1:1 + A].sum(1) == S).all()
+    assert (res.visits.cpu().numpy() == visit[:, 1:1 + A]).all()
+    assert (a.pool.n_nodes.cpu().numpy() == 1 + (S + 1) * A).all()
+    np.testing.assert_allclose(res.policy.sum(1).cpu().numpy(), 1.0, rtol=1e-12)
+    parent = a.pool.parent.cpu().numpy()
+    fc = a.pool.first_child.cpu().numpy()
+    # every non-root node's parent points at it through first_child .. first_child + A
+    idx = np.arange(1, parent.shape[1])
+    pfc = np.take_along_axis(fc, parent[:, 1:], axis=1)
+    assert ((idx[None] >= pfc) & (idx[None] < pfc + A)).all()
+    b = BatchedMCTS(nets, G, S, depth, discount=0.998, noise_frac=0.25)
+    rb = b.run(*dev)
+    torch.cuda.synchronize()
+    for name in ("visit", "value_sum", "prior", "reward", "latent"):
+        assert torch.equal(getattr(a.pool, name), getattr(b.pool, name)), name
+    assert torch.equal(res.policy32, rb.policy32) and torch.equal(res.value, rb.value)
+
+
+@pytest.mark.parametrize("G,S,depth", [(1, 1, 1), (17, 2, 0), (31, 3, 2), (4100, 4, 1)])
+def test_ragged_and_minimal_batches(G, S, depth):
+    """Batches that do not fill a 16-tree workgroup, a single tree, a single simulation: fused
+    and per-stage kernels agree bit for bit and both replay through the oracle."""
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    _, g, f = _c4_nets(1)
+    A, D = 7, 168
+    nets = PackedNetworks(g, f)
+    lat, eta, rand, to_play = _inputs(G, A, S, D, seed=3 * G + S)
+    dev = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
+    pools = []
+    for fused in (True, False):
+        m = BatchedMCTS(nets, G, S, depth, discount=0.99, noise_frac=0.25)
+        trace = {}
+        res = m.run(*dev, trace=trace, fused=fused)
+        torch.cuda.synchronize()
+        _replay_through_oracle(m, nets, res, trace, lat, eta, rand, to_play, depth, 0.25, 0.99)
+        pools.append((m, res))
+    for name in ("visit", "value_sum", "prior", "reward", "latent"):
+        assert torch.equal(getattr(pools[0][0].pool, name), getattr(pools[1][0].pool, name)), name
+    assert torch.equal(pools[0][1].policy32, pools[1][1].policy32)
