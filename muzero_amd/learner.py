@@ -1,0 +1,145 @@
+"""Batched and data-parallel learner step.
+
+The reference trains one window at a time at batch size 1 (src/training.py:131-172, bptt
+:244-305) and sums the per-window losses before one optimizer step.  For tower-less (MLP)
+configurations the same loss and the same gradient come from ONE batched unroll over all
+windows -- no layer mixes rows (no BatchNorm) -- which is what `batched_unroll_loss` computes;
+`DataParallelLearner` then splits the windows over ranks (one process per GPU), all-reduces
+the flat gradient once per optimizer step (RCCL over xGMI with the `nccl` backend, gloo on
+the CPU) and keeps the actors' packed weights in step with `broadcast_weights`.
+
+Loss definitions are the reference's (src/training.py:307-320): MSE for value and reward,
+cross entropy with the already-softmaxed policy used as logits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from muzero_amd.ring_buffer import Frame, FrameRingBuffer, make_history_tensor
+
+
+@dataclass
+class WindowBatch:
+    """B training windows in tensor form (what R3's slicing produces, src/training.py:131-160)."""
+    history: torch.Tensor     # f32[B, C*K+K, H, W]  input of h (past frames + action planes)
+    actions: torch.Tensor     # i64[B, w+1]
+    policies: torch.Tensor    # f32[B, w+1, A]
+    z: torch.Tensor           # f32[B, w+1]   value targets
+    rewards: torch.Tensor     # f32[B, w+1]
+    is_weights: torch.Tensor  # f32[B]
+
+    def to(self, device):
+        return WindowBatch(*(t.to(device) for t in (self.history, self.actions, self.policies, self.z, self.rewards,
+                                                    self.is_weights)))
+
+    def rows(self, idx):
+        return WindowBatch(self.history[idx], self.actions[idx], self.policies[idx], self.z[idx], self.rewards[idx],
+                           self.is_weights[idx])
+
+    def __len__(self):
+        return int(self.history.shape[0])
+
+
+def windows_to_batch(windows, z_targets: np.ndarray, rewards: np.ndarray, is_weights, history_length: int,
+                     lookback: int, roll_ahead: int) -> WindowBatch:
+    """`windows`: list of (episode, k).  History assembly follows bptt (src/training.py:252-262):
+    the ring buffer is filled with the first past frame and the following ones are added."""
+    hist, acts, pols = [], [], []
+    w = roll_ahead
+    for ep, k in windows:
+        start = max(0, k - lookback)
+        ring = FrameRingBuffer(size=history_length)
+        ring.fill(Frame(state=ep.chunks[start].state, action=ep.chunks[start].best_action))
+        for i in range(start + 1, k):
+            ring.add(Frame(state=ep.chunks[i].state, action=ep.chunks[i].best_action))
+        hist.append(make_history_tensor(ring))
+        acts.append([int(ep.chunks[i].best_action) for i in range(k, k + w + 1)])
+        pols.append(torch.stack([torch.as_tensor(ep.chunks[i].policy, dtype=torch.float32) for i in range(k, k + w + 1)]))
+    return WindowBatch(torch.cat(hist, 0), torch.tensor(acts, dtype=torch.long), torch.stack(pols),
+                       torch.as_tensor(np.asarray(z_targets), dtype=torch.float32),
+                       torch.as_tensor(np.asarray(rewards), dtype=torch.float32),
+                       torch.as_tensor(np.asarray(is_weights, dtype=np.float64), dtype=torch.float32))
+
+
+def batched_unroll_loss(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, coeff=(1.0, 1.0, 1.0)):
+    """Returns (weighted_sum, per_window_loss[B], (policy_sum, value_sum, reward_sum)).
+
+    weighted_sum = sum_b is_weights[b] * loss_b, NOT yet divided by sum(is_weights): the caller
+    normalises (a data-parallel caller after summing over ranks)."""
+    cp, cv, cr = coeff
+    latent = repr_net(batch.history)
+    B = len(batch)
+    lp = torch.zeros(B, dtype=torch.float32, device=latent.device)
+    lv = torch.zeros_like(lp)
+    lr = torch.zeros_like(lp)
+    for i in range(roll_ahead):
+        pred_p, pred_v = pred_net(latent)
+        latent, pred_r = dyn_net(latent, batch.actions[:, i])
+        lp = lp + F.cross_entropy(pred_p, batch.policies[:, i], reduction="none") * cp
+        lv = lv + (pred_v[:, 0] - batch.z[:, i]) ** 2 * cv
+        lr = lr + (pred_r[:, 0] - batch.rewards[:, i]) ** 2 * cr
+    final_p, final_v = pred_net(latent)
+    lv = lv + (final_v[:, 0] - batch.z[:, roll_ahead]) ** 2 * cv
+    lp = lp + F.cross_entropy(final_p, batch.policies[:, roll_ahead], reduction="none") * cp
+    per_window = lp + lv + lr
+    return (batch.is_weights * per_window).sum(), per_window, (lp.sum(), lv.sum(), lr.sum())
+
+
+class DataParallelLearner:
+    """One optimizer step over a batch of windows split across ranks.
+
+    Every rank holds identical weights and an identical optimizer; rank r takes the windows
+    r, r + world, ...; gradients of the weighted loss SUM and the weight total are all-reduced
+    in one flat buffer (a single collective of n_params + 1 floats, ~1 MB for c4_mlp: one
+    message per step suits point-to-point xGMI links better than per-tensor calls)."""
+
+    def __init__(self, repr_net, dyn_net, pred_net, optimizer, roll_ahead: int, coeff=(1.0, 1.0, 1.0), dist=None):
+        self.nets = (repr_net, dyn_net, pred_net)
+        self.params = [p for n in self.nets for p in n.parameters()]
+        self.optimizer, self.roll_ahead, self.coeff, self.dist = optimizer, roll_ahead, coeff, dist
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+
+    def step(self, batch: WindowBatch):
+        """`batch`: the FULL batch (every rank passes the same one; each uses its share).
+        Returns (normalised loss, per-window |loss| of this rank's windows, their positions)."""
+        mine = torch.arange(self.rank, len(batch), self.world)
+        self.optimizer.zero_grad(set_to_none=False)
+        dev = self.params[0].device
+        flat_extra = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of weights, weighted loss sum]
+        per_window = torch.zeros(0)
+        if len(mine) > 0:
+            local = batch.rows(mine).to(dev)
+            wsum, per_window, _ = batched_unroll_loss(*self.nets, local, self.roll_ahead, self.coeff)
+            wsum.backward()
+            flat_extra[0] = local.is_weights.sum()
+            flat_extra[1] = wsum.detach()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        flat = torch.cat([g.reshape(-1) for g in grads] + [flat_extra])
+        if self.world > 1:
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+        norm = flat[-2]
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = (flat[off:off + n] / norm).view_as(p).clone()
+            off += n
+        self.optimizer.step()
+        return float(flat[-1] / norm), per_window.detach().abs().cpu(), mine
+
+    def broadcast_weights(self, src: int = 0):
+        """Learner -> actors: one flat broadcast; actors re-pack their MFMA weight blob afterwards
+        (PackedNetworks.refresh)."""
+        if self.world == 1:
+            return
+        flat = torch.cat([p.data.reshape(-1) for p in self.params])
+        self.dist.broadcast(flat, src=src)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.data.copy_(flat[off:off + n].view_as(p))
+            off += n
