@@ -234,10 +234,10 @@ def main():
     }
     if args.selfplay_moves > 0:
         # whole self-play moves: observe -> history -> h -> MCTS.run -> action pick -> env step ->
-        # restart of finished games, for G games per GPU; includes the host-side generation and
-        # upload of the per-move Dirichlet and child-choice streams
+        # restart of finished games, for G games per GPU; the per-move Dirichlet, child-choice and
+        # exploration streams are drawn on the device
         from muzero_amd.selfplay import SelfPlayEngine
-        sp = SelfPlayEngine(h, g, f, G, cfg.training_data_generator, device=dev, seed=rank)
+        sp = SelfPlayEngine(h, g, f, G, cfg.training_data_generator, device=dev, seed=rank, device_rng=True)
         for _ in range(2):
             sp.move()
         fence()

@@ -83,8 +83,14 @@ def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_act
 
 
 class SelfPlayEngine:
-    def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0):
-        """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps)."""
+    def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0,
+                 device_rng: bool = False):
+        """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps).
+
+        The search consumes no random numbers itself: the Dirichlet noise, the child draws and the
+        exploration decisions of a move are inputs.  By default they come from a numpy generator on
+        the host (reproducible against a CPU replay); `device_rng=True` draws them on the GPU with
+        torch's generator instead, which keeps the whole move on the device."""
         self.G, self.cfg = G, config
         self.device = torch.device(device)
         m = config.mcts
@@ -98,6 +104,14 @@ class SelfPlayEngine:
                                 device=device)
         self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
         self.rng = np.random.default_rng(seed)
+        self.device_rng = device_rng
+        if device_rng:
+            self.gen = torch.Generator(device=self.device)
+            self.gen.manual_seed(seed)
+            self._alpha = torch.full((G, self.A), float(m.dirichlet_alpha), device=self.device)
+            p = config.random_action_probability
+            p = np.full(self.A, 1.0 / self.A) if p is None else np.asarray(p)
+            self._p_random = torch.as_tensor(p.astype(np.float32)).to(self.device)
         self.alpha = m.dirichlet_alpha
         dev = self.device
         self.step_in_episode = torch.zeros(G, dtype=torch.int32, device=dev)
@@ -115,13 +129,21 @@ class SelfPlayEngine:
         obs, to_play = self.env.observe()
         hist = self.history.push(obs, self.step_in_episode, None)  # self-play stores action id 0 with every frame
         latent = self.h(hist).reshape(G, -1)
-        rand = torch.from_numpy(self.rng.integers(0, A, size=(G, S + 1), dtype=np.int32)).to(dev)
-        eta = torch.from_numpy(self.rng.dirichlet(np.full(A, self.alpha), size=G).astype(np.float32)).to(dev)
-        res = self.mcts.run(latent, to_play, eta, rand)
         eps = self.epsilon(training_steps)
-        explore = torch.from_numpy((self.rng.random(G) < eps).astype(np.int8)).to(dev)
-        p = self.cfg.random_action_probability
-        rnd = torch.from_numpy(self.rng.choice(A, size=G, p=p).astype(np.int32)).to(dev)
+        if self.device_rng:
+            rand = torch.randint(0, A, (G, S + 1), device=dev, dtype=torch.int32, generator=self.gen)
+            # Dirichlet(alpha) = normalised Gamma(alpha, 1) draws
+            gam = torch._standard_gamma(self._alpha, generator=self.gen).clamp_min_(1e-30)
+            eta = (gam / gam.sum(dim=1, keepdim=True)).contiguous()
+            explore = (torch.rand(G, device=dev, generator=self.gen) < eps).to(torch.int8)
+            rnd = torch.multinomial(self._p_random, G, replacement=True, generator=self.gen).to(torch.int32)
+        else:
+            rand = torch.from_numpy(self.rng.integers(0, A, size=(G, S + 1), dtype=np.int32)).to(dev)
+            eta = torch.from_numpy(self.rng.dirichlet(np.full(A, self.alpha), size=G).astype(np.float32)).to(dev)
+            explore = torch.from_numpy((self.rng.random(G) < eps).astype(np.int8)).to(dev)
+            p = self.cfg.random_action_probability
+            rnd = torch.from_numpy(self.rng.choice(A, size=G, p=p).astype(np.int32)).to(dev)
+        res = self.mcts.run(latent, to_play, eta, rand)
         pick_action(res.policy32, explore, rnd, self.action)
         reward, done = self.env.step(self.action)
         self.step_in_episode += 1

@@ -183,8 +183,9 @@ def test_learner_matches_reference_losses():
     np.testing.assert_allclose(h.final_conv.weight.detach().numpy(), z["learner_repr_weight"], rtol=1e-4, atol=1e-7)
 
 
-def test_batched_selfplay_engine_produces_valid_episodes():
-    """4096-way lock-step self-play on the GPU env: every recorded episode is a legal game
+@pytest.mark.parametrize("device_rng", [False, True], ids=["host_streams", "device_streams"])
+def test_batched_selfplay_engine_produces_valid_episodes(device_rng):
+    """Lock-step self-play on the GPU env (random streams drawn on the host or on the device): every recorded episode is a legal game
     under the CPU rules, ends exactly where the rules say, and carries normalised policies."""
     from muzero_amd.config import MCTSConfig, TrainingDataGeneratorConfig
     from muzero_amd.selfplay import SelfPlayEngine
@@ -196,7 +197,7 @@ def test_batched_selfplay_engine_produces_valid_episodes():
         mcts=MCTSConfig(selection_strategy="puct", max_iterations=8, max_time=0, model_look_ahead=1,
                         discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
     G = 256
-    eng = SelfPlayEngine(h, g, f, G, cfg, seed=1)
+    eng = SelfPlayEngine(h, g, f, G, cfg, seed=1, device_rng=device_rng)
     episodes = eng.generate(num_moves=30)
     assert len(episodes) >= G // 2
     for ep in episodes[:200]:
