@@ -50,3 +50,51 @@ def test_host_only_entry_points():
     m.layer[1].in_features = 255  # chain mismatch must be rejected with a message
     assert _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan)) < 0
     assert b"in_features" in _hip.lib().mz_last_error()
+
+
+def _search_args(A=7, D=8, G=4, S=5, cap=None, depth=1, tab_len=None):
+    """Argument structs for mz_search_run with non-NULL dummy pointers: the checks under test run
+    on the host before anything is launched, so the pointers are never dereferenced."""
+    import ctypes as C
+    dummy = 0x1000
+    pool = _hip.Pool()
+    pool.G, pool.A, pool.cap, pool.D = G, A, (1 + (S + 1) * A) if cap is None else cap, D
+    for n in ("visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes", "latent"):
+        setattr(pool, n, dummy)
+    plan = _hip.PackedNets()
+    plan.D, plan.A = D, A
+    prm = _hip.SearchParams()
+    prm.S, prm.depth, prm.tab_len = S, depth, (S + 2) if tab_len is None else tab_len
+    for n in ("sqrt_tab", "log_tab", "root_latent", "root_to_play", "eta", "rand_child"):
+        setattr(prm, n, dummy)
+    return pool, plan, prm, C.c_void_p(dummy)
+
+
+def _run_search(pool, plan, prm, blob):
+    import ctypes as C
+    lib = _hip.lib()
+    rc = lib.mz_search_run(C.byref(pool), C.byref(plan), blob, C.byref(prm), None, None, None, None, None)
+    return rc, lib.mz_last_error().decode()
+
+
+def test_search_entry_point_rejects_bad_arguments_before_launching():
+    """mz_search_run validates on the host and reports through mz_last_error(); nothing here
+    reaches a GPU."""
+    lib = _hip.lib()
+    assert lib.mz_search_run(None, None, None, None, None, None, None, None, None) != 0
+    rc, msg = _run_search(*_search_args(A=40))
+    assert rc != 0 and "32 actions" in msg
+    rc, msg = _run_search(*_search_args(depth=8))
+    assert rc != 0 and "model_look_ahead" in msg
+    rc, msg = _run_search(*_search_args(cap=10))
+    assert rc != 0 and "capacity" in msg
+    rc, msg = _run_search(*_search_args(tab_len=3))
+    assert rc != 0 and "tab_len" in msg
+    pool, plan, prm, blob = _search_args()
+    plan.A = 5  # networks built for another action count than the pool
+    rc, msg = _run_search(pool, plan, prm, blob)
+    assert rc != 0 and "disagree" in msg
+    pool, plan, prm, blob = _search_args()
+    prm.eta = None
+    rc, msg = _run_search(pool, plan, prm, blob)
+    assert rc != 0 and "NULL" in msg
