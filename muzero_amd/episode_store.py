@@ -1,0 +1,129 @@
+"""Fixed-shape episode store on the device: the actor -> learner hand-off without Python objects.
+
+The reference keeps self-play output as lists of `Chunk` dataclasses and pickles them
+(src/training_data_generator.py:28-51,188-235); the learner then slices windows out of those
+lists one sample at a time (src/training.py:131-160).  With thousands of concurrent games that
+costs more than the search, so the batched engine records every move of every game straight
+into tensors `[slot, step, ...]` and windows are cut out of them with gathers:
+
+    store.record(obs, policy, value, action, reward, ended)   # once per lock-step move
+    batch = store.sample_windows(B, lookback, roll_ahead, K)  # -> muzero_amd.learner.WindowBatch
+
+`to_episodes()` converts back to the reference's Episode/Chunk lists, and
+`tests/test_episode_store.py` checks that windows cut from the tensors equal the windows the
+list-based path (muzero_amd.learner.windows_to_batch) cuts from those lists.
+"""
+from __future__ import annotations
+
+import torch
+
+from muzero_amd.learner import WindowBatch
+
+
+class DeviceEpisodeStore:
+    def __init__(self, games: int, max_steps: int, obs_shape, num_actions: int, capacity: int, device="cuda"):
+        """`capacity`: finished episodes kept (a ring: the oldest is overwritten)."""
+        self.G, self.T, self.A, self.cap = games, max_steps, num_actions, capacity
+        self.device = torch.device(device)
+        C, H, W = obs_shape
+        dev = self.device
+
+        def buf(n, *shape, dtype=torch.float32):
+            return torch.zeros((n, max_steps) + shape, dtype=dtype, device=dev)
+
+        # episodes in progress, one row per game
+        self.cur = dict(obs=buf(games, C, H, W), policy=buf(games, num_actions), value=buf(games, dtype=torch.float64),
+                        reward=buf(games), action=buf(games, dtype=torch.int64))
+        self.cur_len = torch.zeros(games, dtype=torch.int64, device=dev)
+        # finished episodes
+        self.done = dict(obs=buf(capacity, C, H, W), policy=buf(capacity, num_actions),
+                         value=buf(capacity, dtype=torch.float64), reward=buf(capacity),
+                         action=buf(capacity, dtype=torch.int64))
+        self.done_len = torch.zeros(capacity, dtype=torch.int64, device=dev)
+        self.n_finished = 0  # total episodes ever finished (slot = count % capacity)
+
+    def record(self, obs, policy, value, action, reward, ended) -> int:
+        """One lock-step move of all games (the tuple SelfPlayEngine.move returns).  Games whose
+        `ended` flag is set are moved to the finished ring.  Returns how many finished."""
+        g = torch.arange(self.G, device=self.device)
+        t = self.cur_len
+        self.cur["obs"][g, t] = obs.reshape(self.G, *self.cur["obs"].shape[2:]).to(torch.float32)
+        self.cur["policy"][g, t] = policy.to(torch.float32)
+        self.cur["value"][g, t] = value.to(torch.float64)
+        self.cur["reward"][g, t] = reward.to(torch.float32)
+        self.cur["action"][g, t] = action.to(torch.int64)
+        self.cur_len = t + 1
+        fin = torch.nonzero(ended.to(torch.bool) | (self.cur_len >= self.T)).flatten()
+        n = int(fin.numel())
+        if n:
+            slots = (self.n_finished + torch.arange(n, device=self.device)) % self.cap
+            keep, kslots = fin, slots
+            if n > self.cap:  # more finished at once than the ring holds: keep the last ones
+                keep, kslots = fin[-self.cap:], slots[-self.cap:]
+            for k in self.cur:
+                self.done[k][kslots] = self.cur[k][keep]
+            self.done_len[kslots] = self.cur_len[keep]
+            self.cur_len[fin] = 0
+            self.n_finished += n
+        return n
+
+    @property
+    def size(self) -> int:
+        return min(self.n_finished, self.cap)
+
+    def eligible(self, lookback: int, roll_ahead: int) -> torch.Tensor:
+        """Slots whose episode is long enough for a window (src/training.py:216-221)."""
+        return torch.nonzero(self.done_len[: self.size] >= lookback + roll_ahead + 1).flatten()
+
+    def cut_windows(self, slots: torch.Tensor, k: torch.Tensor, lookback: int, roll_ahead: int, history_length: int,
+                    discount: float, z_targets, is_weights=None) -> WindowBatch:
+        """Windows (slot[i], k[i]).  History: the ring buffer of bptt (src/training.py:252-262) is
+        filled with the first past frame and the later ones are added, so slot j of the K-frame
+        ring ends up holding past frame start + 1 + a, a the largest add index = j (mod K), or the
+        first past frame if there was none.  `z_targets(R, V, discount) -> Z` (f64 [B, w+1])."""
+        dev, K, w = self.device, history_length, roll_ahead
+        B = int(slots.numel())
+        start = torch.clamp(k - lookback, min=0)
+        n_add = k - start - 1
+        j = torch.arange(K, device=dev)[None, :]
+        last = j + K * torch.div(n_add[:, None] - 1 - j, K, rounding_mode="floor")
+        frame = torch.where(n_add[:, None] > j, start[:, None] + 1 + last, start[:, None])  # [B, K]
+        obs = self.done["obs"][slots[:, None], frame]                                       # [B, K, C, H, W]
+        act = self.done["action"][slots[:, None], frame].to(torch.float32)                  # [B, K]
+        C, H, W = obs.shape[2:]
+        planes = act[:, :, None, None].expand(B, K, H, W)
+        history = torch.cat([obs.reshape(B, K * C, H, W), planes], dim=1)
+        steps = k[:, None] + torch.arange(w + 1, device=dev)[None, :]
+        sl = slots[:, None]
+        R = self.done["reward"][sl, steps].to(torch.float64)
+        V = self.done["value"][sl, steps]
+        Z = z_targets(R, V, discount)
+        isw = torch.ones(B, device=dev) if is_weights is None else torch.as_tensor(is_weights, dtype=torch.float32, device=dev)
+        return WindowBatch(history, self.done["action"][sl, steps], self.done["policy"][sl, steps],
+                           torch.as_tensor(Z, device=dev).to(torch.float32), R.to(torch.float32), isw)
+
+    def sample_windows(self, batch_size: int, lookback: int, roll_ahead: int, history_length: int, discount: float,
+                       z_targets, generator=None):
+        """Uniform over eligible episodes, window start uniform in [lookback, len - roll_ahead - 1]
+        as random.randrange does (src/training.py:139-142).  Returns (WindowBatch, slots, k)."""
+        el = self.eligible(lookback, roll_ahead)
+        if el.numel() == 0:
+            raise ValueError("no stored episode is long enough for a training window")
+        pick = torch.randint(0, int(el.numel()), (batch_size,), device=self.device, generator=generator)
+        slots = el[pick]
+        span = self.done_len[slots] - roll_ahead - lookback  # number of admissible starts
+        u = torch.rand(batch_size, device=self.device, generator=generator)
+        k = lookback + torch.minimum((u * span).long(), span - 1)
+        return self.cut_windows(slots, k, lookback, roll_ahead, history_length, discount, z_targets), slots, k
+
+    def to_episodes(self):
+        """The stored episodes as the reference's Episode/Chunk lists (states on the CPU)."""
+        from muzero_amd.training_data_generator import Chunk, Episode
+        out = []
+        host = {k: v[: self.size].cpu() for k, v in self.done.items()}
+        lens = self.done_len[: self.size].cpu()
+        for s in range(self.size):
+            out.append(Episode(chunks=[
+                Chunk(state=host["obs"][s, t].unsqueeze(0), policy=host["policy"][s, t], reward=float(host["reward"][s, t]),
+                      value=float(host["value"][s, t]), best_action=int(host["action"][s, t])) for t in range(int(lens[s]))]))
+        return out

@@ -31,6 +31,21 @@ BASE_PATH = "training_runs"
 random.seed(0)  # the reference seeds Python's global RNG when this module is imported (:28)
 
 
+def z_targets_device(R: Tensor, V: Tensor, gamma: float) -> Tensor:
+    """z-targets for B unroll windows that already live on the GPU (f64 [B, w+1] in and out): one
+    `mz_z_targets` launch, no host round trip (src/training.py:223-242)."""
+    B, n = R.shape
+    w = n - 1
+    pw = np.zeros(w + 2, np.float64)
+    _hip.check(_hip.lib().mz_gamma_powers(float(gamma), w, ptr(pw)), "mz_gamma_powers")
+    d_r, d_v = R.to(torch.float64).contiguous(), V.to(torch.float64).contiguous()
+    d_p = torch.from_numpy(pw).to(R.device)
+    z = torch.empty((B, n), dtype=torch.float64, device=R.device)
+    _hip.check(_hip.lib().mz_z_targets(ptr(d_r), ptr(d_v), ptr(d_p), B, w, ptr(z),
+                                       torch.cuda.current_stream().cuda_stream), "mz_z_targets")
+    return z
+
+
 def compute_z_targets_batch(R: np.ndarray, V: np.ndarray, gamma: float) -> np.ndarray:
     """z-targets for B unroll windows on the GPU.  R, V: float64 [B, w+1]."""
     B, n = R.shape

@@ -208,3 +208,55 @@ def test_batched_selfplay_engine_produces_valid_episodes(device_rng):
             r, d = game.step(c.best_action)
             assert r == c.reward
             assert d == (i == len(ep.chunks) - 1)
+
+
+def test_actor_store_learner_loop_on_device():
+    """Self-play -> device episode store -> batched learner step -> re-packed weights, all on
+    the GPU: windows come out of the store in tensor form (z-targets by the HIP kernel), one
+    gradient steps lower the loss on the same batch, and the search sees the new weights after
+    PackedNetworks.refresh()."""
+    from muzero_amd.config import MCTSConfig, TrainingDataGeneratorConfig
+    from muzero_amd.episode_store import DeviceEpisodeStore
+    from muzero_amd.learner import DataParallelLearner, batched_unroll_loss
+    from muzero_amd.selfplay import SelfPlayEngine
+    from muzero_amd.training import compute_z_targets_batch, z_targets_device
+    from tests.test_gpu_nets import _c4_nets
+    h, g, f = _c4_nets(0)
+    h, g, f = h.cuda(), g.cuda(), f.cuda()
+    cfg = TrainingDataGeneratorConfig(
+        num_episodes=1, max_steps_per_episode=42, total_time=0, epsilon=1.0, epsilon_decay=1.0, min_epsilon=0.25,
+        mcts=MCTSConfig(selection_strategy="puct", max_iterations=6, max_time=0, model_look_ahead=1,
+                        discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
+    G = 128
+    eng = SelfPlayEngine(h, g, f, G, cfg, seed=3, device_rng=True)
+    store = DeviceEpisodeStore(G, 42, (2, 6, 7), 7, capacity=512)
+    for _ in range(45):
+        store.record(*eng.move())
+    assert store.size >= G
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    batch, slots, k = store.sample_windows(64, 4, 5, h.history_length, 0.998, z_targets_device, generator=gen)
+    # the device z-targets equal the host-array entry point of the same kernel
+    sl = slots[:, None].cpu()
+    steps = (k[:, None] + torch.arange(6, device="cuda")[None]).cpu()
+    R = store.done["reward"].cpu()[sl, steps].double().numpy()
+    V = store.done["value"].cpu()[sl, steps].numpy()
+    np.testing.assert_array_equal(batch.z.cpu().numpy(), compute_z_targets_batch(R, V, 0.998).astype(np.float32))
+    params = [p for n in (h, g, f) for p in n.parameters()]
+    dp = DataParallelLearner(h, g, f, torch.optim.SGD(params, lr=1e-3), 5)
+    before, _, _ = dp.step(batch)
+    for _ in range(2):
+        dp.step(batch)
+    with torch.no_grad():
+        after = float(batched_unroll_loss(h, g, f, batch, 5)[0] / batch.is_weights.sum())
+    assert after < before  # plain gradient steps on one batch lower its loss
+    # the actors pick the new weights up
+    lat = torch.randn(G, 168, device="cuda")
+    pol_old = torch.empty(G, 7, device="cuda")
+    eng.nets.prediction(lat, G, softmax_times=1, policy=pol_old)
+    eng.nets.refresh()
+    pol_new = torch.empty(G, 7, device="cuda")
+    eng.nets.prediction(lat, G, softmax_times=1, policy=pol_new)
+    assert not torch.equal(pol_old, pol_new)
+    with torch.no_grad():
+        want = torch.softmax(f(lat.reshape(G, 4, 6, 7))[0], dim=1)
+    torch.testing.assert_close(pol_new, want, rtol=1e-5, atol=2e-6)
