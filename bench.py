@@ -143,11 +143,11 @@ def kernel_rooflines(mcts, plan, step):
     return out
 
 
-def cpu_baseline(g, f, budget_s=12.0):
+def cpu_baseline(g, f, budget_s=12.0, seed=1):
     """The per-node CPU port (same Python/torch call structure as the reference) on one core."""
     from oracle import pyref
     torch.set_num_threads(1)
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(seed)
     ev = pyref.TorchEvaluator(g, f, torch.arange(A), 1)
     sims = moves = 0
     with torch.no_grad():
@@ -166,6 +166,31 @@ def cpu_baseline(g, f, budget_s=12.0):
     return {"value": sims / dt, "unit": "sims/s", "cores": 1, "kind": "port",
             "sample": f"{moves} single-game MCTS.run calls (50 sims, c4_mlp nets, torch CPU 1 thread) in {dt:.1f}s",
             "env_steps_per_s": moves / dt}
+
+
+def cpu_baseline_all_cores(budget_s=10.0):
+    """The same port on P independent processes (P = min(16, cores): the GPU box gives one GPU's
+    job 16 cores), each playing its own games -- how the reference would be scaled on a host.
+    Must run BEFORE this process touches the GPU: the workers are started as child programs."""
+    import subprocess
+    procs = max(1, min(16, os.cpu_count() or 1))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(100 + i), str(budget_s)],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(procs)]
+    sims = 0.0
+    ok = 0
+    for pr in ps:
+        try:
+            out, _ = pr.communicate(timeout=budget_s * 4 + 180)
+            r = json.loads(out.strip().splitlines()[-1])
+            sims += r["value"]
+            ok += 1
+        except Exception:
+            pr.kill()
+    if ok == 0:
+        return None
+    return {"value": sims, "unit": "sims/s", "cores": ok, "kind": "port",
+            "sample": f"{ok} processes x {budget_s:.0f}s of single-game MCTS.run calls, 1 torch thread each"}
 
 
 def pmc_traffic(G, S):
@@ -189,7 +214,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selfplay-moves", type=int, default=8, help="timed self-play moves per game (0 = skip)")
+    ap.add_argument("--cpu-worker", nargs=2, metavar=("SEED", "SECONDS"), help="internal: one CPU-baseline process")
     args = ap.parse_args()
+    if args.cpu_worker:  # a child of cpu_baseline_all_cores: CPU only, prints one JSON line
+        _, _, g, f = build_networks()
+        print(json.dumps(cpu_baseline(g, f, float(args.cpu_worker[1]), int(args.cpu_worker[0]))))
+        return
+    multi = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        multi = cpu_baseline_all_cores()  # child programs: started before the GPU is initialised
 
     from muzero_amd import sharding
     shard = sharding.shard_from_env(args.games)
@@ -268,6 +301,7 @@ def main():
         line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(g, f)
+        line["cpu_baseline"]["all_cores"] = multi
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
