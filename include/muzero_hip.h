@@ -145,7 +145,8 @@ typedef struct mz_packed_mlp {
 } mz_packed_mlp;
 
 /* Host-only: computes the packed layout of `h_mlp` starting at float offset `base_off`;
- * returns the number of floats it occupies (negative on error). */
+ * returns the number of floats it occupies, 4 KiB of read slack at the end included
+ * (negative on error). */
 int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out);
 /* Re-tiles the weights named by `h_mlp` (device pointers) into blob[plan offsets]. */
 int mz_mlp_pack(const mz_mlp *h_mlp, const mz_packed_mlp *h_plan, float *blob, void *stream);

@@ -206,6 +206,8 @@ int launch_by_rows(int B, size_t lds_per_row_floats, size_t extra_bytes, Launch1
 
 extern "C" {
 
+constexpr int64_t kPackedSlackFloats = 1024;
+
 int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out) {
     if (validate_mlp(h_mlp, "mz_mlp_plan") != MZ_OK) return MZ_ERR_ARG;
     if (!h_out || base_off < 0 || (base_off & 3))
@@ -229,6 +231,9 @@ int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out)
         off += L.Np;
         h_out->max_width = std::max(h_out->max_width, L.N);
     }
+    // read slack: the kernels fetch whole batches of k-steps and may run up to 3 KiB past a
+    // layer's last weight tile (values that feed no arithmetic)
+    off += kPackedSlackFloats;
     return off - base_off;
 }
 

@@ -351,11 +351,14 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     auto fetch = [&](f32x4 (&w)[NTW][KP]) {
         const int kt0 = fb * KP;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int t = 0; t < NTW; ++t) {
+            // one scalar base per tile and batch, the k-steps at constant offsets (1 KiB apart):
+            // a group's last batch may read up to KP - 1 k-steps past its tile, i.e. into the next
+            // tile or the slack every packed MLP ends with (mz_mlp_plan); those values feed no MFMA
+            glb_f4 *base = fbase[t] + (size_t)kt0 * 64;
 #pragma unroll
-            for (int j = 0; j < KP; ++j) {
-                w[t][j] = fbase[t][(size_t)min(kt0 + j, KT - 1) * 64 + lane];
-            }
+            for (int j = 0; j < KP; ++j) w[t][j] = base[j * 64 + lane];
+        }
         if (++fb == nb) {
             fb = 0;
             if (++fg < ngroups) fetch_bases();
