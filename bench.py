@@ -197,7 +197,7 @@ def pmc_traffic(G, S):
     """HBM bytes per launch of the search kernel from the committed counter passes (FETCH_SIZE and
     WRITE_SIZE need separate profiler runs, so they cannot be collected inside this process);
     None when the workload differs from the profiled one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_d_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_f_pmc_traffic.json")
     if not os.path.exists(path) or (G, S) != (4096, 50):
         return None
     with open(path) as fh:
