@@ -45,7 +45,7 @@ def test_host_only_entry_points():
     m.layer[1] = _hip.Dense(1, None, 256, 7, 4, 0)
     plan = _hip.PackedMlp()
     n = _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan))
-    assert n == 176 * 256 + 256 + 256 * 16 + 16
+    assert n == 176 * 256 + 256 + 256 * 16 + 16 + 1024  # tiles + padded bias per layer, 4 KiB read slack
     assert (plan.in_features, plan.out_features, plan.max_width) == (168, 7, 256)
     m.layer[1].in_features = 255  # chain mismatch must be rejected with a message
     assert _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan)) < 0
