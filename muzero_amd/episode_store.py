@@ -35,16 +35,18 @@ class DeviceEpisodeStore:
         self.cur = dict(obs=buf(games, C, H, W), policy=buf(games, num_actions), value=buf(games, dtype=torch.float64),
                         reward=buf(games), action=buf(games, dtype=torch.int64))
         self.cur_len = torch.zeros(games, dtype=torch.int64, device=dev)
-        # finished episodes
-        self.done = dict(obs=buf(capacity, C, H, W), policy=buf(capacity, num_actions),
-                         value=buf(capacity, dtype=torch.float64), reward=buf(capacity),
-                         action=buf(capacity, dtype=torch.int64))
-        self.done_len = torch.zeros(capacity, dtype=torch.int64, device=dev)
-        self.n_finished = 0  # total episodes ever finished (slot = count % capacity)
+        # finished episodes (+ one scratch row that absorbs the rows of games still in progress,
+        # so that a move is recorded with fixed-shape copies and no host synchronisation)
+        self.done = dict(obs=buf(capacity + 1, C, H, W), policy=buf(capacity + 1, num_actions),
+                         value=buf(capacity + 1, dtype=torch.float64), reward=buf(capacity + 1),
+                         action=buf(capacity + 1, dtype=torch.int64))
+        self.done_len = torch.zeros(capacity + 1, dtype=torch.int64, device=dev)
+        self._n_finished = torch.zeros((), dtype=torch.int64, device=dev)  # episodes ever finished
 
-    def record(self, obs, policy, value, action, reward, ended) -> int:
+    def record(self, obs, policy, value, action, reward, ended) -> None:
         """One lock-step move of all games (the tuple SelfPlayEngine.move returns).  Games whose
-        `ended` flag is set are moved to the finished ring.  Returns how many finished."""
+        `ended` flag is set (or that reach max_steps) are moved to the finished ring, slot =
+        running count modulo capacity.  Entirely on the device: nothing here waits for the GPU."""
         g = torch.arange(self.G, device=self.device)
         t = self.cur_len
         self.cur["obs"][g, t] = obs.reshape(self.G, *self.cur["obs"].shape[2:]).to(torch.float32)
@@ -52,20 +54,20 @@ class DeviceEpisodeStore:
         self.cur["value"][g, t] = value.to(torch.float64)
         self.cur["reward"][g, t] = reward.to(torch.float32)
         self.cur["action"][g, t] = action.to(torch.int64)
-        self.cur_len = t + 1
-        fin = torch.nonzero(ended.to(torch.bool) | (self.cur_len >= self.T)).flatten()
-        n = int(fin.numel())
-        if n:
-            slots = (self.n_finished + torch.arange(n, device=self.device)) % self.cap
-            keep, kslots = fin, slots
-            if n > self.cap:  # more finished at once than the ring holds: keep the last ones
-                keep, kslots = fin[-self.cap:], slots[-self.cap:]
-            for k in self.cur:
-                self.done[k][kslots] = self.cur[k][keep]
-            self.done_len[kslots] = self.cur_len[keep]
-            self.cur_len[fin] = 0
-            self.n_finished += n
-        return n
+        new_len = t + 1
+        fin = ended.to(torch.bool) | (new_len >= self.T)
+        order = torch.cumsum(fin.to(torch.int64), 0) - 1
+        slot = torch.where(fin, (self._n_finished + order) % self.cap, torch.full_like(order, self.cap))
+        for k in self.cur:
+            self.done[k].index_copy_(0, slot, self.cur[k])
+        self.done_len.index_copy_(0, slot, new_len)
+        self.done_len[self.cap] = 0
+        self.cur_len = torch.where(fin, torch.zeros_like(new_len), new_len)
+        self._n_finished = self._n_finished + fin.sum()
+
+    @property
+    def n_finished(self) -> int:
+        return int(self._n_finished.item())
 
     @property
     def size(self) -> int:

@@ -108,12 +108,20 @@ class DataParallelLearner:
         """`batch`: the FULL batch (every rank passes the same one; each uses its share).
         Returns (normalised loss, per-window |loss| of this rank's windows, their positions)."""
         mine = torch.arange(self.rank, len(batch), self.world)
+        loss, per_window = self.step_local(batch.rows(mine) if len(mine) > 0 else None)
+        return loss, per_window, mine
+
+    def step_local(self, local: WindowBatch | None):
+        """One optimizer step where every rank brings its OWN windows (e.g. cut from its own
+        episode store): the gradient of the weighted loss sum and the weight total are summed
+        over ranks, so the result is the step a single rank would take on the union of the
+        windows.  Returns (normalised loss over all ranks, per-window |loss| of the local ones)."""
         self.optimizer.zero_grad(set_to_none=False)
         dev = self.params[0].device
         flat_extra = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of weights, weighted loss sum]
         per_window = torch.zeros(0)
-        if len(mine) > 0:
-            local = batch.rows(mine).to(dev)
+        if local is not None and len(local) > 0:
+            local = local.to(dev)
             wsum, per_window, _ = batched_unroll_loss(*self.nets, local, self.roll_ahead, self.coeff)
             wsum.backward()
             flat_extra[0] = local.is_weights.sum()
@@ -129,7 +137,7 @@ class DataParallelLearner:
             p.grad = (flat[off:off + n] / norm).view_as(p).clone()
             off += n
         self.optimizer.step()
-        return float(flat[-1] / norm), per_window.detach().abs().cpu(), mine
+        return float(flat[-1] / norm), per_window.detach().abs().cpu()
 
     def broadcast_weights(self, src: int = 0):
         """Learner -> actors: one flat broadcast; actors re-pack their MFMA weight blob afterwards
