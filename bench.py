@@ -227,12 +227,18 @@ def main():
     from muzero_amd import sharding
     shard = sharding.shard_from_env(args.games)
     rank, world, local = shard.rank, shard.world, shard.local_rank
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one rank per GPU; MZ_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 path on one card
+    backend = os.environ.get("MZ_DIST_BACKEND", "nccl")
+    local_dev = local if backend == "nccl" else local % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from muzero_amd.engine import BatchedMCTS, PackedNetworks
     cfg, h, g, f = build_networks()

@@ -67,7 +67,8 @@ def timed_steps(step, steps: int, dist=None, cuda: bool = True, device=None) -> 
 def max_over_ranks(value: float, dist=None, device=None) -> float:
     if dist is None or not dist.is_initialized():
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    on_cpu = device is None or dist.get_backend() == "gloo"
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if on_cpu else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
