@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- ctypes front end of oracle/c4_oracle.c plus a duck-typed
 single-game environment with the reference adapter's interface
-(src/environments/connect_four.py:18-72).  Rule parity with PettingZoo is UNPINNED (see
-c4_oracle.c)."""
+(src/environments/connect_four.py:18-72).  The reward convention of PettingZoo is UNPINNED, legality
+and the win test are pinned by published position counts (see c4_oracle.c)."""
 from __future__ import annotations
 
 import ctypes as C

@@ -4,10 +4,12 @@
  * not vendored in the reference and not installed here) as seen through the
  * reference's adapter src/environments/connect_four.py:18-72.
  *
- * Parity status: UNPINNED for the rules (no reference test or fixture exercises them:
- * tests/search/test_mcts.py:22 and tests/environments pin only the observation shape
- * (2,6,7) and the 7 actions).  The rules below restate the published PettingZoo
- * behaviour; known-answer boards in tests/test_c4.py are hand-made.
+ * Parity status: no reference test or fixture exercises the rules
+ * (tests/search/test_mcts.py:22 and tests/environments pin only the observation shape
+ * (2,6,7) and the 7 actions).  Move legality and the win test are pinned independently
+ * by the published number of positions after n plies (John Tromp's table, OEIS A212693;
+ * tests/test_c4_oracle.py).  UNPINNED: the reward / termination convention of the
+ * PettingZoo wrappers restated below; its known-answer boards are hand-made.
  *
  * Board: 6 rows x 7 columns, flat cell index row*7+col with row 0 at the TOP.
  * Player 0 (`player_0`, to_play +1) moves first.  A move drops into the lowest empty

@@ -63,3 +63,35 @@ def test_illegal_move_full_column():
     before = g.board.copy()
     assert g.step(3) == (0.0, True)  # finished games ignore further steps
     assert np.array_equal(before, g.board)
+
+
+# Number of distinct Connect-Four positions on the 7x6 board after n plies when play stops at the
+# first four-in-a-row (John Tromp's table, OEIS A212693).  Independent of PettingZoo: it pins move
+# legality (column heights) and the win test (a position with a four-in-a-row is counted but not
+# continued) against published numbers.
+TROMP_POSITIONS = [1, 7, 49, 238, 1120, 4263, 16422, 54859]
+
+
+def test_position_counts_match_published_table():
+    import ctypes as C
+
+    from oracle.c4 import C4, _State
+    from oracle import lib
+    step = lib().mzo_c4_step
+    step.restype = C.c_float
+    root = C4()
+    frontier = {bytes(root.s.board): bytes(root.s)}
+    counts = [1]
+    for ply in range(1, len(TROMP_POSITIONS)):
+        nxt = {}
+        for raw in frontier.values():
+            for a in range(7):
+                s = _State.from_buffer_copy(raw)
+                if s.board[a] != 0:  # top cell of the column occupied: not a legal move
+                    continue
+                d = C.c_int(0)
+                step(C.byref(s), C.c_int(a), C.byref(d))
+                nxt[bytes(s.board)] = (bytes(s), bool(d.value))
+        counts.append(len(nxt))
+        frontier = {k: raw for k, (raw, done) in nxt.items() if not done}
+    assert counts == TROMP_POSITIONS

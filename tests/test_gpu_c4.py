@@ -51,3 +51,32 @@ def test_single_game_adapter_interface():
         assert (r, d) == (0.0, False)
     s, r, d = env.step(0)
     assert (r, d) == (-1.0, True) and env.get_to_play() == -1
+
+
+def test_position_counts_match_published_table():
+    """Breadth-first enumeration with the GPU kernels themselves: the number of distinct positions
+    after n plies (play stops at a four-in-a-row) equals John Tromp's published table (OEIS
+    A212693) up to ply 8 -- an anchor for move legality and the win test that does not depend on
+    the CPU restatement."""
+    from muzero_amd.environments.connect_four import BatchedConnectFour
+    want = [1, 7, 49, 238, 1120, 4263, 16422, 54859, 184275]
+    root = BatchedConnectFour(1)
+    root.reset()
+    pieces, to_move = root.pieces.clone(), root.to_move.clone()
+    counts = [1]
+    for ply in range(1, len(want)):
+        n = pieces.shape[0]
+        env = BatchedConnectFour(n * 7)
+        env.pieces.copy_(pieces.repeat_interleave(7, 0))
+        env.to_move.copy_(to_move.repeat_interleave(7, 0))
+        env.done.zero_()
+        before = env.pieces.clone()
+        act = torch.arange(7, dtype=torch.int32, device="cuda").repeat(n)
+        _, done = env.step(act)
+        legal = (env.pieces != before).any(dim=1)  # a full column leaves the board unchanged
+        state = torch.cat([env.pieces[legal], env.to_move[legal, None].long(), done[legal, None].long()], dim=1)
+        uniq = torch.unique(state, dim=0)
+        counts.append(int(uniq.shape[0]))
+        live = uniq[uniq[:, 3] == 0]
+        pieces, to_move = live[:, :2].contiguous(), live[:, 2].to(torch.int8).contiguous()
+    assert counts == want
