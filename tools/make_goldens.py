@@ -378,8 +378,70 @@ def make_selfplay_and_learner():
     print("selfplay_learner.npz ok:", [len(ep.chunks) for ep in episodes], mgr.loss_history)
 
 
+# ----------------------------------------------------------------------------------------
+# residual towers: g/f with ResBlocks (train-mode batch statistics per call) and res_final
+# ----------------------------------------------------------------------------------------
+def res(out_channels, k=3):
+    return rcfg.ResBlockConfig(out_channels=out_channels, kernel_size=k, stride=1, padding=(k - 1) // 2,
+                               activation="relu", pool_kernel_size=1, pool_stride=1)
+
+
+def make_towers():
+    out = {}
+    # (latent_shape, A, g blocks, f blocks, reward, value, policy)
+    nets = [
+        ((16, 4, 4), 5, [3], [3], [16], [16, 8], [16]),       # the shipped shape in small: c -> 3 -> c
+        ((4, 3, 3), 3, [4, 4], [4], [8], [8], [8, 8]),        # channel-preserving blocks, no res_final
+        ((6, 2, 5), 7, [8, 2], [5], [12], [12], [12]),        # widening then narrowing, two blocks in g
+    ]
+    for ni, (shape, A, gb, fb, rw, vl, pl) in enumerate(nets):
+        torch.manual_seed(100 + ni)
+        g = RefG(shape, A, rcfg.DynamicsNetworkConfig(res_net=[res(c) for c in gb], reward_net=[dense(n) for n in rw]))
+        f = RefF(shape, A, rcfg.PredictionNetworkConfig(res_net=[res(c) for c in fb],
+                                                        value_net=[dense(n) for n in vl],
+                                                        policy_net=[dense(n) for n in pl]))
+        with torch.no_grad():  # non-trivial affine parameters
+            for m in list(g.modules()) + list(f.modules()):
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+        out.update(sd_arrays(f"net{ni}_g.", g))
+        out.update(sd_arrays(f"net{ni}_f.", f))
+        out[f"net{ni}_shape"] = np.array(shape, np.int32)
+        out[f"net{ni}_A"] = np.int32(A)
+        out[f"net{ni}_g_blocks"] = np.array(gb, np.int32)
+        out[f"net{ni}_f_blocks"] = np.array(fb, np.int32)
+        B = 6
+        lat = torch.randn(B, *shape)
+        act = torch.randint(0, A, (B,))
+        with torch.no_grad():
+            # the search calls the networks one latent at a time (batch statistics of that call)
+            g1 = [g(lat[i:i + 1], act[i:i + 1]) for i in range(B)]
+            f1 = [f(lat[i:i + 1]) for i in range(B)]
+            # expansion: one latent repeated for all actions in ONE call
+            gA = [g(lat[i:i + 1].repeat(A, 1, 1, 1), torch.arange(A)) for i in range(B)]
+        out[f"net{ni}_latent"] = lat.numpy()
+        out[f"net{ni}_action"] = act.numpy().astype(np.int64)
+        out[f"net{ni}_g1_next"] = np.concatenate([x[0].numpy() for x in g1])
+        out[f"net{ni}_g1_reward"] = np.concatenate([x[1].numpy() for x in g1])
+        out[f"net{ni}_f1_policy"] = np.concatenate([x[0].numpy() for x in f1])
+        out[f"net{ni}_f1_value"] = np.concatenate([x[1].numpy() for x in f1])
+        out[f"net{ni}_gA_next"] = np.stack([x[0].numpy() for x in gA])
+        out[f"net{ni}_gA_reward"] = np.stack([x[1].numpy() for x in gA])
+        for ti, (S, depth, nf, tp) in enumerate([(30, 1, 0.25, 1), (20, 2, 0.0, 0)]):
+            torch.manual_seed(200 + 10 * ni + ti)
+            root_latent = torch.randn(1, *shape)
+            c = capture_tree(g, f, A, S, depth, tp, nf, 0.998, root_latent, 300 + 10 * ni + ti)
+            for k, v in c.items():
+                out[f"net{ni}_t{ti}_{k}"] = np.asarray(v)
+    out["n_nets"] = np.int32(len(nets))
+    out["n_trees"] = np.int32(2)
+    np.savez_compressed(os.path.join(OUT, "towers.npz"), **out)
+    print("towers.npz ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay"]
+    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay", "towers"]
     if "trees" in which:
         make_trees()
     if "c4" in which:
@@ -388,3 +450,5 @@ if __name__ == "__main__":
         make_data()
     if "selfplay" in which:
         make_selfplay_and_learner()
+    if "towers" in which:
+        make_towers()
