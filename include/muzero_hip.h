@@ -302,6 +302,77 @@ int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *
                   const mz_search_params *prm, double *policy, float *policy32, double *value,
                   int32_t *visits, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Residual-tower networks (`res_net` non-empty; latent [C][H][W] with D = C*H*W up to the
+ * shipped 256*6*6 = 9216): the pieces of DynamicsNetwork.forward / PredictionNetwork.forward
+ * (src/neural_networks/neural_network.py:152-188, :234-262) that the LDS-resident MLP kernels
+ * above do not cover.  The host side composes them (muzero_amd/towers.py).
+ * ------------------------------------------------------------------------------------ */
+
+/* One Linear layer of any width (fc_merge and the first layer of each head at D = 9216):
+ * same packed tile layout as mz_mlp_pack, no 4096 limit.  Returns the floats it occupies in
+ * the blob, read slack included (negative on error). */
+int64_t mz_wide_plan(const mz_dense *h_layer, int64_t base_off, mz_packed_layer *h_out);
+int mz_wide_pack(const mz_dense *h_layer, const mz_packed_layer *h_plan, float *blob, void *stream);
+/* Floats of workspace mz_wide_forward needs for B rows (partial sums of the split
+ * reduction dimension; 0 when the layer is not split). */
+int64_t mz_wide_workspace(const mz_packed_layer *h_plan, int32_t B);
+/* y[r][:] = act(x[x_rows[r]][:] W^T + bias) for B rows; x rows of K floats with stride ldx and
+ * optional gather x_rows (negative -> zeros); y f32[B][N] with row stride ldy.  `workspace`
+ * holds at least mz_wide_workspace() floats (may be NULL when that is 0). */
+int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                    const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
+                    int64_t workspace_floats, void *stream);
+
+/* ResBlock (src/neural_networks/network_builder.py:73-151) with stride 1, padding
+ * (kernel_size-1)/2 and no pooling -- the only form that keeps the latent's H x W, which g and f
+ * require.  Weights are device pointers in torch layout: conv [out][in][k][k] without bias,
+ * BatchNorm2d weight/bias [out]; down_w (1x1 conv [out][in]) and its BatchNorm are NULL when
+ * in_channels == out_channels. */
+typedef struct mz_resblock {
+    const float *conv1_w, *bn1_w, *bn1_b;
+    const float *conv2_w, *bn2_w, *bn2_b;
+    const float *down_w, *dbn_w, *dbn_b;
+    int32_t in_channels, out_channels, kernel_size, activation;
+    float eps1, eps2, epsd, _pad;
+} mz_resblock;
+
+#define MZ_MAX_BLOCKS 4
+
+/* res_blocks followed by res_final (1x1 conv with bias back to C channels, or the identity when
+ * final_w is NULL): neural_network.py:130-144, :209-221. */
+typedef struct mz_tower {
+    int32_t n_blocks, C, H, W;
+    mz_resblock block[MZ_MAX_BLOCKS];
+    const float *final_w; /* [C][last out_channels] or NULL */
+    const float *final_b; /* [C] or NULL                    */
+} mz_tower;
+
+/* y[y_rows[r]] = res_final(res_blocks(x_r)) for B rows of C*H*W floats.
+ * Batch statistics: the reference never leaves train mode, so every BatchNorm2d normalises
+ * with the mean and biased variance of ONE network call (src/search/expansion.py:25-28 calls g
+ * with the A children of a node as one batch; every other call has batch size 1).  Here
+ * consecutive groups of `group` rows form one such call (B must be a multiple of `group`);
+ * running statistics are not updated (nothing on the search path reads them).
+ * Input: x_r = x[x_rows[r]] (gather optional); with row_add != NULL the fc_merge split is
+ * applied while loading, x_r = relu(x[x_rows[r]] + row_add[row_sel[r]]) (row_sel NULL: r % group).
+ * y_rows NULL: row r; negative entries are skipped. */
+int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
+                     const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
+                     int64_t ldy, const int32_t *y_rows, int32_t B, int32_t group, void *stream);
+
+/* table[a][:] = fc_merge.weight[:, D:] @ action_embedding[a] + fc_merge.bias for a < A
+ * (f32[A][D]): the per-action half of fc_merge, neural_network.py:168-172. */
+int mz_action_table(const float *embedding, const float *merge_weight, const float *merge_bias,
+                    int32_t D, int32_t A, float *table, void *stream);
+
+/* Policy post-processing on f32[B][A] rows: `softmax_times` softmax passes (expand_node's
+ * softmax of the network's already-normalised policy, src/search/expansion.py:26-27) into
+ * policy_out (may alias policy_in, or NULL) and the first maximum of the INPUT row into
+ * argmax i32[B] (src/search/simulation.py:36), or NULL. */
+int mz_policy_post(const float *policy_in, int32_t B, int32_t A, int32_t softmax_times,
+                   float *policy_out, int32_t *argmax, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,22 @@ class SearchParams(C.Structure):
                 ("stamps", C.c_void_p)]
 
 
+MAX_BLOCKS = 4
+
+
+class ResBlock(C.Structure):
+    _fields_ = [("conv1_w", C.c_void_p), ("bn1_w", C.c_void_p), ("bn1_b", C.c_void_p), ("conv2_w", C.c_void_p),
+                ("bn2_w", C.c_void_p), ("bn2_b", C.c_void_p), ("down_w", C.c_void_p), ("dbn_w", C.c_void_p),
+                ("dbn_b", C.c_void_p), ("in_channels", C.c_int32), ("out_channels", C.c_int32),
+                ("kernel_size", C.c_int32), ("activation", C.c_int32), ("eps1", C.c_float), ("eps2", C.c_float),
+                ("epsd", C.c_float), ("_pad", C.c_float)]
+
+
+class Tower(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("block", ResBlock * MAX_BLOCKS), ("final_w", C.c_void_p), ("final_b", C.c_void_p)]
+
+
 _LIB = None
 
 _P = C.c_void_p
@@ -110,6 +126,15 @@ _SIGS = {
     "mz_pick_action": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "mz_gamma_powers": (C.c_int, [C.c_double, C.c_int32, _P]),
     "mz_z_targets": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "mz_wide_plan": (C.c_int64, [C.POINTER(Dense), C.c_int64, C.POINTER(PackedLayer)]),
+    "mz_wide_pack": (C.c_int, [C.POINTER(Dense), C.POINTER(PackedLayer), _P, _P]),
+    "mz_wide_workspace": (C.c_int64, [C.POINTER(PackedLayer), C.c_int32]),
+    "mz_wide_forward": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P,
+                                  C.c_int64, _P]),
+    "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
+                                   C.c_int32, C.c_int32, _P]),
+    "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "mz_policy_post": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
 }
 
 

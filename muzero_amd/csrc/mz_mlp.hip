@@ -268,6 +268,47 @@ int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *
         });
 }
 
+// ---- one layer of any width (read by the chunked kernels of mz_tower.hip)
+static int validate_wide(const mz_dense *d, const char *what) {
+    if (!d || d->in_features <= 0 || d->out_features <= 0 || !d->weight)
+        return mz::fail(MZ_ERR_ARG, "%s: NULL layer, bad dims or NULL weight", what);
+    if (d->activation < MZ_ACT_NONE || d->activation > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "%s: activation %d is not element-wise", what, d->activation);
+    if (d->ldw != 0 && d->ldw < d->in_features) return mz::fail(MZ_ERR_ARG, "%s: ldw below in_features", what);
+    return MZ_OK;
+}
+
+int64_t mz_wide_plan(const mz_dense *h_layer, int64_t base_off, mz_packed_layer *h_out) {
+    if (validate_wide(h_layer, "mz_wide_plan") != MZ_OK) return MZ_ERR_ARG;
+    if (!h_out || base_off < 0 || (base_off & 3))
+        return mz::fail(MZ_ERR_ARG, "mz_wide_plan: h_out is NULL or base_off is not a non-negative multiple of 4");
+    std::memset(h_out, 0, sizeof(*h_out));
+    h_out->K = h_layer->in_features;
+    h_out->N = h_layer->out_features;
+    h_out->Kp = ceil16(h_out->K);
+    h_out->Np = ceil16(h_out->N);
+    h_out->act = h_layer->activation;
+    h_out->w_off = base_off;
+    h_out->b_off = base_off + (int64_t)h_out->Kp * h_out->Np;
+    return (int64_t)h_out->Kp * h_out->Np + h_out->Np + kPackedSlackFloats;
+}
+
+int mz_wide_pack(const mz_dense *h_layer, const mz_packed_layer *h_plan, float *blob, void *stream) {
+    MZ_TRY(validate_wide(h_layer, "mz_wide_pack"));
+    if (!h_plan || !blob || h_plan->K != h_layer->in_features || h_plan->N != h_layer->out_features)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_pack: plan does not match the layer");
+    return pack_layer(*h_layer, *h_plan, blob, (hipStream_t)stream);
+}
+
+int mz_action_table(const float *embedding, const float *merge_weight, const float *merge_bias, int32_t D,
+                    int32_t A, float *table, void *stream) {
+    if (!embedding || !merge_weight || !table || D <= 0 || A <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_action_table: NULL argument or non-positive D, A");
+    hipLaunchKernelGGL(k_action_table, dim3((unsigned)(((long long)A * D + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, embedding, merge_weight, merge_bias, D, D, A, table);
+    return mz::check_launch("k_action_table");
+}
+
 int mz_nets_plan(const mz_dynamics_net *h_dyn, const mz_prediction_net *h_pred, mz_packed_nets *h_out) {
     if (!h_dyn || !h_pred || !h_out) return mz::fail(MZ_ERR_ARG, "mz_nets_plan: NULL argument");
     if (h_dyn->D <= 0 || h_dyn->A <= 0 || h_dyn->A > 64 || h_pred->D != h_dyn->D || h_pred->A != h_dyn->A)

@@ -1,0 +1,600 @@
+// Residual-tower pieces of g and f (gfx950):
+//   * a dense layer of any width, its reduction dimension streamed through LDS in chunks and
+//     optionally split across workgroups (fc_merge and the head inputs at D = 9216), on
+//     v_mfma_f32_16x16x4_f32 with the packed weight tiles of mz_mlp_pack;
+//   * the ResBlock tower with the batch statistics of one network call per group of rows;
+//   * policy post-processing.
+// The convolutions of the shipped g/f towers are skinny (256 -> 3 -> 3 -> 256 channels on a
+// 6 x 6 latent): a 16-wide matrix tile would idle on 13 of 16 columns, so they run on the
+// vector ALUs with wave-uniform weights; the matrix cores take fc_merge and the heads.
+#include <algorithm>
+#include <cstring>
+
+#include "mz_common.h"
+#include "mz_mlp_device.h"
+
+using namespace mzd;
+
+namespace {
+
+constexpr int kWT = 256;       // threads per workgroup of every kernel in this file
+constexpr int kKC = 64;        // floats of the reduction dimension per LDS chunk (4 k-tiles)
+constexpr int kLdX = kKC + 4;  // LDS row stride of a chunk: 16 rows x b128 reads hit 64 distinct banks
+constexpr size_t kMaxLds = 160 * 1024;
+
+// ------------------------------------------------------------------ wide dense layer
+// Workgroup = 2 x 2 waves, wave tile = (16 MTW) x (16 NTW), workgroup tile TM x TN = 32 MTW x 32 NTW.
+// Activations: global -> registers -> LDS chunk (double buffered, one barrier per chunk);
+// weights: packed tiles straight from global/L2 into registers, one k-tile ahead.
+template <int MTW, int NTW>
+__global__ void __launch_bounds__(kWT)
+k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restrict__ x, long long ldx,
+       const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B, int splitk,
+       int chunks_per_split, float *__restrict__ ws, int vec_ok) {
+    constexpr int TM = 32 * MTW, TN = 32 * NTW, XR = TM / 16;
+    extern __shared__ __align__(16) float xs[];  // [2][TM][kLdX]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m = lane & 15, kq = lane >> 4;
+    const int KT = L.Kp >> 4, NT = L.Np >> 4;
+    const int n0 = blockIdx.x * TN, m0 = blockIdx.y * TM, z = blockIdx.z;
+    const int nchunks = (KT + 3) >> 2;
+    const int c_lo = z * chunks_per_split, c_hi = min(nchunks, c_lo + chunks_per_split);
+
+    const int sc = (tid & 15) * 4, sr = tid >> 4;
+    const float *xrow[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int r = m0 + sr + 16 * i;
+        long long src = -1;
+        if (r < B) src = x_rows ? (long long)x_rows[r] : (long long)r;
+        xrow[i] = src >= 0 ? x + src * ldx : nullptr;
+    }
+    auto fetch = [&](int c, f32x4 (&v)[XR]) {
+        const int k = c * kKC + sc;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (xrow[i] != nullptr) {
+                if (vec_ok) {
+                    if (k < L.K) t = *reinterpret_cast<const f32x4 *>(xrow[i] + k);
+                } else {
+                    if (k < L.K) t.x = xrow[i][k];
+                    if (k + 1 < L.K) t.y = xrow[i][k + 1];
+                    if (k + 2 < L.K) t.z = xrow[i][k + 2];
+                    if (k + 3 < L.K) t.w = xrow[i][k + 3];
+                }
+            }
+            v[i] = t;
+        }
+    };
+    auto stash = [&](int buf, const f32x4 (&v)[XR]) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i)
+            *reinterpret_cast<f32x4 *>(&xs[(buf * TM + sr + 16 * i) * kLdX + sc]) = v[i];
+    };
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(blob + L.w_off) + lane;
+    long long wbase[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wbase[t] = (long long)min((n0 >> 4) + wn * NTW + t, NT - 1) * KT * 64;
+    auto wload = [&](int kt, f32x4 (&w)[NTW]) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) w[t] = wp[wbase[t] + (long long)kt * 64];
+    };
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (c_lo < c_hi) {
+        f32x4 xv[XR], wc[NTW], wnx[NTW];
+        fetch(c_lo, xv);
+        wload(c_lo * 4, wc);
+        stash(0, xv);
+        __syncthreads();
+        for (int c = c_lo; c < c_hi; ++c) {
+            const int buf = (c - c_lo) & 1;
+            const bool more = c + 1 < c_hi;
+            if (more) fetch(c + 1, xv);
+            const int kt0 = c * 4, nk = min(4, KT - kt0);
+            for (int t = 0; t < nk; ++t) {
+                const int kt = kt0 + t;
+                wload(min(kt + 1, KT - 1), wnx);  // next k-tile (the last one re-reads its own tile)
+                f32x4 a[MTW];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+                    a[mt] = *reinterpret_cast<const f32x4 *>(
+                        &xs[(buf * TM + (wm * MTW + mt) * 16 + m) * kLdX + t * 16 + kq * 4]);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, wc[nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, wc[nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, wc[nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, wc[nt].w, acc[mt][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) wc[nt] = wnx[nt];
+            }
+            if (more) stash(buf ^ 1, xv);
+            __syncthreads();
+        }
+    }
+
+    const float *bias = blob + L.b_off;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int col = n0 + (wn * NTW + nt) * 16 + m;
+        if (col >= L.Np) continue;
+        const float b = bias[col];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = m0 + (wm * MTW + mt) * 16 + kq * 4 + j;
+                if (row >= B) continue;
+                if (splitk == 1) {
+                    if (col < L.N) y[(long long)row * ldy + col] = activate(acc[mt][nt][j] + b, L.act);
+                } else {
+                    ws[((long long)z * B + row) * L.Np + col] = acc[mt][nt][j];
+                }
+            }
+    }
+}
+
+// y = act(sum over splits (fixed order) + bias)
+__global__ void __launch_bounds__(kWT)
+k_wide_finish(mz_packed_layer L, const float *__restrict__ blob, const float *__restrict__ ws, int splitk, int B,
+              float *__restrict__ y, long long ldy) {
+    const long long total = (long long)B * L.N;
+    const float *bias = blob + L.b_off;
+    for (long long i = (long long)blockIdx.x * kWT + threadIdx.x; i < total; i += (long long)gridDim.x * kWT) {
+        const int r = (int)(i / L.N), c = (int)(i - (long long)r * L.N);
+        float s = 0.0f;
+        for (int z = 0; z < splitk; ++z) s += ws[((long long)z * B + r) * L.Np + c];
+        y[(long long)r * ldy + c] = activate(s + bias[c], L.act);
+    }
+}
+
+struct WideShape {
+    bool big;
+    int tm, tn, tiles_m, tiles_n, splitk, chunks_per_split;
+};
+
+WideShape wide_shape(const mz_packed_layer &L, int B) {
+    WideShape s{};
+    s.big = B > 64 && L.Np > 64;
+    s.tm = s.tn = s.big ? 128 : 64;
+    s.tiles_m = (B + s.tm - 1) / s.tm;
+    s.tiles_n = (L.Np + s.tn - 1) / s.tn;
+    const int nchunks = ((L.Kp >> 4) + 3) >> 2;
+    // two 4-wave workgroups fit a CU: aim at one round of 512 workgroups, at most 16 splits
+    const int tiles = s.tiles_m * s.tiles_n;
+    int k = std::max(1, 512 / std::max(1, tiles));
+    k = std::min(k, std::min(16, nchunks));
+    s.chunks_per_split = (nchunks + k - 1) / k;
+    s.splitk = (nchunks + s.chunks_per_split - 1) / s.chunks_per_split;
+    return s;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes, const char *what) {
+    if (bytes <= 64 * 1024) return MZ_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return mz::fail(MZ_ERR_HIP, "%s: cannot enable %zu bytes of LDS: %s", what, bytes, hipGetErrorString(e));
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------ residual tower
+struct TowerGeom {
+    int C, H, W, HW, P;  // P = group * HW positions normalised together
+    int cmax;            // widest block output
+    int stage_c;         // input channels of the first block staged per pass
+    int pw, ks;          // waves across positions / slices of the input channels (pw * ks = 4)
+    int off_a, off_b, off_c, off_red, off_stage;  // LDS offsets in floats
+};
+
+constexpr int COB = 4;  // output channels accumulated together per pass
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// In-place BatchNorm2d with the statistics of the P values of each channel (mean and biased
+// variance, accumulated in double as torch's CPU kernels do), then the activation.
+__device__ void bn_act(lds_f *buf, int C, int P, const float *__restrict__ gamma, const float *__restrict__ beta,
+                       float eps, int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += kWT / 64) {
+        lds_f *v = buf + c * P;
+        double s = 0.0;
+        for (int p = lane; p < P; p += 64) s += (double)v[p];
+        const double mean = wave_sum(s) / P;
+        double q = 0.0;
+        for (int p = lane; p < P; p += 64) {
+            const double d = (double)v[p] - mean;
+            q += d * d;
+        }
+        const double invstd = 1.0 / sqrt(wave_sum(q) / P + (double)eps);
+        const float scale = (float)((double)gamma[c] * invstd);
+        const float shift = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+        for (int p = lane; p < P; p += 64) v[p] = activate(v[p] * scale + shift, act);
+    }
+}
+
+// Adds, for output channels co0 .. co0+COB-1 at position p, the k x k convolution (and, if
+// DOWN, the 1x1 convolution) over the input channels [c_lo, c_hi) held in LDS as
+// src[(ci - c_base) * P + position].  KF = k when known at compile time, 0 otherwise.
+template <bool DOWN, int KF>
+__device__ __forceinline__ void conv_accumulate(const lds_f *src, int c_base, int c_lo, int c_hi, int Cin, int Cout,
+                                                const float *__restrict__ w, const float *__restrict__ wd, int co0,
+                                                int k_rt, int H, int W, int P, int p, bool live, float (&acc)[COB],
+                                                float (&accd)[COB]) {
+    const int k = KF ? KF : k_rt;
+    const int HW = H * W, pad = (k - 1) >> 1, kk = k * k;
+    const int row = p / HW, s = p - row * HW, py = s / W, px = s - py * W;
+    long long wo[COB], wdo[COB];
+#pragma unroll
+    for (int o = 0; o < COB; ++o) {
+        const int co = min(co0 + o, Cout - 1);  // surplus channels repeat the last one and are dropped
+        wo[o] = (long long)co * Cin * kk;
+        wdo[o] = (long long)co * Cin;
+    }
+    for (int ci = c_lo; ci < c_hi; ++ci) {
+        const lds_f *plane = src + (ci - c_base) * P + row * HW;
+#pragma unroll
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = py + ky - pad;
+#pragma unroll
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = px + kx - pad;
+                const bool in = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const float v = in ? plane[yy * W + xx] : 0.0f;
+#pragma unroll
+                for (int o = 0; o < COB; ++o) acc[o] = fmaf(w[wo[o] + ci * kk + ky * k + kx], v, acc[o]);
+            }
+        }
+        if (DOWN) {
+            const float v = live ? plane[s] : 0.0f;
+#pragma unroll
+            for (int o = 0; o < COB; ++o) accd[o] = fmaf(wd[wdo[o] + ci], v, accd[o]);
+        }
+    }
+}
+
+template <bool DOWN>
+__device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int c_lo, int c_hi, int Cin, int Cout,
+                                              const float *__restrict__ w, const float *__restrict__ wd, int co0,
+                                              int k, int H, int W, int P, int p, bool live, float (&acc)[COB],
+                                              float (&accd)[COB]) {
+    if (k == 3) conv_accumulate<DOWN, 3>(src, c_base, c_lo, c_hi, Cin, Cout, w, wd, co0, k, H, W, P, p, live, acc, accd);
+    else if (k == 1) conv_accumulate<DOWN, 1>(src, c_base, c_lo, c_hi, Cin, Cout, w, wd, co0, k, H, W, P, p, live, acc, accd);
+    else conv_accumulate<DOWN, 0>(src, c_base, c_lo, c_hi, Cin, Cout, w, wd, co0, k, H, W, P, p, live, acc, accd);
+}
+
+// One workgroup per group of rows (one network call of the reference).  LDS holds three
+// activation buffers of cmax x P floats (a: block input / result, b: after conv1, c: skip path
+// or conv2 output), the staging area for the first block's input and the slice partials.
+__global__ void __launch_bounds__(kWT)
+k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
+        const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
+        float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, int group) {
+    extern __shared__ __align__(16) float smem[];
+    lds_f *S = to_lds(smem);
+    lds_f *cur = S + G.off_a, *mid = S + G.off_b, *aux = S + G.off_c, *red = S + G.off_red, *stage = S + G.off_stage;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = G.HW, P = G.P;
+    const int r0 = blockIdx.x * group;
+    const int pwi = wave % G.pw, ksi = wave / G.pw;  // position slot / channel slice of this wave
+    const int pstride = G.pw * 64;
+
+    auto src_row = [&](int r) -> const float * {
+        const long long s = x_rows ? (long long)x_rows[r0 + r] : (long long)(r0 + r);
+        return s < 0 ? nullptr : x + s * ldx;
+    };
+    auto add_row = [&](int r) -> const float * {
+        if (row_add == nullptr) return nullptr;
+        const int sel = row_sel ? row_sel[r0 + r] : r;
+        return row_add + (long long)sel * ld_add;
+    };
+    // tower input (merge split applied) for channels [cb, cb+cn) -> dst[c * P + p]
+    auto load_input = [&](lds_f *dst, int cb, int cn) {
+        for (int p = tid; p < P; p += kWT) {
+            const int r = p / HW, s = p - r * HW;
+            const float *xr = src_row(r), *ar = add_row(r);
+            for (int c = 0; c < cn; ++c) {
+                float v = xr ? xr[(cb + c) * HW + s] : 0.0f;
+                if (ar) {
+                    v += ar[(cb + c) * HW + s];
+                    v = v > 0.0f ? v : 0.0f;
+                }
+                dst[c * P + p] = v;
+            }
+        }
+    };
+    // sums the channel slices of acc in a fixed order (slice 0 ends up with the total)
+    auto reduce_slices = [&](float (&acc)[COB], int which, int slot, bool live) {
+        if (live)
+            for (int o = 0; o < COB; ++o) red[((ksi * 2 + which) * COB + o) * pstride + slot] = acc[o];
+        __syncthreads();
+        if (ksi == 0 && live)
+            for (int o = 0; o < COB; ++o) {
+                float s = 0.0f;
+                for (int q = 0; q < G.ks; ++q) s += red[((q * 2 + which) * COB + o) * pstride + slot];
+                acc[o] = s;
+            }
+    };
+
+    for (int b = 0; b < T.n_blocks; ++b) {
+        const mz_resblock &R = T.block[b];
+        const int Cin = R.in_channels, Cout = R.out_channels, k = R.kernel_size;
+        const bool down = R.down_w != nullptr;
+        const bool from_global = b == 0;
+        // ---- conv1 -> mid, and the 1x1 skip convolution of the same input -> aux
+        for (int co0 = 0; co0 < Cout; co0 += COB) {
+            for (int pb = 0; pb < P; pb += pstride) {
+                const int slot = pwi * 64 + lane, p = pb + slot;
+                const bool live = p < P;
+                const int pc = live ? p : 0;
+                float acc[COB] = {0.0f, 0.0f, 0.0f, 0.0f}, accd[COB] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (from_global) {
+                    for (int cb = 0; cb < Cin; cb += G.stage_c) {
+                        const int cn = min(G.stage_c, Cin - cb);
+                        __syncthreads();  // the previous pass has been consumed
+                        load_input(stage, cb, cn);
+                        __syncthreads();
+                        const int per = (cn + G.ks - 1) / G.ks;
+                        const int lo = cb + min(cn, ksi * per), hi = cb + min(cn, (ksi + 1) * per);
+                        if (down) conv_dispatch<true>(stage, cb, lo, hi, Cin, Cout, R.conv1_w, R.down_w, co0, k, G.H, G.W, P, pc, live, acc, accd);
+                        else conv_dispatch<false>(stage, cb, lo, hi, Cin, Cout, R.conv1_w, nullptr, co0, k, G.H, G.W, P, pc, live, acc, accd);
+                    }
+                } else {
+                    const int per = (Cin + G.ks - 1) / G.ks;
+                    const int lo = min(Cin, ksi * per), hi = min(Cin, (ksi + 1) * per);
+                    if (down) conv_dispatch<true>(cur, 0, lo, hi, Cin, Cout, R.conv1_w, R.down_w, co0, k, G.H, G.W, P, pc, live, acc, accd);
+                    else conv_dispatch<false>(cur, 0, lo, hi, Cin, Cout, R.conv1_w, nullptr, co0, k, G.H, G.W, P, pc, live, acc, accd);
+                }
+                if (G.ks > 1) {
+                    __syncthreads();  // earlier partials have been read
+                    reduce_slices(acc, 0, slot, live);
+                    if (down) reduce_slices(accd, 1, slot, live);
+                }
+                if (ksi == 0 && live)
+                    for (int o = 0; o < COB; ++o)
+                        if (co0 + o < Cout) {
+                            mid[(co0 + o) * P + p] = acc[o];
+                            if (down) aux[(co0 + o) * P + p] = accd[o];
+                        }
+            }
+        }
+        __syncthreads();
+        bn_act(mid, Cout, P, R.bn1_w, R.bn1_b, R.eps1, R.activation);
+        if (down) bn_act(aux, Cout, P, R.dbn_w, R.dbn_b, R.epsd, MZ_ACT_NONE);
+        __syncthreads();
+        // ---- conv2: mid -> dst.  `cur` is free unless it still holds the identity skip.
+        lds_f *dst = (!from_global && !down) ? aux : cur;
+        for (int co0 = 0; co0 < Cout; co0 += COB) {
+            for (int pb = 0; pb < P; pb += pstride) {
+                const int slot = pwi * 64 + lane, p = pb + slot;
+                const bool live = p < P;
+                float acc[COB] = {0.0f, 0.0f, 0.0f, 0.0f}, accd[COB] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int per = (Cout + G.ks - 1) / G.ks;
+                const int lo = min(Cout, ksi * per), hi = min(Cout, (ksi + 1) * per);
+                conv_dispatch<false>(mid, 0, lo, hi, Cout, Cout, R.conv2_w, nullptr, co0, k, G.H, G.W, P, live ? p : 0, live, acc, accd);
+                if (G.ks > 1) {
+                    __syncthreads();
+                    reduce_slices(acc, 0, slot, live);
+                }
+                if (ksi == 0 && live)
+                    for (int o = 0; o < COB; ++o)
+                        if (co0 + o < Cout) dst[(co0 + o) * P + p] = acc[o];
+            }
+        }
+        __syncthreads();
+        bn_act(dst, Cout, P, R.bn2_w, R.bn2_b, R.eps2, MZ_ACT_NONE);
+        __syncthreads();
+        // ---- skip connection + activation -> cur (input of the next block)
+        if (from_global && !down) {
+            // identity skip from the tower input: stage it (Cin == Cout <= cmax fits `mid`, now free)
+            load_input(mid, 0, Cout);
+            __syncthreads();
+        }
+        const lds_f *skip = down ? aux : (from_global ? mid : cur);
+        for (int i = tid; i < Cout * P; i += kWT) cur[i] = activate(dst[i] + skip[i], R.activation);
+        __syncthreads();
+    }
+
+    // ---- res_final (1x1 convolution with bias back to C channels) and the store
+    const int Cl = T.n_blocks ? T.block[T.n_blocks - 1].out_channels : G.C;
+    for (int p = tid; p < P; p += kWT) {
+        const int r = p / HW, s = p - r * HW;
+        const long long dr = y_rows ? (long long)y_rows[r0 + r] : (long long)(r0 + r);
+        if (dr < 0) continue;
+        float *yr = y + dr * ldy + s;
+        if (T.final_w != nullptr) {
+            for (int c = 0; c < G.C; ++c) {
+                float v = T.final_b ? T.final_b[c] : 0.0f;
+                for (int ci = 0; ci < Cl; ++ci) v = fmaf(T.final_w[c * Cl + ci], cur[ci * P + p], v);
+                yr[c * HW] = v;
+            }
+        } else if (T.n_blocks) {
+            for (int c = 0; c < G.C; ++c) yr[c * HW] = cur[c * P + p];
+        } else {
+            const float *xr = src_row(r), *ar = add_row(r);
+            for (int c = 0; c < G.C; ++c) {
+                float v = xr ? xr[c * HW + s] : 0.0f;
+                if (ar) {
+                    v += ar[c * HW + s];
+                    v = v > 0.0f ? v : 0.0f;
+                }
+                yr[c * HW] = v;
+            }
+        }
+    }
+}
+
+int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes) {
+    if (!T || T->n_blocks < 0 || T->n_blocks > MZ_MAX_BLOCKS || T->C <= 0 || T->H <= 0 || T->W <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_forward: bad tower (n_blocks 0..%d, positive C, H, W)", MZ_MAX_BLOCKS);
+    if (group <= 0) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: group must be positive");
+    std::memset(g, 0, sizeof(*g));
+    g->C = T->C;
+    g->H = T->H;
+    g->W = T->W;
+    g->HW = T->H * T->W;
+    g->P = group * g->HW;
+    if (T->n_blocks && g->P < 2)
+        // torch.nn.BatchNorm2d: "Expected more than 1 value per channel when training"
+        return mz::fail(MZ_ERR_ARG, "mz_tower_forward: batch statistics need more than 1 value per channel");
+    int cin = T->C;
+    for (int b = 0; b < T->n_blocks; ++b) {
+        const mz_resblock &R = T->block[b];
+        if (R.in_channels != cin || R.out_channels <= 0 || R.kernel_size <= 0 || !(R.kernel_size & 1))
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d: in_channels %d (expected %d), out_channels %d, "
+                            "kernel_size %d (must be odd)", b, R.in_channels, cin, R.out_channels, R.kernel_size);
+        if (!R.conv1_w || !R.bn1_w || !R.bn1_b || !R.conv2_w || !R.bn2_w || !R.bn2_b)
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d has a NULL weight", b);
+        if ((R.in_channels != R.out_channels) != (R.down_w != nullptr) || (R.down_w && (!R.dbn_w || !R.dbn_b)))
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d: the 1x1 skip convolution must be given exactly "
+                            "when the channel count changes", b);
+        if (R.activation < MZ_ACT_NONE || R.activation > MZ_ACT_SIGMOID)
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d has unsupported activation %d", b, R.activation);
+        g->cmax = std::max(g->cmax, R.out_channels);
+        cin = R.out_channels;
+    }
+    if (T->final_w == nullptr && cin != T->C)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_forward: the last block leaves %d channels, res_final is needed for C=%d",
+                        cin, T->C);
+    const int slots = (g->P + 63) / 64;
+    g->pw = slots >= 3 ? 4 : slots;  // 1, 2 or 4 waves across the positions
+    g->ks = 4 / g->pw;
+    const long long buf = (long long)std::max(1, g->cmax) * g->P;
+    const long long red = g->ks > 1 ? (long long)g->ks * 2 * COB * g->pw * 64 : 0;
+    const long long fixed = 3 * buf + red;
+    const long long room = (long long)(kMaxLds / sizeof(float)) - fixed;
+    if (room < g->P)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_forward: %d channels x %d positions per call exceed the LDS-resident "
+                        "tower", g->cmax, g->P);
+    g->off_a = 0;
+    g->off_b = (int)buf;
+    g->off_c = (int)(2 * buf);
+    g->off_red = (int)(3 * buf);
+    g->off_stage = (int)fixed;
+    g->stage_c = (int)std::min<long long>(T->C, room / g->P);
+    *lds_bytes = (size_t)(fixed + (T->n_blocks ? (long long)g->stage_c * g->P : 0)) * sizeof(float);
+    return MZ_OK;
+}
+
+// ------------------------------------------------------------------ policy post-processing
+__global__ void __launch_bounds__(kWT)
+k_policy_post(const float *__restrict__ in, int B, int A, int times, float *__restrict__ out,
+              int32_t *__restrict__ argmax) {
+    const int r = blockIdx.x * kWT + threadIdx.x;
+    if (r >= B) return;
+    const float *p = in + (long long)r * A;
+    if (argmax) {
+        int best = 0;
+        for (int i = 1; i < A; ++i)
+            if (p[i] > p[best]) best = i;
+        argmax[r] = best;
+    }
+    if (out == nullptr) return;
+    float *q = out + (long long)r * A;
+    if (q != p)
+        for (int i = 0; i < A; ++i) q[i] = p[i];
+    for (int t = 0; t < times; ++t) {
+        float mx = q[0];
+        for (int i = 1; i < A; ++i) mx = fmaxf(mx, q[i]);
+        float s = 0.0f;
+        for (int i = 0; i < A; ++i) {
+            const float e = expf(q[i] - mx);
+            q[i] = e;
+            s += e;
+        }
+        for (int i = 0; i < A; ++i) q[i] = q[i] / s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mz_wide_workspace(const mz_packed_layer *h_plan, int32_t B) {
+    if (!h_plan || B < 0) return mz::fail(MZ_ERR_ARG, "mz_wide_workspace: NULL plan or negative B");
+    if (B == 0) return 0;
+    const WideShape s = wide_shape(*h_plan, B);
+    return s.splitk > 1 ? (int64_t)s.splitk * B * h_plan->Np : 0;
+}
+
+int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                    const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
+                    int64_t workspace_floats, void *stream) {
+    if (!h_plan || !blob || !x || !y || B < 0 || ldx < h_plan->K || ldy < h_plan->N)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_forward: NULL argument, negative B or row stride below the row width");
+    if (h_plan->act < MZ_ACT_NONE || h_plan->act > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_forward: activation %d is not element-wise", h_plan->act);
+    if (B == 0) return MZ_OK;
+    const mz_packed_layer L = *h_plan;
+    const WideShape s = wide_shape(L, B);
+    const int64_t need = s.splitk > 1 ? (int64_t)s.splitk * B * L.Np : 0;
+    if (need > 0 && (!workspace || workspace_floats < need))
+        return mz::fail(MZ_ERR_ARG, "mz_wide_forward: workspace of %lld floats needed, %lld given", (long long)need,
+                        (long long)(workspace ? workspace_floats : 0));
+    hipStream_t st = (hipStream_t)stream;
+    const int vec_ok = (ldx % 4 == 0) && (L.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const dim3 grid(s.tiles_n, s.tiles_m, s.splitk);
+    const size_t lds = (size_t)2 * s.tm * kLdX * sizeof(float);
+    if (s.big) {
+        MZ_TRY(allow_lds(k_wide<4, 4>, lds, "k_wide"));
+        hipLaunchKernelGGL((k_wide<4, 4>), grid, dim3(kWT), lds, st, L, blob, x, (long long)ldx, x_rows, y,
+                           (long long)ldy, B, s.splitk, s.chunks_per_split, workspace, vec_ok);
+    } else {
+        hipLaunchKernelGGL((k_wide<2, 2>), grid, dim3(kWT), lds, st, L, blob, x, (long long)ldx, x_rows, y,
+                           (long long)ldy, B, s.splitk, s.chunks_per_split, workspace, vec_ok);
+    }
+    MZ_TRY(mz::check_launch("k_wide"));
+    if (s.splitk > 1) {
+        const long long total = (long long)B * L.N;
+        const int nb = (int)std::min<long long>((total + kWT - 1) / kWT, 8192);
+        hipLaunchKernelGGL(k_wide_finish, dim3(nb), dim3(kWT), 0, st, L, blob, workspace, s.splitk, B, y,
+                           (long long)ldy);
+        MZ_TRY(mz::check_launch("k_wide_finish"));
+    }
+    return MZ_OK;
+}
+
+int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
+                     const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
+                     int64_t ldy, const int32_t *y_rows, int32_t B, int32_t group, void *stream) {
+    TowerGeom g;
+    size_t lds = 0;
+    MZ_TRY(tower_geometry(h_tower, group, &g, &lds));
+    const int D = g.C * g.HW;
+    if (!x || !y || B < 0 || ldx < D || ldy < D || (row_add && ld_add < D))
+        return mz::fail(MZ_ERR_ARG, "mz_tower_forward: NULL argument, negative B or a row stride below C*H*W=%d", D);
+    if (B % group) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: B=%d is not a multiple of group=%d", B, group);
+    if (B == 0) return MZ_OK;
+    MZ_TRY(allow_lds(k_tower, lds, "k_tower"));
+    hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kWT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
+                       x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, group);
+    return mz::check_launch("k_tower");
+}
+
+int mz_policy_post(const float *policy_in, int32_t B, int32_t A, int32_t softmax_times, float *policy_out,
+                   int32_t *argmax, void *stream) {
+    if (!policy_in || B < 0 || A <= 0 || softmax_times < 0)
+        return mz::fail(MZ_ERR_ARG, "mz_policy_post: NULL input, negative B or softmax_times, or A <= 0");
+    if (B == 0 || (!policy_out && !argmax)) return MZ_OK;
+    hipLaunchKernelGGL(k_policy_post, dim3((B + kWT - 1) / kWT), dim3(kWT), 0, (hipStream_t)stream, policy_in, B, A,
+                       softmax_times, policy_out, argmax);
+    return mz::check_launch("k_policy_post");
+}
+
+}  // extern "C"

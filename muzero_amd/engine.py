@@ -267,8 +267,12 @@ class BatchedMCTS:
         (mz_search_run); otherwise the per-stage kernels are driven in lock step.  Both leave
         bit-identical pools."""
         assert rand_child.shape == (self.G, self.S + 1) and rand_child.dtype == torch.int32
+        fusable = getattr(self.nets, "fusable", True)
         if fused is None:
-            fused = self.A <= 32
+            fused = self.A <= 32 and fusable
+        if fused and not fusable:
+            raise NotImplementedError("the single-launch search covers the MLP-only networks; "
+                                      "these networks run in lock step (fused=False)")
         if fused:
             return self.run_fused(root_latent, root_to_play, eta, rand_child, trace)
         self.begin(root_latent, root_to_play, eta, rand_child[:, 0])

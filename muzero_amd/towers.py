@@ -1,0 +1,279 @@
+"""Batched g / f for residual-tower configurations (`res_net` non-empty) on the HIP kernels.
+
+`TowerNetworks` offers the same `dynamics(...)` / `prediction(...)` calls as
+`muzero_amd.engine.PackedNetworks`, so `BatchedMCTS` drives it in lock step (one launch per
+stage per simulation for all G trees).  What the kernels compute follows
+src/neural_networks/neural_network.py:152-188 (g) and :234-262 (f):
+
+* fc_merge is split as for the MLP networks: `W[:, :D] @ latent` once per distinct latent
+  (`mz_wide_forward`, fp32 MFMA, reduction dimension streamed through LDS) plus a per-action
+  table `W[:, D:] @ E[a] + b` (`mz_action_table`) added while the tower loads its input;
+* the ResBlocks and res_final run in `mz_tower_forward` with the batch statistics of ONE
+  reference call per group of rows: the reference never leaves train mode, so expansion
+  normalises over the A children of a node together (src/search/expansion.py:25-28) and every
+  other call over a single latent;
+* heads: the first Linear of a head reads D inputs (`mz_wide_forward` when D exceeds the
+  LDS-resident MLP kernels' width, else the whole head goes through `mz_mlp_forward`).
+
+There is no CPU fallback: every call goes through libmuzero_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from muzero_amd import _hip
+from muzero_amd._hip import ptr
+from muzero_amd.neural_networks.network_builder import ResBlock
+
+MAX_BLOCKS = _hip.MAX_BLOCKS
+CTower = _hip.Tower
+
+_ACT_OF = {torch.nn.Identity: "none", torch.nn.ReLU: "relu", torch.nn.Tanh: "tanh", torch.nn.Sigmoid: "sigmoid",
+           torch.nn.Softmax: "softmax"}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Head:
+    """One MLP head: optional wide first layer + the rest through the LDS-resident MLP kernel."""
+
+    def __init__(self):
+        self.wide: _hip.PackedLayer | None = None
+        self.rest: _hip.PackedMlp | None = None
+        self.extra_softmax = 0   # the network's own softmax when no kernel layer applies it
+        self.out_features = 0
+        self.mid_features = 0
+
+
+class TowerNetworks:
+    """Device copy of g / f with residual towers, evaluated by the HIP kernels.
+
+    `wide_above`: heads whose input is wider than this use the chunked wide-layer kernel for
+    their first layer (the LDS-resident MLP kernels hold rows of at most 4096 floats)."""
+
+    fusable = False  # no single-launch search for these networks: BatchedMCTS runs in lock step
+
+    def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096):
+        self.device = torch.device(device)
+        self.dynamics_net, self.prediction_net = dynamics, prediction
+        c, h, w = dynamics.latent_shape
+        self.shape = (c, h, w)
+        self.D, self.A = c * h * w, dynamics.num_actions
+        self.wide_above = wide_above
+        self._keep: list[torch.Tensor] = []
+        self._bufs: dict = {}
+        self.blob = None
+        self.refresh()
+
+    # ---- packing ----------------------------------------------------------------------------
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(self.device, torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _tower(self, blocks, res_final) -> CTower:
+        c, h, w = self.shape
+        t = CTower()
+        t.n_blocks, t.C, t.H, t.W = len(blocks), c, h, w
+        if len(blocks) > MAX_BLOCKS:
+            raise NotImplementedError(f"at most {MAX_BLOCKS} residual blocks per tower")
+        for i, blk in enumerate(blocks):
+            assert isinstance(blk, ResBlock)
+            k = blk.conv1.kernel_size[0]
+            if (blk.conv1.kernel_size != (k, k) or blk.conv1.stride != (1, 1) or
+                    blk.conv1.padding != ((k - 1) // 2, (k - 1) // 2) or k % 2 == 0 or
+                    not isinstance(blk.pool, torch.nn.Identity)):
+                # anything else changes H x W, which neural_network.py:185,254 cannot flatten into the heads
+                raise NotImplementedError("g/f residual blocks must keep the latent's H x W "
+                                          "(stride 1, padding (k-1)/2, no pooling)")
+            b = t.block[i]
+            b.conv1_w, b.bn1_w, b.bn1_b = (ptr(self._dev(x)) for x in (blk.conv1.weight, blk.bn1.weight, blk.bn1.bias))
+            b.conv2_w, b.bn2_w, b.bn2_b = (ptr(self._dev(x)) for x in (blk.conv2.weight, blk.bn2.weight, blk.bn2.bias))
+            if blk.downsample is not None:
+                conv, bn = blk.downsample[0], blk.downsample[1]
+                b.down_w, b.dbn_w, b.dbn_b = (ptr(self._dev(x)) for x in (conv.weight, bn.weight, bn.bias))
+                b.epsd = bn.eps
+            b.in_channels, b.out_channels, b.kernel_size = blk.conv1.in_channels, blk.conv1.out_channels, k
+            b.activation = _hip.ACT[_ACT_OF[type(blk.activation)]]
+            b.eps1, b.eps2 = blk.bn1.eps, blk.bn2.eps
+        if not isinstance(res_final, torch.nn.Identity):
+            t.final_w = ptr(self._dev(res_final.weight.reshape(res_final.out_channels, res_final.in_channels)))
+            t.final_b = ptr(self._dev(res_final.bias)) if res_final.bias is not None else None
+        return t
+
+    def _layers(self, seq: torch.nn.Sequential):
+        mods = list(seq)
+        out = []
+        for i in range(0, len(mods), 2):
+            lin = mods[i]
+            assert isinstance(lin, torch.nn.Linear), f"unexpected module {type(lin)} in MLP"
+            act = mods[i + 1] if i + 1 < len(mods) else torch.nn.Identity()
+            out.append((lin, _ACT_OF[type(act)]))
+        return out
+
+    def _dense(self, lin: torch.nn.Linear, act: str, ldw: int = 0, cols=None) -> _hip.Dense:
+        w = self._dev(lin.weight)
+        b = self._dev(lin.bias) if lin.bias is not None else None
+        return _hip.Dense(ptr(w), ptr(b), cols or lin.in_features, lin.out_features, _hip.ACT[act], ldw)
+
+    def refresh(self) -> None:
+        """Re-reads the modules' weights (call after a weight update)."""
+        self._keep = []
+        lib = _hip.lib()
+        g, f = self.dynamics_net, self.prediction_net
+        D, A = self.D, self.A
+        self.tower_g = self._tower(list(g.res_blocks), g.res_final)
+        self.tower_f = self._tower(list(f.res_blocks), f.res_final)
+        # plan every packed piece into one blob
+        plans = []  # (kind, dense-or-mlp, plan)
+        off = 0
+
+        def plan_wide(dense):
+            nonlocal off
+            pl = _hip.PackedLayer()
+            n = lib.mz_wide_plan(C.byref(dense), off, C.byref(pl))
+            if n < 0:
+                _hip.check(int(n), "mz_wide_plan")
+            off += n
+            plans.append(("wide", dense, pl))
+            return pl
+
+        def plan_mlp(layers):
+            nonlocal off
+            m = _hip.Mlp()
+            m.n_layers = len(layers)
+            for i, (lin, act) in enumerate(layers):
+                m.layer[i] = self._dense(lin, act)
+            pm = _hip.PackedMlp()
+            n = lib.mz_mlp_plan(C.byref(m), off, C.byref(pm))
+            if n < 0:
+                _hip.check(int(n), "mz_mlp_plan")
+            off += n
+            plans.append(("mlp", m, pm))
+            return pm
+
+        def plan_head(seq):
+            layers = self._layers(seq)
+            hd = _Head()
+            hd.out_features = layers[-1][0].out_features
+            if D > self.wide_above:
+                lin, act = layers[0]
+                if act == "softmax":   # a one-layer policy head: normalise afterwards
+                    act, hd.extra_softmax = "none", 1
+                hd.wide = plan_wide(self._dense(lin, act))
+                hd.mid_features = lin.out_features
+                layers = layers[1:]
+            if layers:
+                hd.rest = plan_mlp(layers)
+            return hd
+
+        merge = _hip.Dense(ptr(self._dev(g.fc_merge.weight)), None, D, D, _hip.ACT["none"], 2 * D)
+        self.merge = plan_wide(merge)
+        self.reward_head = plan_head(g.reward_mlp)
+        self.value_head = plan_head(f.value_mlp)
+        self.policy_head = plan_head(f.policy_mlp)
+        if self.blob is None or self.blob.numel() != off:
+            self.blob = torch.empty(off, dtype=torch.float32, device=self.device)
+        for kind, src, pl in plans:
+            if kind == "wide":
+                _hip.check(lib.mz_wide_pack(C.byref(src), C.byref(pl), ptr(self.blob), _stream()), "mz_wide_pack")
+            else:
+                _hip.check(lib.mz_mlp_pack(C.byref(src), C.byref(pl), ptr(self.blob), _stream()), "mz_mlp_pack")
+        self.table = torch.empty((A, D), dtype=torch.float32, device=self.device)
+        _hip.check(lib.mz_action_table(ptr(self._dev(g.action_embedding.weight)), ptr(self._dev(g.fc_merge.weight)),
+                                       ptr(self._dev(g.fc_merge.bias)) if g.fc_merge.bias is not None else None,
+                                       D, A, ptr(self.table), _stream()), "mz_action_table")
+
+    # ---- scratch ----------------------------------------------------------------------------
+    def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        t = self._bufs.get(name)
+        n = 1
+        for s in shape:
+            n *= s
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t[:n].view(*shape)
+
+    def _group_index(self, B: int, A: int) -> torch.Tensor:
+        key = ("gidx", B, A)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.arange(B, dtype=torch.int32, device=self.device) // A).contiguous()
+            self._bufs[key] = t
+        return t
+
+    # ---- kernels ----------------------------------------------------------------------------
+    def _wide(self, plan, x, ldx, x_rows, y, B) -> None:
+        lib = _hip.lib()
+        need = lib.mz_wide_workspace(C.byref(plan), B)
+        ws = self._buf("wide_ws", (need,)) if need > 0 else None
+        _hip.check(lib.mz_wide_forward(C.byref(plan), ptr(self.blob), ptr(x), ldx, ptr(x_rows), ptr(y), y.shape[-1], B,
+                                       ptr(ws), need, _stream()), "mz_wide_forward")
+
+    def _head(self, hd: _Head, name: str, x, ldx, x_rows, B) -> torch.Tensor:
+        """Returns f32[B][out_features] (network output of the head, its own softmax included)."""
+        lib = _hip.lib()
+        out = self._buf(name + "_out", (B, hd.out_features))
+        if hd.wide is not None:
+            first = out if hd.rest is None else self._buf(name + "_mid", (B, hd.mid_features))
+            self._wide(hd.wide, x, ldx, x_rows, first, B)
+            x, ldx, x_rows = first, hd.mid_features, None
+        if hd.rest is not None:
+            _hip.check(lib.mz_mlp_forward(C.byref(hd.rest), ptr(self.blob), ptr(x), ldx, ptr(x_rows), ptr(out),
+                                          hd.out_features, B, _stream()), "mz_mlp_forward")
+        if hd.extra_softmax:
+            _hip.check(lib.mz_policy_post(ptr(out), B, hd.out_features, hd.extra_softmax, ptr(out), None, _stream()),
+                       "mz_policy_post")
+        return out
+
+    def _tower_call(self, tower, x, ldx, x_rows, row_add, row_sel, y, ldy, y_rows, B, group) -> None:
+        _hip.check(_hip.lib().mz_tower_forward(C.byref(tower), ptr(x), ldx, ptr(x_rows), ptr(row_add), self.D,
+                                               ptr(row_sel), ptr(y), ldy, ptr(y_rows), B, group, _stream()),
+                   "mz_tower_forward")
+
+    # ---- batched g / f (same calls as PackedNetworks) -----------------------------------------
+    def dynamics(self, latent, B, *, ld=None, rows=None, action=None, next_latent=None, ld_next=None, next_rows=None,
+                 reward=None) -> None:
+        """action None: the expansion pattern -- consecutive groups of A rows share one latent and
+        take actions 0..A-1; each group is one call of the reference (shared batch statistics).
+        action i32[B]: B independent calls of batch size 1."""
+        D, A = self.D, self.A
+        ld = ld or D
+        if action is None:
+            assert B % A == 0, "expansion rows come in groups of A"
+            U = B // A
+            base_rows = rows[::A].contiguous() if rows is not None else \
+                (torch.arange(U, dtype=torch.int32, device=self.device) * A)
+            base = self._buf("merge_base", (U, D))
+            self._wide(self.merge, latent, ld, base_rows, base, U)
+            x_rows, row_sel, group = self._group_index(B, A), None, A
+        else:
+            base = self._buf("merge_base", (B, D))
+            self._wide(self.merge, latent, ld, rows, base, B)
+            x_rows, row_sel, group = None, action, 1
+        if next_latent is None:
+            next_latent, ld_next, next_rows = self._buf("g_next", (B, D)), D, None
+        ld_next = ld_next or D
+        self._tower_call(self.tower_g, base, D, x_rows, self.table, row_sel, next_latent, ld_next, next_rows, B, group)
+        if reward is not None:
+            out = self._head(self.reward_head, "reward", next_latent, ld_next, next_rows, B)
+            reward.view(-1)[:B].copy_(out.view(-1))
+
+    def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None) -> None:
+        if policy is None and value is None and argmax is None:
+            return
+        D = self.D
+        t = self._buf("f_tower", (B, D))
+        self._tower_call(self.tower_f, latent, ld or D, rows, None, None, t, D, None, B, 1)
+        if policy is not None or argmax is not None:
+            p = self._head(self.policy_head, "policy", t, D, None, B)
+            _hip.check(_hip.lib().mz_policy_post(ptr(p), B, self.A, softmax_times, ptr(policy), ptr(argmax), _stream()),
+                       "mz_policy_post")
+        if value is not None:
+            v = self._head(self.value_head, "value", t, D, None, B)
+            value.view(-1)[:B].copy_(v.view(-1))

@@ -1,0 +1,202 @@
+"""Residual-tower g / f on the GPU through the C ABI:
+  * the wide dense layer against torch fp32 (1e-5), every tiling / split / tail case;
+  * the tower kernel and the composed g / f against the vectors captured from the reference
+    (tests/golden/towers.npz): per-latent calls and the expansion call whose batch
+    statistics couple the A children;
+  * the lock-step search with these networks: its own network outputs replayed through the
+    CPU tree oracle reproduce every tree bit for bit, and the reference's trees are
+    reproduced whenever no near-tie flips.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyref, tree as otree
+from tests.test_towers_golden import NETS, TREES, Z, load_tower_nets
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def _wide(lin_w, lin_b, act, x, x_rows=None, ldw=0, K=None):
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    N = lin_w.shape[0]
+    K = K or lin_w.shape[1]
+    w = lin_w.cuda().contiguous()
+    b = lin_b.cuda().contiguous() if lin_b is not None else None
+    d = _hip.Dense(ptr(w), ptr(b), K, N, _hip.ACT[act], ldw)
+    pl = _hip.PackedLayer()
+    n = lib.mz_wide_plan(C.byref(d), 0, C.byref(pl))
+    assert n > 0
+    blob = torch.zeros(n, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _hip.check(lib.mz_wide_pack(C.byref(d), C.byref(pl), ptr(blob), st), "pack")
+    xg = x.cuda().contiguous()
+    rows = None if x_rows is None else torch.as_tensor(x_rows, dtype=torch.int32).cuda()
+    B = xg.shape[0] if rows is None else rows.numel()
+    need = lib.mz_wide_workspace(C.byref(pl), B)
+    ws = torch.empty(max(need, 1), device="cuda")
+    y = torch.full((B, N + 3), 7.0, device="cuda")  # row stride wider than N: padding must stay untouched
+    _hip.check(lib.mz_wide_forward(C.byref(pl), ptr(blob), ptr(xg), xg.shape[1], ptr(rows), ptr(y), N + 3, B,
+                                   ptr(ws), need, st), "forward")
+    torch.cuda.synchronize()
+    assert (y[:, N:] == 7.0).all()
+    return y[:, :N].cpu(), need
+
+
+@pytest.mark.parametrize("B,K,N,act", [
+    (5, 36, 10, "none"),        # one small tile, K not a multiple of 16, odd N
+    (64, 64, 64, "relu"),       # exactly one small tile
+    (70, 130, 75, "tanh"),      # big tiles with tails everywhere, K % 4 != 0 -> scalar loads
+    (256, 1024, 512, "relu"),   # big tiles, split reduction
+    (300, 520, 130, "sigmoid"),
+    (2, 9216, 24, "none"),      # the shipped head shape, tiny batch: deep split
+    (1792, 256, 128, "relu"),
+])
+def test_wide_layer_matches_torch(B, K, N, act):
+    torch.manual_seed(B + K + N)
+    w = torch.randn(N, K) / K ** 0.5
+    b = torch.randn(N)
+    x = torch.randn(B, K)
+    got, need = _wide(w, b, act, x)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = {"none": lambda v: v, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act](ref).float()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_wide_layer_gather_submatrix_and_determinism():
+    """Row gather with repeated and negative (= zero) rows; a layer that reads the left half of a
+    wider weight matrix (fc_merge's latent half); two runs give identical bits."""
+    torch.manual_seed(3)
+    D = 200
+    w = torch.randn(D, 2 * D) / D ** 0.5
+    x = torch.randn(40, D)
+    rows = [3, 3, -1, 39, 0, 17] * 30
+    got, need = _wide(w, None, "none", x, x_rows=rows, ldw=2 * D, K=D)
+    again, _ = _wide(w, None, "none", x, x_rows=rows, ldw=2 * D, K=D)
+    assert need > 0  # this shape splits the reduction: the partial sums are combined in a fixed order
+    assert torch.equal(got, again)
+    xr = torch.stack([x[r] if r >= 0 else torch.zeros(D) for r in rows])
+    ref = (xr.double() @ w[:, :D].double().t()).float()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("wide_above", [4096, 0], ids=["mlp-heads", "wide-heads"])
+@pytest.mark.parametrize("ni", NETS)
+def test_g_and_f_match_reference_vectors(ni, wide_above):
+    from muzero_amd.towers import TowerNetworks
+    g, f, A, shape = load_tower_nets(ni)
+    D = int(np.prod(shape))
+    nets = TowerNetworks(g, f, wide_above=wide_above)
+    lat = torch.from_numpy(Z[f"net{ni}_latent"]).cuda().reshape(-1, D).contiguous()
+    act = torch.from_numpy(Z[f"net{ni}_action"]).to(torch.int32).cuda()
+    B = lat.shape[0]
+    # --- B independent calls of batch size 1
+    nxt = torch.zeros(B, D, device="cuda")
+    rew = torch.zeros(B, device="cuda")
+    nets.dynamics(lat, B, action=act, next_latent=nxt, reward=rew)
+    pol = torch.zeros(B, A, device="cuda")
+    pol2 = torch.zeros(B, A, device="cuda")
+    val = torch.zeros(B, device="cuda")
+    arg = torch.zeros(B, dtype=torch.int32, device="cuda")
+    nets.prediction(lat, B, policy=pol, value=val, argmax=arg)
+    nets.prediction(lat, B, softmax_times=1, policy=pol2)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nxt.cpu().numpy(), Z[f"net{ni}_g1_next"].reshape(B, D), **TOL)
+    np.testing.assert_allclose(rew.cpu().numpy(), Z[f"net{ni}_g1_reward"][:, 0], **TOL)
+    np.testing.assert_allclose(pol.cpu().numpy(), Z[f"net{ni}_f1_policy"], **TOL)
+    np.testing.assert_allclose(val.cpu().numpy(), Z[f"net{ni}_f1_value"][:, 0], **TOL)
+    assert np.array_equal(arg.cpu().numpy(), Z[f"net{ni}_f1_policy"].argmax(1))
+    want2 = torch.softmax(torch.from_numpy(Z[f"net{ni}_f1_policy"]), dim=1).numpy()
+    np.testing.assert_allclose(pol2.cpu().numpy(), want2, **TOL)
+    # --- expansion: every latent with all A actions as ONE call (statistics over the A children),
+    # gathered from / scattered to rows of a larger buffer as the search does
+    store = torch.zeros(B * (A + 1) + 5, D, device="cuda")
+    src_rows = torch.arange(B, dtype=torch.int32, device="cuda") * (A + 1) + 2
+    store[src_rows.long()] = lat
+    rows_rep = src_rows.repeat_interleave(A)
+    dst_rows = (src_rows[:, None] + 1 + torch.arange(A, dtype=torch.int32, device="cuda")[None]).reshape(-1).contiguous()
+    rewA = torch.zeros(B, A, device="cuda")
+    nets.dynamics(store, B * A, rows=rows_rep, action=None, next_latent=store, next_rows=dst_rows, reward=rewA)
+    torch.cuda.synchronize()
+    got = store[dst_rows.long()].reshape(B, A, D).cpu().numpy()
+    np.testing.assert_allclose(got, Z[f"net{ni}_gA_next"].reshape(B, A, D), **TOL)
+    np.testing.assert_allclose(rewA.cpu().numpy(), Z[f"net{ni}_gA_reward"][:, :, 0], **TOL)
+    assert torch.equal(store[src_rows.long()], lat)  # sources untouched
+
+
+def test_tower_rejects_what_it_cannot_hold():
+    from muzero_amd import _hip
+    from muzero_amd.towers import TowerNetworks
+    g, f, A, shape = load_tower_nets(1)
+    nets = TowerNetworks(g, f)
+    lib = _hip.lib()
+    x = torch.zeros(8, nets.D, device="cuda")
+    # B not a multiple of the group
+    rc = lib.mz_tower_forward(C.byref(nets.tower_g), x.data_ptr(), nets.D, None, None, 0, None, x.data_ptr(), nets.D,
+                              None, 7, 3, None)
+    assert rc < 0 and b"multiple" in lib.mz_last_error()
+    # one value per channel: torch raises for it too (BatchNorm2d in train mode)
+    t1 = _hip.Tower.from_buffer_copy(nets.tower_g)
+    t1.H = t1.W = 1
+    rc = lib.mz_tower_forward(C.byref(t1), x.data_ptr(), nets.D, None, None, 0, None, x.data_ptr(), nets.D, None, 4, 1, None)
+    assert rc < 0 and b"more than 1 value" in lib.mz_last_error()
+
+
+@pytest.mark.parametrize("ni,ti", TREES)
+def test_lockstep_search_with_towers(ni, ti):
+    """G copies of the reference's recorded search plus perturbed roots, run in lock step."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    k = f"net{ni}_t{ti}_"
+    g, f, A, shape = load_tower_nets(ni)
+    D = int(np.prod(shape))
+    S, depth = int(Z[k + "S"]), int(Z[k + "depth"])
+    noise, disc, tp = float(Z[k + "noise_frac"]), float(Z[k + "discount"]), int(Z[k + "to_play"])
+    G = 6
+    rng = np.random.default_rng(ni * 10 + ti)
+    lat = np.repeat(Z[k + "root_latent"].reshape(1, D), G, 0).astype(np.float32)
+    lat[2:] += rng.standard_normal((G - 2, D)).astype(np.float32) * 0.5
+    eta = np.repeat(Z[k + "eta"][None], G, 0).astype(np.float32)
+    rand = np.repeat(Z[k + "rand"][None], G, 0).astype(np.int32)
+    rand[3:] = rng.integers(0, A, size=(G - 3, S + 1))
+    to_play = np.full(G, tp, np.int8)
+    nets = TowerNetworks(g, f)
+    mcts = BatchedMCTS(nets, G, S, depth, discount=disc, noise_frac=noise)
+    trace = {}
+    res = mcts.run(torch.from_numpy(lat).cuda(), torch.from_numpy(to_play).cuda(), torch.from_numpy(eta).cuda(),
+                   torch.from_numpy(rand).cuda(), trace=trace)
+    torch.cuda.synchronize()
+    pool = mcts.pool
+    # --- the GPU's own network outputs replayed through the tree oracle: bit-exact trees
+    prior_s = np.stack([p.cpu().numpy() for p in trace["prior"]], axis=1)
+    rollout = np.stack([r.cpu().numpy() for r in trace["rollout"]], axis=1)
+    reward_nodes = pool.reward.cpu().numpy()
+    root_prior = torch.empty(G, A, device="cuda")
+    nets.prediction(torch.from_numpy(lat).cuda(), G, softmax_times=1, policy=root_prior)
+    prior_stream = np.concatenate([root_prior.cpu().numpy()[:, None], prior_s], axis=1)
+    reward_stream = np.stack([reward_nodes[:, 1 + s * A:1 + (s + 1) * A] for s in range(S + 1)], axis=1)
+    ref = otree.run_batch(A, S, depth, to_play, prior_stream, reward_stream, rand, rollout, eta, noise, disc)
+    assert np.array_equal(np.stack([x.cpu().numpy() for x in trace["leaf"]], 1), ref["leaf"])
+    assert np.array_equal(pool.visit.cpu().numpy(), ref["visit"])
+    assert np.array_equal(pool.value_sum.cpu().numpy(), ref["value_sum"])
+    assert np.array_equal(res.value.cpu().numpy(), ref["utility"])
+    # --- trees 0 and 1 are the reference's recorded search: its network streams to 1e-5 wherever
+    # the same nodes were visited, the whole tree when no near-tie flipped
+    for gi in (0, 1):
+        np.testing.assert_allclose(prior_stream[gi, 0], Z[k + "prior_stream"][0], **TOL)
+        np.testing.assert_allclose(reward_stream[gi, 0], Z[k + "reward_stream"][0], **TOL)
+        if np.array_equal(ref["leaf"][gi], Z[k + "leaf"]) and np.array_equal(ref["child"][gi], Z[k + "child"]):
+            np.testing.assert_allclose(prior_stream[gi], Z[k + "prior_stream"], **TOL)
+            np.testing.assert_allclose(reward_stream[gi], Z[k + "reward_stream"], **TOL)
+            np.testing.assert_allclose(rollout[gi], Z[k + "sim_stream"], **TOL)
+            assert np.array_equal(ref["visit"][gi], Z[k + "visit"])
+            np.testing.assert_allclose(ref["value_sum"][gi], Z[k + "value_sum"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(res.policy[gi].cpu().numpy(), Z[k + "policy"], rtol=1e-5)
+    same_as_reference = sum(int(np.array_equal(ref["visit"][gi], Z[k + "visit"])) for gi in (0, 1))
+    assert same_as_reference == 2, "the reference's recorded tree was not reproduced"
