@@ -8,6 +8,7 @@
 // 6 x 6 latent): a 16-wide matrix tile would idle on 13 of 16 columns, so they run on the
 // vector ALUs with wave-uniform weights; the matrix cores take fc_merge and the heads.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "mz_common.h"
@@ -27,7 +28,7 @@ constexpr size_t kMaxLds = 160 * 1024;
 // Activations: global -> registers -> LDS chunk (double buffered, one barrier per chunk);
 // weights: packed tiles straight from global/L2 into registers, one k-tile ahead.
 template <int MTW, int NTW>
-__global__ void __launch_bounds__(kWT)
+__global__ void __launch_bounds__(kWT) __attribute__((amdgpu_waves_per_eu(2)))
 k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restrict__ x, long long ldx,
        const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B, int splitk,
        int chunks_per_split, float *__restrict__ ws, int vec_ok) {
@@ -50,10 +51,12 @@ k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restric
         if (r < B) src = x_rows ? (long long)x_rows[r] : (long long)r;
         xrow[i] = src >= 0 ? x + src * ldx : nullptr;
     }
-    auto fetch = [&](int c, f32x4 (&v)[XR]) {
+    constexpr int XH = XR / 2;  // the chunk is fetched in two halves to halve the registers it holds
+    auto fetch = [&](int c, int half, f32x4 (&v)[XH]) {
         const int k = c * kKC + sc;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) {
+        for (int ii = 0; ii < XH; ++ii) {
+            const int i = half * XH + ii;
             f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
             if (xrow[i] != nullptr) {
                 if (vec_ok) {
@@ -65,13 +68,13 @@ k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restric
                     if (k + 3 < L.K) t.w = xrow[i][k + 3];
                 }
             }
-            v[i] = t;
+            v[ii] = t;
         }
     };
-    auto stash = [&](int buf, const f32x4 (&v)[XR]) {
+    auto stash = [&](int buf, int half, const f32x4 (&v)[XH]) {
 #pragma unroll
-        for (int i = 0; i < XR; ++i)
-            *reinterpret_cast<f32x4 *>(&xs[(buf * TM + sr + 16 * i) * kLdX + sc]) = v[i];
+        for (int ii = 0; ii < XH; ++ii)
+            *reinterpret_cast<f32x4 *>(&xs[(buf * TM + sr + 16 * (half * XH + ii)) * kLdX + sc]) = v[ii];
     };
     const f32x4 *wp = reinterpret_cast<const f32x4 *>(blob + L.w_off) + lane;
     long long wbase[NTW];
@@ -88,38 +91,80 @@ k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restric
 #pragma unroll
         for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    auto aload = [&](int buf, int t, f32x4 (&a)[MTW]) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+            a[mt] = *reinterpret_cast<const f32x4 *>(
+                &xs[(buf * TM + (wm * MTW + mt) * 16 + m) * kLdX + t * 16 + kq * 4]);
+    };
+    // 4 k-steps of one k-tile; the k-step is the outer loop so that consecutive MFMAs never
+    // depend on each other
+    auto mm = [&](const f32x4 (&a)[MTW], const f32x4 (&w)[NTW]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], w[nt][j], acc[mt][nt], 0, 0, 0);
+    };
+
     if (c_lo < c_hi) {
-        f32x4 xv[XR], wc[NTW], wnx[NTW];
-        fetch(c_lo, xv);
-        wload(c_lo * 4, wc);
-        stash(0, xv);
+        // Weights stream from HBM: three k-tiles are in flight per wave (ring w0..w3) so that a
+        // request is about 200 MFMAs old when it is consumed; the scheduling barriers keep the
+        // requests ahead of the MFMAs they were written before.
+        f32x4 xv[XH], w0[NTW], w1[NTW], w2[NTW], w3[NTW], a0[MTW], a1[MTW];
+        const int kl = KT - 1;
+        fetch(c_lo, 0, xv);
+        wload(min(c_lo * 4, kl), w0);
+        wload(min(c_lo * 4 + 1, kl), w1);
+        wload(min(c_lo * 4 + 2, kl), w2);
+        stash(0, 0, xv);
+        fetch(c_lo, 1, xv);
+        stash(0, 1, xv);
         __syncthreads();
         for (int c = c_lo; c < c_hi; ++c) {
             const int buf = (c - c_lo) & 1;
             const bool more = c + 1 < c_hi;
-            if (more) fetch(c + 1, xv);
             const int kt0 = c * 4, nk = min(4, KT - kt0);
-            for (int t = 0; t < nk; ++t) {
-                const int kt = kt0 + t;
-                wload(min(kt + 1, KT - 1), wnx);  // next k-tile (the last one re-reads its own tile)
-                f32x4 a[MTW];
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-                    a[mt] = *reinterpret_cast<const f32x4 *>(
-                        &xs[(buf * TM + (wm * MTW + mt) * 16 + m) * kLdX + t * 16 + kq * 4]);
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, wc[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, wc[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, wc[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, wc[nt].w, acc[mt][nt], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) wc[nt] = wnx[nt];
+            if (nk == 4) {
+                // a full chunk is never the last of the layer's reduction, but it may be the
+                // last of this split: `more` guards the activation prefetch
+                if (more) fetch(c + 1, 0, xv);
+                aload(buf, 0, a0);
+                wload(min(kt0 + 3, kl), w3);
+                aload(buf, 1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a0, w0);
+                wload(min(kt0 + 4, kl), w0);
+                aload(buf, 2, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a1, w1);
+                if (more) {
+                    stash(buf ^ 1, 0, xv);
+                    fetch(c + 1, 1, xv);
+                }
+                wload(min(kt0 + 5, kl), w1);
+                aload(buf, 3, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a0, w2);
+                wload(min(kt0 + 6, kl), w2);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a1, w3);
+                if (more) stash(buf ^ 1, 1, xv);
+            } else {
+                // last, partial chunk of the reduction: its tiles are already in w0..w2
+                aload(buf, 0, a0);
+                mm(a0, w0);
+                if (nk > 1) {
+                    aload(buf, 1, a1);
+                    mm(a1, w1);
+                }
+                if (nk > 2) {
+                    aload(buf, 2, a0);
+                    mm(a0, w2);
+                }
             }
-            if (more) stash(buf ^ 1, xv);
             __syncthreads();
         }
     }
@@ -171,11 +216,31 @@ WideShape wide_shape(const mz_packed_layer &L, int B) {
     s.tiles_m = (B + s.tm - 1) / s.tm;
     s.tiles_n = (L.Np + s.tn - 1) / s.tn;
     const int nchunks = ((L.Kp >> 4) + 3) >> 2;
-    // two 4-wave workgroups fit a CU: aim at one round of 512 workgroups, at most 16 splits
-    const int tiles = s.tiles_m * s.tiles_n;
-    int k = std::max(1, 512 / std::max(1, tiles));
-    k = std::min(k, std::min(16, nchunks));
-    s.chunks_per_split = (nchunks + k - 1) / k;
+    // Split of the reduction dimension: a CU holds two 4-wave workgroups and works through
+    // ceil(workgroups / 256) of them; one workgroup costs its chunks plus a fixed part (first
+    // loads, partial-sum store) of about `kFixed` chunks.  Take the split with the least
+    // estimated time; ties go to the smaller split (less partial-sum traffic).
+    constexpr int kFixed = 4, kMaxSplit = 64;
+    const long long tiles = (long long)s.tiles_m * s.tiles_n;
+    long long best = -1;
+    int best_k = 1;
+    static const int forced = [] {
+        const char *e = getenv("MZ_WIDE_SPLITK");  // tuning aid
+        return e ? atoi(e) : 0;
+    }();
+    for (int k = 1; k <= std::min(kMaxSplit, nchunks); ++k) {
+        const int cps = (nchunks + k - 1) / k;
+        const int real_k = (nchunks + cps - 1) / cps;
+        if (real_k != k) continue;
+        const long long rounds = (tiles * k + 255) / 256;
+        const long long cost = rounds * (cps + kFixed);
+        if (best < 0 || cost < best) {
+            best = cost;
+            best_k = k;
+        }
+    }
+    if (forced > 0) best_k = std::min(forced, nchunks);
+    s.chunks_per_split = (nchunks + best_k - 1) / best_k;
     s.splitk = (nchunks + s.chunks_per_split - 1) / s.chunks_per_split;
     return s;
 }
@@ -196,10 +261,27 @@ struct TowerGeom {
     int cmax;            // widest block output
     int stage_c;         // input channels of the first block staged per pass
     int pw, ks;          // waves across positions / slices of the input channels (pw * ks = 4)
-    int off_a, off_b, off_c, off_red, off_stage;  // LDS offsets in floats
+    int vec_ok;          // rows may be read as 16-byte vectors
+    int off_a, off_b, off_c, off_red, off_stage, off_w;  // LDS offsets in floats
 };
 
 constexpr int COB = 4;  // output channels accumulated together per pass
+
+// Diagnostics build (-DMZ_TOWER_TIMELINE): workgroup 0 records the shader clock at the marked
+// points of its last launch; mz_debug_tower_stamps copies them out.
+#ifdef MZ_TOWER_TIMELINE
+__device__ unsigned long long g_tower_stamps[16];
+#define MZ_TT(i)                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tower_stamps[i] = __builtin_readcyclecounter();
+#else
+#define MZ_TT(i)
+#endif
+
+// Weights are read-only for the whole launch and indexed wave-uniformly: reading them through
+// the constant address space makes those reads scalar loads (one fetch per wave, no vector
+// memory instruction, no vector register).
+typedef __attribute__((address_space(4))) const float cst_f;
+__device__ __forceinline__ cst_f *as_constant(const float *p) { return (cst_f *)p; }
 
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -222,32 +304,30 @@ __device__ void bn_act(lds_f *buf, int C, int P, const float *__restrict__ gamma
             q += d * d;
         }
         const double invstd = 1.0 / sqrt(wave_sum(q) / P + (double)eps);
-        const float scale = (float)((double)gamma[c] * invstd);
-        const float shift = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+        const double ga = (double)as_constant(gamma)[c], be = (double)as_constant(beta)[c];
+        const float scale = (float)(ga * invstd);
+        const float shift = (float)(be - mean * ga * invstd);
         for (int p = lane; p < P; p += 64) v[p] = activate(v[p] * scale + shift, act);
     }
 }
 
-// Adds, for output channels co0 .. co0+COB-1 at position p, the k x k convolution (and, if
-// DOWN, the 1x1 convolution) over the input channels [c_lo, c_hi) held in LDS as
-// src[(ci - c_base) * P + position].  KF = k when known at compile time, 0 otherwise.
+// Adds, for COB output channels at position p, the k x k convolution (and, if DOWN, the 1x1
+// convolution) over the input channels [c_lo, c_hi) held in LDS as src[(ci - c_base) * P +
+// position].  The weights of those channels were staged by load_weights: wk[(ci - c_base)][tap]
+// and wd[(ci - c_base)] are vectors over the COB output channels, read as wave-wide broadcasts.
+// KF = k when known at compile time, 0 otherwise.
 template <bool DOWN, int KF>
-__device__ __forceinline__ void conv_accumulate(const lds_f *src, int c_base, int c_lo, int c_hi, int Cin, int Cout,
-                                                const float *__restrict__ w, const float *__restrict__ wd, int co0,
-                                                int k_rt, int H, int W, int P, int p, bool live, float (&acc)[COB],
-                                                float (&accd)[COB]) {
+__device__ __forceinline__ void conv_accumulate(const lds_f *src, int c_base, int c_lo, int c_hi, const lds_f *wk,
+                                                const lds_f *wd, int k_rt, int H, int W, int P, int p, bool live,
+                                                float (&acc)[COB], float (&accd)[COB]) {
+    static_assert(COB == 4, "weights are read as 4-vectors");
     const int k = KF ? KF : k_rt;
     const int HW = H * W, pad = (k - 1) >> 1, kk = k * k;
     const int row = p / HW, s = p - row * HW, py = s / W, px = s - py * W;
-    long long wo[COB], wdo[COB];
-#pragma unroll
-    for (int o = 0; o < COB; ++o) {
-        const int co = min(co0 + o, Cout - 1);  // surplus channels repeat the last one and are dropped
-        wo[o] = (long long)co * Cin * kk;
-        wdo[o] = (long long)co * Cin;
-    }
+#pragma unroll 4
     for (int ci = c_lo; ci < c_hi; ++ci) {
         const lds_f *plane = src + (ci - c_base) * P + row * HW;
+        const lds_f4 *w4 = reinterpret_cast<const lds_f4 *>(wk + (ci - c_base) * kk * COB);
 #pragma unroll
         for (int ky = 0; ky < k; ++ky) {
             const int yy = py + ky - pad;
@@ -256,26 +336,31 @@ __device__ __forceinline__ void conv_accumulate(const lds_f *src, int c_base, in
                 const int xx = px + kx - pad;
                 const bool in = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
                 const float v = in ? plane[yy * W + xx] : 0.0f;
-#pragma unroll
-                for (int o = 0; o < COB; ++o) acc[o] = fmaf(w[wo[o] + ci * kk + ky * k + kx], v, acc[o]);
+                const f32x4 ww = w4[ky * k + kx];
+                acc[0] = fmaf(ww.x, v, acc[0]);
+                acc[1] = fmaf(ww.y, v, acc[1]);
+                acc[2] = fmaf(ww.z, v, acc[2]);
+                acc[3] = fmaf(ww.w, v, acc[3]);
             }
         }
         if (DOWN) {
             const float v = live ? plane[s] : 0.0f;
-#pragma unroll
-            for (int o = 0; o < COB; ++o) accd[o] = fmaf(wd[wdo[o] + ci], v, accd[o]);
+            const f32x4 ww = *reinterpret_cast<const lds_f4 *>(wd + (ci - c_base) * COB);
+            accd[0] = fmaf(ww.x, v, accd[0]);
+            accd[1] = fmaf(ww.y, v, accd[1]);
+            accd[2] = fmaf(ww.z, v, accd[2]);
+            accd[3] = fmaf(ww.w, v, accd[3]);
         }
     }
 }
 
 template <bool DOWN>
-__device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int c_lo, int c_hi, int Cin, int Cout,
-                                              const float *__restrict__ w, const float *__restrict__ wd, int co0,
-                                              int k, int H, int W, int P, int p, bool live, float (&acc)[COB],
-                                              float (&accd)[COB]) {
-    if (k == 3) conv_accumulate<DOWN, 3>(src, c_base, c_lo, c_hi, Cin, Cout, w, wd, co0, k, H, W, P, p, live, acc, accd);
-    else if (k == 1) conv_accumulate<DOWN, 1>(src, c_base, c_lo, c_hi, Cin, Cout, w, wd, co0, k, H, W, P, p, live, acc, accd);
-    else conv_accumulate<DOWN, 0>(src, c_base, c_lo, c_hi, Cin, Cout, w, wd, co0, k, H, W, P, p, live, acc, accd);
+__device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int c_lo, int c_hi, const lds_f *wk,
+                                              const lds_f *wd, int k, int H, int W, int P, int p, bool live,
+                                              float (&acc)[COB], float (&accd)[COB]) {
+    if (k == 3) conv_accumulate<DOWN, 3>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
+    else if (k == 1) conv_accumulate<DOWN, 1>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
+    else conv_accumulate<DOWN, 0>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
 }
 
 // One workgroup per group of rows (one network call of the reference).  LDS holds three
@@ -288,6 +373,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     extern __shared__ __align__(16) float smem[];
     lds_f *S = to_lds(smem);
     lds_f *cur = S + G.off_a, *mid = S + G.off_b, *aux = S + G.off_c, *red = S + G.off_red, *stage = S + G.off_stage;
+    lds_f *wst = S + G.off_w;  // staged convolution weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = G.HW, P = G.P;
@@ -304,20 +390,55 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         const int sel = row_sel ? row_sel[r0 + r] : r;
         return row_add + (long long)sel * ld_add;
     };
-    // tower input (merge split applied) for channels [cb, cb+cn) -> dst[c * P + p]
+    // tower input (merge split applied) for channels [cb, cb+cn) -> dst[c * P + p].  A row's
+    // channels are contiguous in memory (cn * HW floats), so the copy is coalesced.
     auto load_input = [&](lds_f *dst, int cb, int cn) {
-        for (int p = tid; p < P; p += kWT) {
-            const int r = p / HW, s = p - r * HW;
+        const int n = cn * HW;
+        for (int r = 0; r < group; ++r) {
             const float *xr = src_row(r), *ar = add_row(r);
-            for (int c = 0; c < cn; ++c) {
-                float v = xr ? xr[(cb + c) * HW + s] : 0.0f;
-                if (ar) {
-                    v += ar[(cb + c) * HW + s];
-                    v = v > 0.0f ? v : 0.0f;
+            if (xr) xr += cb * HW;
+            if (ar) ar += cb * HW;
+            lds_f *d = dst + r * HW;
+            if (G.vec_ok) {
+                for (int j = tid * 4; j < n; j += kWT * 4) {
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (xr) v = *reinterpret_cast<const f32x4 *>(xr + j);
+                    if (ar) {
+                        const f32x4 a = *reinterpret_cast<const f32x4 *>(ar + j);
+                        v.x = fmaxf(v.x + a.x, 0.0f);
+                        v.y = fmaxf(v.y + a.y, 0.0f);
+                        v.z = fmaxf(v.z + a.z, 0.0f);
+                        v.w = fmaxf(v.w + a.w, 0.0f);
+                    }
+                    const int c = j / HW, s = j - c * HW;  // HW % 4 == 0: the four share a channel
+                    *reinterpret_cast<lds_f4 *>(d + c * P + s) = v;
                 }
-                dst[c * P + p] = v;
+            } else {
+                for (int j = tid; j < n; j += kWT) {
+                    float v = xr ? xr[j] : 0.0f;
+                    if (ar) v = fmaxf(v + ar[j], 0.0f);
+                    const int c = j / HW, s = j - c * HW;
+                    d[c * P + s] = v;
+                }
             }
         }
+    };
+    // convolution weights of output channels co0 .. co0+COB-1 (surplus channels repeat the last
+    // one and are dropped later) and input channels [cb, cb+cn): wst[(c * kk + tap) * COB + o],
+    // followed by the 1x1 skip weights [c * COB + o].  Returns where the latter start.
+    auto load_weights = [&](const float *w_g, const float *wd_g, int co0, int Cout, int Cin, int cb, int cn,
+                            int kk) -> lds_f * {
+        lds_f *wdst = wst + cn * kk * COB;
+        for (int o = 0; o < COB; ++o) {
+            const int co = min(co0 + o, Cout - 1);
+            const float *src = w_g + ((long long)co * Cin + cb) * kk;
+            for (int i = tid; i < cn * kk; i += kWT) wst[i * COB + o] = src[i];
+            if (wd_g) {
+                const float *sd = wd_g + (long long)co * Cin + cb;
+                for (int i = tid; i < cn; i += kWT) wdst[i * COB + o] = sd[i];
+            }
+        }
+        return wdst;
     };
     // sums the channel slices of acc in a fixed order (slice 0 ends up with the total)
     auto reduce_slices = [&](float (&acc)[COB], int which, int slot, bool live) {
@@ -332,6 +453,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             }
     };
 
+    MZ_TT(0)
     for (int b = 0; b < T.n_blocks; ++b) {
         const mz_resblock &R = T.block[b];
         const int Cin = R.in_channels, Cout = R.out_channels, k = R.kernel_size;
@@ -348,19 +470,26 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                     for (int cb = 0; cb < Cin; cb += G.stage_c) {
                         const int cn = min(G.stage_c, Cin - cb);
                         __syncthreads();  // the previous pass has been consumed
+                        MZ_TT(1)
                         load_input(stage, cb, cn);
+                        const lds_f *wdn = load_weights(R.conv1_w, R.down_w, co0, Cout, Cin, cb, cn, k * k);
                         __syncthreads();
+                        MZ_TT(2)
                         const int per = (cn + G.ks - 1) / G.ks;
                         const int lo = cb + min(cn, ksi * per), hi = cb + min(cn, (ksi + 1) * per);
-                        if (down) conv_dispatch<true>(stage, cb, lo, hi, Cin, Cout, R.conv1_w, R.down_w, co0, k, G.H, G.W, P, pc, live, acc, accd);
-                        else conv_dispatch<false>(stage, cb, lo, hi, Cin, Cout, R.conv1_w, nullptr, co0, k, G.H, G.W, P, pc, live, acc, accd);
+                        if (down) conv_dispatch<true>(stage, cb, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
+                        else conv_dispatch<false>(stage, cb, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
                     }
                 } else {
+                    __syncthreads();
+                    const lds_f *wdn = load_weights(R.conv1_w, R.down_w, co0, Cout, Cin, 0, Cin, k * k);
+                    __syncthreads();
                     const int per = (Cin + G.ks - 1) / G.ks;
                     const int lo = min(Cin, ksi * per), hi = min(Cin, (ksi + 1) * per);
-                    if (down) conv_dispatch<true>(cur, 0, lo, hi, Cin, Cout, R.conv1_w, R.down_w, co0, k, G.H, G.W, P, pc, live, acc, accd);
-                    else conv_dispatch<false>(cur, 0, lo, hi, Cin, Cout, R.conv1_w, nullptr, co0, k, G.H, G.W, P, pc, live, acc, accd);
+                    if (down) conv_dispatch<true>(cur, 0, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
+                    else conv_dispatch<false>(cur, 0, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
                 }
+                MZ_TT(3)
                 if (G.ks > 1) {
                     __syncthreads();  // earlier partials have been read
                     reduce_slices(acc, 0, slot, live);
@@ -375,9 +504,11 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             }
         }
         __syncthreads();
+        MZ_TT(4)
         bn_act(mid, Cout, P, R.bn1_w, R.bn1_b, R.eps1, R.activation);
         if (down) bn_act(aux, Cout, P, R.dbn_w, R.dbn_b, R.epsd, MZ_ACT_NONE);
         __syncthreads();
+        MZ_TT(5)
         // ---- conv2: mid -> dst.  `cur` is free unless it still holds the identity skip.
         lds_f *dst = (!from_global && !down) ? aux : cur;
         for (int co0 = 0; co0 < Cout; co0 += COB) {
@@ -387,7 +518,10 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 float acc[COB] = {0.0f, 0.0f, 0.0f, 0.0f}, accd[COB] = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int per = (Cout + G.ks - 1) / G.ks;
                 const int lo = min(Cout, ksi * per), hi = min(Cout, (ksi + 1) * per);
-                conv_dispatch<false>(mid, 0, lo, hi, Cout, Cout, R.conv2_w, nullptr, co0, k, G.H, G.W, P, live ? p : 0, live, acc, accd);
+                __syncthreads();
+                load_weights(R.conv2_w, nullptr, co0, Cout, Cout, 0, Cout, k * k);
+                __syncthreads();
+                conv_dispatch<false>(mid, 0, lo, hi, wst, wst, k, G.H, G.W, P, live ? p : 0, live, acc, accd);
                 if (G.ks > 1) {
                     __syncthreads();
                     reduce_slices(acc, 0, slot, live);
@@ -398,8 +532,10 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             }
         }
         __syncthreads();
+        MZ_TT(6)
         bn_act(dst, Cout, P, R.bn2_w, R.bn2_b, R.eps2, MZ_ACT_NONE);
         __syncthreads();
+        MZ_TT(7)
         // ---- skip connection + activation -> cur (input of the next block)
         if (from_global && !down) {
             // identity skip from the tower input: stage it (Cin == Cout <= cmax fits `mid`, now free)
@@ -411,33 +547,60 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         __syncthreads();
     }
 
-    // ---- res_final (1x1 convolution with bias back to C channels) and the store
+    // ---- res_final (1x1 convolution with bias back to C channels) and the store: a wave per
+    // output channel (wave-uniform weights), lanes along the positions
+    MZ_TT(8)
     const int Cl = T.n_blocks ? T.block[T.n_blocks - 1].out_channels : G.C;
-    for (int p = tid; p < P; p += kWT) {
-        const int r = p / HW, s = p - r * HW;
+    const int wv = tid >> 6;
+    // res_final's weights and bias, one row of `fs` floats per output channel (bias last)
+    const int fs = Cl <= 3 ? 4 : Cl + 1;
+    lds_f *wfin = stage;
+    if (T.final_w != nullptr) {
+        for (int i = tid; i < G.C * fs; i += kWT) {
+            const int c = i / fs, j = i - c * fs;
+            float v = 0.0f;
+            if (j < Cl) v = T.final_w[c * Cl + j];
+            else if (j == fs - 1 && T.final_b) v = T.final_b[c];
+            wfin[i] = v;
+        }
+        __syncthreads();
+    }
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        const int p = p0 + lane;
+        const bool live = p < P;
+        const int pc = live ? p : 0;
+        const int r = pc / HW, s = pc - r * HW;
         const long long dr = y_rows ? (long long)y_rows[r0 + r] : (long long)(r0 + r);
-        if (dr < 0) continue;
+        if (!live || dr < 0) continue;
         float *yr = y + dr * ldy + s;
         if (T.final_w != nullptr) {
-            for (int c = 0; c < G.C; ++c) {
-                float v = T.final_b ? T.final_b[c] : 0.0f;
-                for (int ci = 0; ci < Cl; ++ci) v = fmaf(T.final_w[c * Cl + ci], cur[ci * P + p], v);
-                yr[c * HW] = v;
+            if (Cl <= 3) {
+                // the shipped towers end in 3 channels: the position's values stay in registers
+                const float i0 = cur[p], i1 = Cl > 1 ? cur[P + p] : 0.0f, i2 = Cl > 2 ? cur[2 * P + p] : 0.0f;
+#pragma unroll 4
+                for (int c = wv; c < G.C; c += kWT / 64) {
+                    const f32x4 q = *reinterpret_cast<const lds_f4 *>(wfin + c * 4);
+                    yr[c * HW] = fmaf(q.z, i2, fmaf(q.y, i1, fmaf(q.x, i0, q.w)));
+                }
+            } else {
+                for (int c = wv; c < G.C; c += kWT / 64) {
+                    float v = wfin[c * fs + fs - 1];
+                    for (int ci = 0; ci < Cl; ++ci) v = fmaf(wfin[c * fs + ci], cur[ci * P + p], v);
+                    yr[c * HW] = v;
+                }
             }
         } else if (T.n_blocks) {
-            for (int c = 0; c < G.C; ++c) yr[c * HW] = cur[c * P + p];
+            for (int c = wv; c < G.C; c += kWT / 64) yr[c * HW] = cur[c * P + p];
         } else {
             const float *xr = src_row(r), *ar = add_row(r);
-            for (int c = 0; c < G.C; ++c) {
+            for (int c = wv; c < G.C; c += kWT / 64) {
                 float v = xr ? xr[c * HW + s] : 0.0f;
-                if (ar) {
-                    v += ar[c * HW + s];
-                    v = v > 0.0f ? v : 0.0f;
-                }
+                if (ar) v = fmaxf(v + ar[c * HW + s], 0.0f);
                 yr[c * HW] = v;
             }
         }
     }
+    MZ_TT(9)
 }
 
 int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes) {
@@ -475,11 +638,25 @@ int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes
     const int slots = (g->P + 63) / 64;
     g->pw = slots >= 3 ? 4 : slots;  // 1, 2 or 4 waves across the positions
     g->ks = 4 / g->pw;
-    const long long buf = (long long)std::max(1, g->cmax) * g->P;
+    auto up4 = [](long long v) { return (v + 3) & ~3LL; };
+    int kkmax = 1;
+    for (int b = 0; b < T->n_blocks; ++b) kkmax = std::max(kkmax, T->block[b].kernel_size * T->block[b].kernel_size);
+    const long long wpc = (long long)(kkmax + 1) * COB;  // staged weight floats per input channel
+    const long long buf = up4((long long)std::max(1, g->cmax) * g->P);
     const long long red = g->ks > 1 ? (long long)g->ks * 2 * COB * g->pw * 64 : 0;
     const long long fixed = 3 * buf + red;
-    const long long room = (long long)(kMaxLds / sizeof(float)) - fixed;
-    if (room < g->P)
+    const long long lds_floats = (long long)(kMaxLds / sizeof(float));
+    const int cl = T->n_blocks ? T->block[T->n_blocks - 1].out_channels : T->C;
+    const long long fin = T->final_w ? (long long)T->C * (cl <= 3 ? 4 : cl + 1) : 0;
+    // the first block's input is staged `stage_c` channels at a time next to their weights
+    int sc = 0;
+    for (int c = T->C; c >= 1; --c)
+        if (fixed + up4((long long)c * g->P) + (long long)std::max(c, g->cmax) * wpc <= lds_floats) {
+            sc = c;
+            break;
+        }
+    if (!T->n_blocks) sc = 1;
+    if (sc == 0 || fixed + fin > lds_floats)
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: %d channels x %d positions per call exceed the LDS-resident "
                         "tower", g->cmax, g->P);
     g->off_a = 0;
@@ -487,8 +664,10 @@ int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes
     g->off_c = (int)(2 * buf);
     g->off_red = (int)(3 * buf);
     g->off_stage = (int)fixed;
-    g->stage_c = (int)std::min<long long>(T->C, room / g->P);
-    *lds_bytes = (size_t)(fixed + (T->n_blocks ? (long long)g->stage_c * g->P : 0)) * sizeof(float);
+    g->stage_c = sc;
+    g->off_w = (int)(fixed + up4((long long)sc * g->P));
+    const long long stage_floats = T->n_blocks ? up4((long long)sc * g->P) + (long long)std::max(sc, g->cmax) * wpc : 0;
+    *lds_bytes = (size_t)(fixed + std::max(stage_floats, fin)) * sizeof(float);
     return MZ_OK;
 }
 
@@ -581,11 +760,20 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: NULL argument, negative B or a row stride below C*H*W=%d", D);
     if (B % group) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: B=%d is not a multiple of group=%d", B, group);
     if (B == 0) return MZ_OK;
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    g.vec_ok = g.HW % 4 == 0 && ldx % 4 == 0 && aligned(x) && (!row_add || (ld_add % 4 == 0 && aligned(row_add)));
     MZ_TRY(allow_lds(k_tower, lds, "k_tower"));
     hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kWT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
                        x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, group);
     return mz::check_launch("k_tower");
 }
+
+#ifdef MZ_TOWER_TIMELINE
+int mz_debug_tower_stamps(unsigned long long *h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_tower_stamps), sizeof(unsigned long long) * 16) == hipSuccess
+               ? MZ_OK : MZ_ERR_HIP;
+}
+#endif
 
 int mz_policy_post(const float *policy_in, int32_t B, int32_t A, int32_t softmax_times, float *policy_out,
                    int32_t *argmax, void *stream) {

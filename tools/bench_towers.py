@@ -1,0 +1,127 @@
+"""Lock-step search with residual-tower networks at the shipped latent shape
+(src/config/config_car_racing.yaml:57-165: latent [256, 6, 6], one ResBlock 256 -> 3 in g and f,
+reward [128], value [256, 128], policy [256, 256]; 5 actions, 50 simulations per move).
+
+    python tools/bench_towers.py [--games 256] [--sims 50] [--steps 3] [--latent 256 6 6]
+
+Prints one JSON line: simulations/s of the whole search, and for the dominant kernel (the
+fc_merge product, fp32 MFMA) its achieved TFLOP/s measured with HIP events around the call.
+Synthetic inputs, random-init weights (torch default init, seed 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def build_nets(shape, A):
+    from muzero_amd.config import DenseLayerConfig, DynamicsNetworkConfig, PredictionNetworkConfig, ResBlockConfig
+    from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork
+    d = lambda n: DenseLayerConfig(out_features=n, activation="relu")  # noqa: E731
+    rb = lambda: ResBlockConfig(out_channels=3, kernel_size=3, stride=1, padding=1, activation="relu",  # noqa: E731
+                                pool_kernel_size=1, pool_stride=1)
+    torch.manual_seed(0)
+    g = DynamicsNetwork(shape, A, DynamicsNetworkConfig(res_net=[rb()], reward_net=[d(128)]))
+    f = PredictionNetwork(shape, A, PredictionNetworkConfig(res_net=[rb()], value_net=[d(256), d(128)],
+                                                            policy_net=[d(256), d(256)]))
+    return g, f
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=256)
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--actions", type=int, default=5)
+    ap.add_argument("--latent", type=int, nargs=3, default=[256, 6, 6])
+    args = ap.parse_args()
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    shape, A, G, S = tuple(args.latent), args.actions, args.games, args.sims
+    D = shape[0] * shape[1] * shape[2]
+    t0 = time.time()
+    g, f = build_nets(shape, A)
+    nets = TowerNetworks(g, f)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    lat = torch.randn(G, D, device="cuda", generator=gen)
+    eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((G,)).float().cuda()
+    rand = torch.randint(0, A, (G, S + 1), device="cuda", generator=gen, dtype=torch.int32)
+    to_play = torch.zeros(G, dtype=torch.int8, device="cuda")
+    for _ in range(args.warmup):
+        res = mcts.run(lat, to_play, eta, rand)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        res = mcts.run(lat, to_play, eta, rand)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / args.steps
+    assert int(res.visits.sum()) == G * S
+    # the dominant kernel alone: fc_merge's latent half for G rows (one call per expansion and
+    # one per rollout step, i.e. 2 per simulation)
+    base = torch.empty(G, D, device="cuda")
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_rep = 20
+    nets._wide(nets.merge, lat, D, None, base, G)
+    ev0.record()
+    for _ in range(n_rep):
+        nets._wide(nets.merge, lat, D, None, base, G)
+    ev1.record()
+    torch.cuda.synchronize()
+    merge_ms = ev0.elapsed_time(ev1) / n_rep
+    merge_flop = 2.0 * G * D * D
+    # whole g / f stages
+    def timed(fn):
+        fn()
+        ev0.record()
+        for _ in range(5):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / 5
+    rows = mcts.tree_base.clone()
+    pol = torch.empty(G, A, device="cuda")
+    val = torch.empty(G, device="cuda")
+    arg = torch.empty(G, dtype=torch.int32, device="cuda")
+    rew = torch.empty(G, A, device="cuda")
+    nxt = torch.empty(G * A, D, device="cuda")
+    f_ms = timed(lambda: nets.prediction(mcts.pool.latent, G, rows=rows, softmax_times=1, policy=pol))
+    gA_ms = timed(lambda: nets.dynamics(mcts.pool.latent, G * A, rows=rows.repeat_interleave(A), action=None,
+                                        next_latent=nxt, reward=rew))
+    g1_ms = timed(lambda: nets.dynamics(mcts.pool.latent, G, rows=rows, action=arg.zero_(), next_latent=nxt[:G],
+                                        reward=val))
+    # reference arithmetic per simulation: 3 f calls and A+1 g calls, each g with the full 2D x D fc_merge
+    F_heads = 2.0 * (D * 256 + 256 * 128 + 128 + D * 256 + 256 * 256 + 256 * A)
+    F_tower = 2.0 * 36 * (shape[0] * 9 * 3 + 3 * 9 * 3 + shape[0] * 3 + 3 * shape[0])
+    F_f = F_tower + F_heads
+    F_g = 2.0 * 2 * D * D + F_tower + 2.0 * (D * 128 + 128)
+    print(json.dumps({
+        "metric": "mcts_simulations_per_sec", "value": G * S / dt, "unit": "sims/s", "n_gpus": 1,
+        "ms_per_step": dt * 1e3, "steps": args.steps, "dtype": "f32+f64", "data": "synthetic",
+        "config": {"workload": f"{G} trees x {S} simulations, lock-step search, residual-tower g/f, latent "
+                               f"{list(shape)}, {A} actions"},
+        "reference_flop_per_sim": 3 * F_f + (A + 1) * F_g,
+        "algorithmic_tflops": (3 * F_f + (A + 1) * F_g) * G * S / dt / 1e12,
+        "stage_ms": {"f(G rows)": f_ms, "g expansion (G*A rows)": gA_ms, "g step (G rows)": g1_ms},
+        "roofline": {"bound": "mfma", "kernel": "k_wide<4,4> [fc_merge latent half]",
+                     "achieved": merge_flop / merge_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": merge_flop / merge_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": merge_ms * 1e3,
+                     "flop_per_launch": merge_flop, "traffic": None},
+        "build_s": t_build,
+    }))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""Times mz_tower_forward alone on the shipped tower shape and on reduced variants (which part
+of the kernel the time goes to).   python tools/prof_tower.py [games]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from muzero_amd import _hip  # noqa: E402
+from muzero_amd._hip import ptr  # noqa: E402
+from tools.bench_towers import build_nets  # noqa: E402
+from muzero_amd.towers import TowerNetworks  # noqa: E402
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+A = 5
+g, f = build_nets((256, 6, 6), A)
+nets = TowerNetworks(g, f)
+D = nets.D
+lib = _hip.lib()
+st = torch.cuda.current_stream().cuda_stream
+x = torch.randn(G, D, device="cuda")
+y = torch.empty(G * A, D, device="cuda")
+gidx = (torch.arange(G * A, dtype=torch.int32, device="cuda") // A).contiguous()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def timed(name, tower, B, group, x_rows=None, row_add=None):
+    def call():
+        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(x_rows), ptr(row_add), D, None, ptr(y), D, None,
+                                        B, group, st), name)
+    call()
+    ev0.record()
+    for _ in range(10):
+        call()
+    ev1.record()
+    torch.cuda.synchronize()
+    print(f"{name:55s} {ev0.elapsed_time(ev1) / 10 * 1e3:8.1f} us")
+
+
+timed("f tower, group 1", nets.tower_f, G, 1)
+timed("g tower, group 1, merge table", nets.tower_g, G, 1, row_add=nets.table)
+timed("g tower, group A (expansion), merge table", nets.tower_g, G * A, A, x_rows=gidx, row_add=nets.table)
+copy = _hip.Tower.from_buffer_copy(nets.tower_f)
+copy.n_blocks = 0
+copy.final_w = copy.final_b = None
+timed("no blocks, no res_final (copy only), group 1", copy, G, 1)
+timed("no blocks, no res_final (copy only), group A", copy, G * A, A, x_rows=gidx)
+
+if hasattr(lib, "mz_debug_tower_stamps"):  # diagnostics build only
+    import numpy as np
+    names = ["start", "stage: begin", "stage: loaded", "conv1 done", "before bn1", "after bn1/skip bn", "conv2 done",
+             "after bn2", "before res_final", "end"]
+    for label, tower, B, group, rows, add in (("f tower", nets.tower_f, G, 1, None, None),
+                                               ("g expansion", nets.tower_g, G * A, A, gidx, nets.table)):
+        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(rows), ptr(add), D, None, ptr(y), D, None, B,
+                                        group, st), label)
+        torch.cuda.synchronize()
+        h = np.zeros(16, np.uint64)
+        lib.mz_debug_tower_stamps(h.ctypes.data_as(C.c_void_p))
+        t = h[:10].astype(np.int64)
+        print(label, "(shader-clock cycles since start, workgroup 0; staging stamps are of the last pass)")
+        for i in range(1, 10):
+            print(f"   {names[i]:22s} {int(t[i] - t[0]):9d}")
