@@ -6,7 +6,8 @@
 //   * policy post-processing.
 // The convolutions of the shipped g/f towers are skinny (256 -> 3 -> 3 -> 256 channels on a
 // 6 x 6 latent): a 16-wide matrix tile would idle on 13 of 16 columns, so they run on the
-// vector ALUs with wave-uniform weights; the matrix cores take fc_merge and the heads.
+// 4 x 4 x 1 matrix instruction (16 independent 4-position x 4-channel blocks per wave); the
+// 16 x 16 tiles take fc_merge and the heads.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -18,7 +19,7 @@ using namespace mzd;
 
 namespace {
 
-constexpr int kWT = 256;       // threads per workgroup of every kernel in this file
+constexpr int kWT = 256;       // threads per workgroup (the tower kernel has its own count)
 constexpr int kKC = 64;        // floats of the reduction dimension per LDS chunk (4 k-tiles)
 constexpr int kLdX = kKC + 4;  // LDS row stride of a chunk: 16 rows x b128 reads hit 64 distinct banks
 constexpr size_t kMaxLds = 160 * 1024;
@@ -256,11 +257,14 @@ int allow_lds(K kernel, size_t bytes, const char *what) {
 }
 
 // ------------------------------------------------------------------ residual tower
+constexpr int kTT = 512;       // threads of the tower kernel
+constexpr int kTW = kTT / 64;  // its waves
+
 struct TowerGeom {
     int C, H, W, HW, P;  // P = group * HW positions normalised together
     int cmax;            // widest block output
     int stage_c;         // input channels of the first block staged per pass
-    int pw, ks;          // waves across positions / slices of the input channels (pw * ks = 4)
+    int pw, ks;          // waves across positions / slices of the input channels (pw * ks = kTW)
     int vec_ok;          // rows may be read as 16-byte vectors
     int off_a, off_b, off_c, off_red, off_stage, off_w;  // LDS offsets in floats
 };
@@ -293,7 +297,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ void bn_act(lds_f *buf, int C, int P, const float *__restrict__ gamma, const float *__restrict__ beta,
                        float eps, int act) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = wave; c < C; c += kWT / 64) {
+    for (int c = wave; c < C; c += kTW) {
         lds_f *v = buf + c * P;
         double s = 0.0;
         for (int p = lane; p < P; p += 64) s += (double)v[p];
@@ -311,45 +315,76 @@ __device__ void bn_act(lds_f *buf, int C, int P, const float *__restrict__ gamma
     }
 }
 
-// Adds, for COB output channels at position p, the k x k convolution (and, if DOWN, the 1x1
-// convolution) over the input channels [c_lo, c_hi) held in LDS as src[(ci - c_base) * P +
-// position].  The weights of those channels were staged by load_weights: wk[(ci - c_base)][tap]
-// and wd[(ci - c_base)] are vectors over the COB output channels, read as wave-wide broadcasts.
-// KF = k when known at compile time, 0 otherwise.
+// Adds the k x k convolution (and, if DOWN, the 1x1 convolution) over the input channels
+// [c_lo, c_hi), held in LDS as src[(ci - c_base) * P + position], for 64 positions x COB output
+// channels per wave on v_mfma_f32_4x4x1_16b_f32: the instruction performs 16 independent 4 x 4
+// rank-1 updates, block b = lanes 4b..4b+3.  Lane 4b+i supplies the input value of position
+// (first position of the wave) + 4b+i, lane 4b+j the weight of output channel j (the same for
+// every block), and element i of lane 4b+j's accumulator is the sum for position 4b+i, channel j.
+// So a (channel, tap) step costs each lane one 4-byte read of its input value, one 4-byte read
+// of a weight (4 distinct addresses per wave) and one matrix instruction -- no 16-wide tile to
+// pad the 3 output channels of the shipped towers into.
+// `p` = this lane's position (valid or not: `live`).  The staged weights wk[(ci - c_base)][tap][COB]
+// and wd[(ci - c_base)][COB] come from load_weights.  KF = k when known at compile time.
 template <bool DOWN, int KF>
 __device__ __forceinline__ void conv_accumulate(const lds_f *src, int c_base, int c_lo, int c_hi, const lds_f *wk,
                                                 const lds_f *wd, int k_rt, int H, int W, int P, int p, bool live,
-                                                float (&acc)[COB], float (&accd)[COB]) {
-    static_assert(COB == 4, "weights are read as 4-vectors");
+                                                f32x4 &acc, f32x4 &accd) {
+    static_assert(COB == 4, "one 4 x 4 block column per output channel");
     const int k = KF ? KF : k_rt;
     const int HW = H * W, pad = (k - 1) >> 1, kk = k * k;
     const int row = p / HW, s = p - row * HW, py = s / W, px = s - py * W;
-#pragma unroll 4
+    const int j = threadIdx.x & 3;
+    if (KF) {
+        // tap offsets and validity once per call; every read below is unconditional (a tap outside
+        // the image reads the centre and is zeroed by a select), so the loop body is straight-line
+        // code the scheduler can overlap
+        constexpr int KK = KF * KF;
+        int off[KK ? KK : 1];
+        bool ok[KK ? KK : 1];
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            const int yy = py + t / KF - pad, xx = px + t % KF - pad;
+            ok[t] = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            off[t] = ok[t] ? yy * W + xx : s;
+        }
+#pragma unroll 2
+        for (int ci = c_lo; ci < c_hi; ++ci) {
+            const lds_f *plane = src + (ci - c_base) * P + row * HW;
+            const lds_f *wrow = wk + (ci - c_base) * KK * COB + j;
+            float v[KK ? KK : 1], w[KK ? KK : 1];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                v[t] = plane[off[t]];
+                w[t] = wrow[t * COB];
+            }
+            float vc = 0.0f, wc = 0.0f;
+            if (DOWN) {
+                vc = plane[s];
+                wc = wd[(ci - c_base) * COB + j];
+            }
+#pragma unroll
+            for (int t = 0; t < KK; ++t)
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(ok[t] ? v[t] : 0.0f, w[t], acc, 0, 0, 0);
+            if (DOWN) accd = __builtin_amdgcn_mfma_f32_4x4x1f32(live ? vc : 0.0f, wc, accd, 0, 0, 0);
+        }
+        return;
+    }
     for (int ci = c_lo; ci < c_hi; ++ci) {
         const lds_f *plane = src + (ci - c_base) * P + row * HW;
-        const lds_f4 *w4 = reinterpret_cast<const lds_f4 *>(wk + (ci - c_base) * kk * COB);
-#pragma unroll
+        const lds_f *wrow = wk + (ci - c_base) * kk * COB + j;
         for (int ky = 0; ky < k; ++ky) {
             const int yy = py + ky - pad;
-#pragma unroll
             for (int kx = 0; kx < k; ++kx) {
                 const int xx = px + kx - pad;
                 const bool in = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
                 const float v = in ? plane[yy * W + xx] : 0.0f;
-                const f32x4 ww = w4[ky * k + kx];
-                acc[0] = fmaf(ww.x, v, acc[0]);
-                acc[1] = fmaf(ww.y, v, acc[1]);
-                acc[2] = fmaf(ww.z, v, acc[2]);
-                acc[3] = fmaf(ww.w, v, acc[3]);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(v, wrow[(ky * k + kx) * COB], acc, 0, 0, 0);
             }
         }
         if (DOWN) {
             const float v = live ? plane[s] : 0.0f;
-            const f32x4 ww = *reinterpret_cast<const lds_f4 *>(wd + (ci - c_base) * COB);
-            accd[0] = fmaf(ww.x, v, accd[0]);
-            accd[1] = fmaf(ww.y, v, accd[1]);
-            accd[2] = fmaf(ww.z, v, accd[2]);
-            accd[3] = fmaf(ww.w, v, accd[3]);
+            accd = __builtin_amdgcn_mfma_f32_4x4x1f32(v, wd[(ci - c_base) * COB + j], accd, 0, 0, 0);
         }
     }
 }
@@ -357,7 +392,7 @@ __device__ __forceinline__ void conv_accumulate(const lds_f *src, int c_base, in
 template <bool DOWN>
 __device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int c_lo, int c_hi, const lds_f *wk,
                                               const lds_f *wd, int k, int H, int W, int P, int p, bool live,
-                                              float (&acc)[COB], float (&accd)[COB]) {
+                                              f32x4 &acc, f32x4 &accd) {
     if (k == 3) conv_accumulate<DOWN, 3>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
     else if (k == 1) conv_accumulate<DOWN, 1>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
     else conv_accumulate<DOWN, 0>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
@@ -366,7 +401,7 @@ __device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int 
 // One workgroup per group of rows (one network call of the reference).  LDS holds three
 // activation buffers of cmax x P floats (a: block input / result, b: after conv1, c: skip path
 // or conv2 output), the staging area for the first block's input and the slice partials.
-__global__ void __launch_bounds__(kWT)
+__global__ void __launch_bounds__(kTT)
 k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
         const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
         float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, int group) {
@@ -400,7 +435,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             if (ar) ar += cb * HW;
             lds_f *d = dst + r * HW;
             if (G.vec_ok) {
-                for (int j = tid * 4; j < n; j += kWT * 4) {
+                for (int j = tid * 4; j < n; j += kTT * 4) {
                     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (xr) v = *reinterpret_cast<const f32x4 *>(xr + j);
                     if (ar) {
@@ -414,7 +449,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                     *reinterpret_cast<lds_f4 *>(d + c * P + s) = v;
                 }
             } else {
-                for (int j = tid; j < n; j += kWT) {
+                for (int j = tid; j < n; j += kTT) {
                     float v = xr ? xr[j] : 0.0f;
                     if (ar) v = fmaxf(v + ar[j], 0.0f);
                     const int c = j / HW, s = j - c * HW;
@@ -432,25 +467,33 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         for (int o = 0; o < COB; ++o) {
             const int co = min(co0 + o, Cout - 1);
             const float *src = w_g + ((long long)co * Cin + cb) * kk;
-            for (int i = tid; i < cn * kk; i += kWT) wst[i * COB + o] = src[i];
+            for (int i = tid; i < cn * kk; i += kTT) wst[i * COB + o] = src[i];
             if (wd_g) {
                 const float *sd = wd_g + (long long)co * Cin + cb;
-                for (int i = tid; i < cn; i += kWT) wdst[i * COB + o] = sd[i];
+                for (int i = tid; i < cn; i += kTT) wdst[i * COB + o] = sd[i];
             }
         }
         return wdst;
     };
     // sums the channel slices of acc in a fixed order (slice 0 ends up with the total)
-    auto reduce_slices = [&](float (&acc)[COB], int which, int slot, bool live) {
-        if (live)
-            for (int o = 0; o < COB; ++o) red[((ksi * 2 + which) * COB + o) * pstride + slot] = acc[o];
+    auto reduce_slices = [&](f32x4 &acc, int which, int slot) {
+        for (int o = 0; o < COB; ++o) red[((ksi * 2 + which) * COB + o) * pstride + slot] = acc[o];
         __syncthreads();
-        if (ksi == 0 && live)
+        if (ksi == 0)
             for (int o = 0; o < COB; ++o) {
                 float s = 0.0f;
                 for (int q = 0; q < G.ks; ++q) s += red[((q * 2 + which) * COB + o) * pstride + slot];
                 acc[o] = s;
             }
+    };
+    // accumulator of lane 4b+j, element i = position (wave's first position) + 4b+i, channel co0+j
+    auto store_acc = [&](lds_f *dst, const f32x4 &acc, int co0, int Cout, int first_pos) {
+        const int co = co0 + (lane & 3);
+        if (co >= Cout) return;
+        for (int i = 0; i < 4; ++i) {
+            const int pos = first_pos + (lane & ~3) + i;
+            if (pos < P) dst[co * P + pos] = acc[i];
+        }
     };
 
     MZ_TT(0)
@@ -465,7 +508,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 const int slot = pwi * 64 + lane, p = pb + slot;
                 const bool live = p < P;
                 const int pc = live ? p : 0;
-                float acc[COB] = {0.0f, 0.0f, 0.0f, 0.0f}, accd[COB] = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accd = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (from_global) {
                     for (int cb = 0; cb < Cin; cb += G.stage_c) {
                         const int cn = min(G.stage_c, Cin - cb);
@@ -492,15 +535,13 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 MZ_TT(3)
                 if (G.ks > 1) {
                     __syncthreads();  // earlier partials have been read
-                    reduce_slices(acc, 0, slot, live);
-                    if (down) reduce_slices(accd, 1, slot, live);
+                    reduce_slices(acc, 0, slot);
+                    if (down) reduce_slices(accd, 1, slot);
                 }
-                if (ksi == 0 && live)
-                    for (int o = 0; o < COB; ++o)
-                        if (co0 + o < Cout) {
-                            mid[(co0 + o) * P + p] = acc[o];
-                            if (down) aux[(co0 + o) * P + p] = accd[o];
-                        }
+                if (ksi == 0) {
+                    store_acc(mid, acc, co0, Cout, pb + pwi * 64);
+                    if (down) store_acc(aux, accd, co0, Cout, pb + pwi * 64);
+                }
             }
         }
         __syncthreads();
@@ -515,7 +556,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             for (int pb = 0; pb < P; pb += pstride) {
                 const int slot = pwi * 64 + lane, p = pb + slot;
                 const bool live = p < P;
-                float acc[COB] = {0.0f, 0.0f, 0.0f, 0.0f}, accd[COB] = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accd = {0.0f, 0.0f, 0.0f, 0.0f};
                 const int per = (Cout + G.ks - 1) / G.ks;
                 const int lo = min(Cout, ksi * per), hi = min(Cout, (ksi + 1) * per);
                 __syncthreads();
@@ -524,11 +565,9 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 conv_dispatch<false>(mid, 0, lo, hi, wst, wst, k, G.H, G.W, P, live ? p : 0, live, acc, accd);
                 if (G.ks > 1) {
                     __syncthreads();
-                    reduce_slices(acc, 0, slot, live);
+                    reduce_slices(acc, 0, slot);
                 }
-                if (ksi == 0 && live)
-                    for (int o = 0; o < COB; ++o)
-                        if (co0 + o < Cout) dst[(co0 + o) * P + p] = acc[o];
+                if (ksi == 0) store_acc(dst, acc, co0, Cout, pb + pwi * 64);
             }
         }
         __syncthreads();
@@ -543,7 +582,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             __syncthreads();
         }
         const lds_f *skip = down ? aux : (from_global ? mid : cur);
-        for (int i = tid; i < Cout * P; i += kWT) cur[i] = activate(dst[i] + skip[i], R.activation);
+        for (int i = tid; i < Cout * P; i += kTT) cur[i] = activate(dst[i] + skip[i], R.activation);
         __syncthreads();
     }
 
@@ -556,7 +595,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     const int fs = Cl <= 3 ? 4 : Cl + 1;
     lds_f *wfin = stage;
     if (T.final_w != nullptr) {
-        for (int i = tid; i < G.C * fs; i += kWT) {
+        for (int i = tid; i < G.C * fs; i += kTT) {
             const int c = i / fs, j = i - c * fs;
             float v = 0.0f;
             if (j < Cl) v = T.final_w[c * Cl + j];
@@ -578,22 +617,22 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 // the shipped towers end in 3 channels: the position's values stay in registers
                 const float i0 = cur[p], i1 = Cl > 1 ? cur[P + p] : 0.0f, i2 = Cl > 2 ? cur[2 * P + p] : 0.0f;
 #pragma unroll 4
-                for (int c = wv; c < G.C; c += kWT / 64) {
+                for (int c = wv; c < G.C; c += kTW) {
                     const f32x4 q = *reinterpret_cast<const lds_f4 *>(wfin + c * 4);
                     yr[c * HW] = fmaf(q.z, i2, fmaf(q.y, i1, fmaf(q.x, i0, q.w)));
                 }
             } else {
-                for (int c = wv; c < G.C; c += kWT / 64) {
+                for (int c = wv; c < G.C; c += kTW) {
                     float v = wfin[c * fs + fs - 1];
                     for (int ci = 0; ci < Cl; ++ci) v = fmaf(wfin[c * fs + ci], cur[ci * P + p], v);
                     yr[c * HW] = v;
                 }
             }
         } else if (T.n_blocks) {
-            for (int c = wv; c < G.C; c += kWT / 64) yr[c * HW] = cur[c * P + p];
+            for (int c = wv; c < G.C; c += kTW) yr[c * HW] = cur[c * P + p];
         } else {
             const float *xr = src_row(r), *ar = add_row(r);
-            for (int c = wv; c < G.C; c += kWT / 64) {
+            for (int c = wv; c < G.C; c += kTW) {
                 float v = xr ? xr[c * HW + s] : 0.0f;
                 if (ar) v = fmaxf(v + ar[c * HW + s], 0.0f);
                 yr[c * HW] = v;
@@ -636,8 +675,9 @@ int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: the last block leaves %d channels, res_final is needed for C=%d",
                         cin, T->C);
     const int slots = (g->P + 63) / 64;
-    g->pw = slots >= 3 ? 4 : slots;  // 1, 2 or 4 waves across the positions
-    g->ks = 4 / g->pw;
+    g->pw = 1;  // waves across the positions: a power of two
+    while (g->pw < slots && g->pw < kTW) g->pw <<= 1;
+    g->ks = kTW / g->pw;
     auto up4 = [](long long v) { return (v + 3) & ~3LL; };
     int kkmax = 1;
     for (int b = 0; b < T->n_blocks; ++b) kkmax = std::max(kkmax, T->block[b].kernel_size * T->block[b].kernel_size);
@@ -763,7 +803,7 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     g.vec_ok = g.HW % 4 == 0 && ldx % 4 == 0 && aligned(x) && (!row_add || (ld_add % 4 == 0 && aligned(row_add)));
     MZ_TRY(allow_lds(k_tower, lds, "k_tower"));
-    hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kWT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
+    hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
                        x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, group);
     return mz::check_launch("k_tower");
 }
