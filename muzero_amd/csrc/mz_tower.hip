@@ -28,11 +28,11 @@ constexpr size_t kMaxLds = 160 * 1024;
 // Workgroup = 2 x 2 waves, wave tile = (16 MTW) x (16 NTW), workgroup tile TM x TN = 32 MTW x 32 NTW.
 // Activations: global -> registers -> LDS chunk (double buffered, one barrier per chunk);
 // weights: packed tiles straight from global/L2 into registers, one k-tile ahead.
-template <int MTW, int NTW>
+template <int MTW, int NTW, bool VEC>
 __global__ void __launch_bounds__(kWT) __attribute__((amdgpu_waves_per_eu(2)))
 k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restrict__ x, long long ldx,
        const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B, int splitk,
-       int chunks_per_split, float *__restrict__ ws, int vec_ok) {
+       int chunks_per_split, float *__restrict__ ws) {
     constexpr int TM = 32 * MTW, TN = 32 * NTW, XR = TM / 16;
     extern __shared__ __align__(16) float xs[];  // [2][TM][kLdX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,48 +42,64 @@ k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restric
     const int n0 = blockIdx.x * TN, m0 = blockIdx.y * TM, z = blockIdx.z;
     const int nchunks = (KT + 3) >> 2;
     const int c_lo = z * chunks_per_split, c_hi = min(nchunks, c_lo + chunks_per_split);
+    const int c_full = min(c_hi, KT >> 2);  // chunks [c_lo, c_full) hold four k-tiles
 
+    // activation rows of this thread: source row index (-1: zeros) kept as 32 bits
     const int sc = (tid & 15) * 4, sr = tid >> 4;
-    const float *xrow[XR];
+    int srow[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int r = m0 + sr + 16 * i;
-        long long src = -1;
-        if (r < B) src = x_rows ? (long long)x_rows[r] : (long long)r;
-        xrow[i] = src >= 0 ? x + src * ldx : nullptr;
+        int src = -1;
+        if (r < B) src = x_rows ? x_rows[r] : r;
+        srow[i] = src;
     }
     constexpr int XH = XR / 2;  // the chunk is fetched in two halves to halve the registers it holds
+    // VEC: branch-free -- an absent row or a column past K reads a valid address here and is
+    // zeroed when it is written to LDS (so nothing waits for the load where it is issued)
     auto fetch = [&](int c, int half, f32x4 (&v)[XH]) {
         const int k = c * kKC + sc;
 #pragma unroll
         for (int ii = 0; ii < XH; ++ii) {
             const int i = half * XH + ii;
-            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (xrow[i] != nullptr) {
-                if (vec_ok) {
-                    if (k < L.K) t = *reinterpret_cast<const f32x4 *>(xrow[i] + k);
-                } else {
-                    if (k < L.K) t.x = xrow[i][k];
-                    if (k + 1 < L.K) t.y = xrow[i][k + 1];
-                    if (k + 2 < L.K) t.z = xrow[i][k + 2];
-                    if (k + 3 < L.K) t.w = xrow[i][k + 3];
+            if (VEC) {
+                const float *p = x + (long long)max(srow[i], 0) * ldx + min(k, L.K - 4);
+                v[ii] = *reinterpret_cast<const f32x4 *>(p);
+            } else {
+                f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (srow[i] >= 0) {
+                    const float *p = x + (long long)srow[i] * ldx;
+                    if (k < L.K) t.x = p[k];
+                    if (k + 1 < L.K) t.y = p[k + 1];
+                    if (k + 2 < L.K) t.z = p[k + 2];
+                    if (k + 3 < L.K) t.w = p[k + 3];
                 }
+                v[ii] = t;
             }
-            v[ii] = t;
         }
     };
-    auto stash = [&](int buf, int half, const f32x4 (&v)[XH]) {
+    auto stash = [&](int buf, int c, int half, const f32x4 (&v)[XH]) {
+        const bool kin = c * kKC + sc < L.K;
 #pragma unroll
-        for (int ii = 0; ii < XH; ++ii)
-            *reinterpret_cast<f32x4 *>(&xs[(buf * TM + sr + 16 * (half * XH + ii)) * kLdX + sc]) = v[ii];
+        for (int ii = 0; ii < XH; ++ii) {
+            const int i = half * XH + ii;
+            f32x4 t = v[ii];
+            if (VEC && !(kin && srow[i] >= 0)) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4 *>(&xs[(buf * TM + sr + 16 * i) * kLdX + sc]) = t;
+        }
     };
-    const f32x4 *wp = reinterpret_cast<const f32x4 *>(blob + L.w_off) + lane;
-    long long wbase[NTW];
+    // Packed weight tiles of this wave's column tiles.  The ring below requests up to 3 tiles
+    // past the last one of a column tile: those addresses are the next column tile's weights,
+    // or the bias and the read slack behind the layer -- valid memory that feeds no arithmetic.
+    const f32x4 *wq[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) wbase[t] = (long long)min((n0 >> 4) + wn * NTW + t, NT - 1) * KT * 64;
-    auto wload = [&](int kt, f32x4 (&w)[NTW]) {
+    for (int t = 0; t < NTW; ++t)
+        wq[t] = reinterpret_cast<const f32x4 *>(blob + L.w_off) + lane +
+                ((long long)min((n0 >> 4) + wn * NTW + t, NT - 1) * KT + c_lo * 4) * 64;
+    // tile (first tile of the current chunk) + j
+    auto wload = [&](int j, f32x4 (&w)[NTW]) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) w[t] = wp[wbase[t] + (long long)kt * 64];
+        for (int t = 0; t < NTW; ++t) w[t] = wq[t][j * 64];
     };
 
     f32x4 acc[MTW][NTW];
@@ -115,58 +131,57 @@ k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restric
         // request is about 200 MFMAs old when it is consumed; the scheduling barriers keep the
         // requests ahead of the MFMAs they were written before.
         f32x4 xv[XH], w0[NTW], w1[NTW], w2[NTW], w3[NTW], a0[MTW], a1[MTW];
-        const int kl = KT - 1;
         fetch(c_lo, 0, xv);
-        wload(min(c_lo * 4, kl), w0);
-        wload(min(c_lo * 4 + 1, kl), w1);
-        wload(min(c_lo * 4 + 2, kl), w2);
-        stash(0, 0, xv);
+        wload(0, w0);
+        wload(1, w1);
+        wload(2, w2);
+        stash(0, c_lo, 0, xv);
         fetch(c_lo, 1, xv);
-        stash(0, 1, xv);
+        stash(0, c_lo, 1, xv);
         __syncthreads();
-        for (int c = c_lo; c < c_hi; ++c) {
-            const int buf = (c - c_lo) & 1;
-            const bool more = c + 1 < c_hi;
-            const int kt0 = c * 4, nk = min(4, KT - kt0);
-            if (nk == 4) {
-                // a full chunk is never the last of the layer's reduction, but it may be the
-                // last of this split: `more` guards the activation prefetch
-                if (more) fetch(c + 1, 0, xv);
-                aload(buf, 0, a0);
-                wload(min(kt0 + 3, kl), w3);
-                aload(buf, 1, a1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(a0, w0);
-                wload(min(kt0 + 4, kl), w0);
-                aload(buf, 2, a0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(a1, w1);
-                if (more) {
-                    stash(buf ^ 1, 0, xv);
-                    fetch(c + 1, 1, xv);
-                }
-                wload(min(kt0 + 5, kl), w1);
-                aload(buf, 3, a1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(a0, w2);
-                wload(min(kt0 + 6, kl), w2);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(a1, w3);
-                if (more) stash(buf ^ 1, 1, xv);
-            } else {
-                // last, partial chunk of the reduction: its tiles are already in w0..w2
-                aload(buf, 0, a0);
-                mm(a0, w0);
-                if (nk > 1) {
-                    aload(buf, 1, a1);
-                    mm(a1, w1);
-                }
-                if (nk > 2) {
-                    aload(buf, 2, a0);
-                    mm(a0, w2);
-                }
+        int buf = 0;
+        for (int c = c_lo; c < c_full; ++c) {
+            const bool more = c + 1 < c_hi;  // a full chunk may still be the last of this split
+            if (more) fetch(c + 1, 0, xv);
+            aload(buf, 0, a0);
+            wload(3, w3);
+            aload(buf, 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, w0);
+            wload(4, w0);
+            aload(buf, 2, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, w1);
+            if (more) {
+                stash(buf ^ 1, c + 1, 0, xv);
+                fetch(c + 1, 1, xv);
             }
+            wload(5, w1);
+            aload(buf, 3, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, w2);
+            wload(6, w2);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) wq[t] += 4 * 64;
+            __builtin_amdgcn_sched_barrier(0);
+            mm(a1, w3);
+            if (more) stash(buf ^ 1, c + 1, 1, xv);
             __syncthreads();
+            buf ^= 1;
+        }
+        if (c_full < c_hi) {
+            // last, partial chunk of the layer's reduction: its 1..3 tiles are already in w0..w2
+            const int nk = KT - c_full * 4;
+            aload(buf, 0, a0);
+            mm(a0, w0);
+            if (nk > 1) {
+                aload(buf, 1, a1);
+                mm(a1, w1);
+            }
+            if (nk > 2) {
+                aload(buf, 2, a0);
+                mm(a0, w2);
+            }
         }
     }
 
@@ -767,17 +782,17 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
         return mz::fail(MZ_ERR_ARG, "mz_wide_forward: workspace of %lld floats needed, %lld given", (long long)need,
                         (long long)(workspace ? workspace_floats : 0));
     hipStream_t st = (hipStream_t)stream;
-    const int vec_ok = (ldx % 4 == 0) && (L.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool vec = (ldx % 4 == 0) && (L.K % 4 == 0) && L.K >= 4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const dim3 grid(s.tiles_n, s.tiles_m, s.splitk);
     const size_t lds = (size_t)2 * s.tm * kLdX * sizeof(float);
-    if (s.big) {
-        MZ_TRY(allow_lds(k_wide<4, 4>, lds, "k_wide"));
-        hipLaunchKernelGGL((k_wide<4, 4>), grid, dim3(kWT), lds, st, L, blob, x, (long long)ldx, x_rows, y,
-                           (long long)ldy, B, s.splitk, s.chunks_per_split, workspace, vec_ok);
-    } else {
-        hipLaunchKernelGGL((k_wide<2, 2>), grid, dim3(kWT), lds, st, L, blob, x, (long long)ldx, x_rows, y,
-                           (long long)ldy, B, s.splitk, s.chunks_per_split, workspace, vec_ok);
-    }
+    auto launch = [&](auto kernel) -> int {
+        MZ_TRY(allow_lds(kernel, lds, "k_wide"));
+        hipLaunchKernelGGL(kernel, grid, dim3(kWT), lds, st, L, blob, x, (long long)ldx, x_rows, y, (long long)ldy, B,
+                           s.splitk, s.chunks_per_split, workspace);
+        return MZ_OK;
+    };
+    if (s.big) MZ_TRY(vec ? launch(k_wide<4, 4, true>) : launch(k_wide<4, 4, false>));
+    else MZ_TRY(vec ? launch(k_wide<2, 2, true>) : launch(k_wide<2, 2, false>));
     MZ_TRY(mz::check_launch("k_wide"));
     if (s.splitk > 1) {
         const long long total = (long long)B * L.N;
