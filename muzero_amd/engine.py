@@ -113,7 +113,8 @@ class PackedNetworks:
 
     def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda"):
         if len(dynamics.res_blocks) or len(prediction.res_blocks):
-            raise NotImplementedError("the fused HIP networks cover res_net: [] configurations")
+            raise NotImplementedError("the fused HIP networks cover res_net: [] configurations; "
+                                      "use make_networks() / muzero_amd.towers.TowerNetworks")
         if not isinstance(dynamics.res_final, torch.nn.Identity) or not isinstance(prediction.res_final, torch.nn.Identity):
             raise NotImplementedError("res_final must be the identity for MLP-only networks")
         self.device = torch.device(device)
@@ -172,6 +173,18 @@ class PackedNetworks:
         _hip.check(_hip.lib().mz_prediction_forward(
             C.byref(self.plan), ptr(self.blob), ptr(latent), ld or self.D, ptr(rows), softmax_times, ptr(policy),
             ptr(value), ptr(argmax), B, _stream()), "mz_prediction_forward")
+
+
+def make_networks(dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda"):
+    """Device evaluator for a (g, f) pair: `PackedNetworks` (fused kernels, single-launch search)
+    for `res_net: []` configurations, `muzero_amd.towers.TowerNetworks` when either network has
+    residual blocks or a res_final convolution."""
+    plain = (len(dynamics.res_blocks) == 0 and len(prediction.res_blocks) == 0 and
+             isinstance(dynamics.res_final, torch.nn.Identity) and isinstance(prediction.res_final, torch.nn.Identity))
+    if plain:
+        return PackedNetworks(dynamics, prediction, device=device)
+    from muzero_amd.towers import TowerNetworks
+    return TowerNetworks(dynamics, prediction, device=device)
 
 
 @dataclass

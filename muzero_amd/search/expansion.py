@@ -12,13 +12,13 @@ _PACK_CACHE: dict = {}
 
 
 def packed_for(dynamics_network, prediction_network):
-    """PackedNetworks for a (g, f) module pair, rebuilt when a parameter was modified."""
-    from muzero_amd.engine import PackedNetworks
+    """Device evaluator for a (g, f) module pair, rebuilt when a parameter was modified."""
+    from muzero_amd.engine import make_networks
     key = (id(dynamics_network), id(prediction_network))
     version = tuple(p._version for p in list(dynamics_network.parameters()) + list(prediction_network.parameters()))
     hit = _PACK_CACHE.get(key)
     if hit is None or hit[0] != version:
-        hit = (version, PackedNetworks(dynamics_network, prediction_network))
+        hit = (version, make_networks(dynamics_network, prediction_network))
         _PACK_CACHE[key] = hit
     return hit[1]
 
@@ -39,7 +39,11 @@ def expand_node(node: Node, actions: torch.Tensor, dynamics_network, prediction_
     rep = lat.repeat(batch_size, 1).contiguous()
     nxt = torch.empty((batch_size, nets.D), dtype=torch.float32, device=dev)
     rew = torch.empty(batch_size, dtype=torch.float32, device=dev)
-    nets.dynamics(rep, batch_size, action=actions.to(dev, torch.int32).contiguous(), next_latent=nxt, reward=rew)
+    if batch_size == nets.A and torch.equal(actions.reshape(-1).cpu(), torch.arange(nets.A)):
+        # the A children of one node are ONE call of g: residual towers normalise them together
+        nets.dynamics(rep, batch_size, action=None, next_latent=nxt, reward=rew)
+    else:
+        nets.dynamics(rep, batch_size, action=actions.to(dev, torch.int32).contiguous(), next_latent=nxt, reward=rew)
     prior_h = prior[0].cpu()
     shape = (1,) + tuple(node.latent_state.shape[1:])
     out_dev = node.latent_state.device

@@ -20,7 +20,7 @@ import torch
 
 from muzero_amd import _hip
 from muzero_amd._hip import ptr
-from muzero_amd.engine import BatchedMCTS, PackedNetworks, _stream
+from muzero_amd.engine import BatchedMCTS, _stream, make_networks
 from muzero_amd.environments.connect_four import BatchedConnectFour
 
 
@@ -99,7 +99,7 @@ class SelfPlayEngine:
         self.env = BatchedConnectFour(G, device=device)
         self.A = self.env.num_actions
         self.h = RepresentationRunner(repr_net, device=device)
-        self.nets = PackedNetworks(dyn_net, pred_net, device=device)
+        self.nets = make_networks(dyn_net, pred_net, device=device)
         self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
                                 device=device)
         self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)

@@ -200,3 +200,59 @@ def test_lockstep_search_with_towers(ni, ti):
             np.testing.assert_allclose(res.policy[gi].cpu().numpy(), Z[k + "policy"], rtol=1e-5)
     same_as_reference = sum(int(np.array_equal(ref["visit"][gi], Z[k + "visit"])) for gi in (0, 1))
     assert same_as_reference == 2, "the reference's recorded tree was not reproduced"
+
+
+@pytest.mark.parametrize("ni,ti", TREES)
+def test_dropin_mcts_run_with_towers_reproduces_reference_run(ni, ti):
+    """create_mcts(...).run(root) -- the reference's call -- with residual-tower modules and the
+    global RNGs seeded as the reference's run was."""
+    import random
+    from muzero_amd.config import MCTSConfig
+    from muzero_amd.search.factory import create_mcts
+    from muzero_amd.search.nodes import Node
+    k = f"net{ni}_t{ti}_"
+    g, f, A, shape = load_tower_nets(ni)
+    S, depth = int(Z[k + "S"]), int(Z[k + "depth"])
+    cfg = MCTSConfig(selection_strategy="puct", max_iterations=S, max_time=0, model_look_ahead=depth,
+                     discount_factor=float(Z[k + "discount"]), dirichlet_alpha=0.3, noise_frac=float(Z[k + "noise_frac"]))
+    mcts = create_mcts(g, f, torch.arange(A).long(), cfg)
+    seed = int(Z[k + "seed"])
+    random.seed(seed)
+    torch.manual_seed(seed)
+    root = Node(latent_state=torch.from_numpy(Z[k + "root_latent"]), to_play=int(Z[k + "to_play"]))
+    policy, utility = mcts.run(root)
+    kids = list(root.children.values())
+    assert root.visit_count == S and len(kids) == A
+    np.testing.assert_allclose([float(c.policy_priority) for c in kids], Z[k + "prior"][1:1 + A], rtol=1e-5)
+    assert [c.visit_count for c in kids] == Z[k + "visit"][1:1 + A].tolist()
+    np.testing.assert_allclose(policy, Z[k + "policy"], rtol=1e-5)
+    np.testing.assert_allclose(utility, float(Z[k + "utility"]), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose([c.value_sum for c in kids], Z[k + "value_sum"][1:1 + A], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("ni", NETS)
+def test_dropin_expand_and_simulate_with_towers(ni):
+    """expand_node and MuZeroSimulation on Node objects (the reference's unit-test surface):
+    the children of one expansion are normalised together, a rollout step alone."""
+    from muzero_amd.search.expansion import expand_node
+    from muzero_amd.search.nodes import Node
+    from muzero_amd.search.simulation import MuZeroSimulation
+    g, f, A, shape = load_tower_nets(ni)
+    lat = torch.from_numpy(Z[f"net{ni}_latent"])
+    for i in range(2):
+        node = Node(latent_state=lat[i:i + 1].clone(), to_play=1)
+        expand_node(node, torch.arange(A).long(), g, f)
+        kids = list(node.children.values())
+        got = torch.cat([c.latent_state for c in kids]).numpy()
+        np.testing.assert_allclose(got, Z[f"net{ni}_gA_next"][i], **TOL)
+        np.testing.assert_allclose([float(c.reward) for c in kids], Z[f"net{ni}_gA_reward"][i][:, 0], **TOL)
+        want_prior = torch.softmax(torch.from_numpy(Z[f"net{ni}_f1_policy"][i:i + 1]), dim=1)[0].numpy()
+        np.testing.assert_allclose([c.policy_priority for c in kids], want_prior, **TOL)
+    # one greedy rollout step: f's argmax, g alone, f's value -- against the torch modules
+    node = Node(latent_state=lat[3:4].clone(), to_play=1)
+    out = MuZeroSimulation(g, f, depth=1)(node)
+    with torch.no_grad():
+        a = f(lat[3:4])[0].argmax(dim=1)
+        nl, r = g(lat[3:4], a)
+        v = f(nl)[1]
+    np.testing.assert_allclose(out, [float(r), float(v)], rtol=1e-5, atol=2e-6)

@@ -21,6 +21,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 MFMA_F32_PEAK_TFLOPS = 157.3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the fc_merge kernel from the committed counter passes (None if absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_g_wide_pmc_traffic.json")) as fh:
+            return json.load(fh)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def build_nets(shape, A):
@@ -115,10 +125,10 @@ def main() -> None:
         "reference_flop_per_sim": 3 * F_f + (A + 1) * F_g,
         "algorithmic_tflops": (3 * F_f + (A + 1) * F_g) * G * S / dt / 1e12,
         "stage_ms": {"f(G rows)": f_ms, "g expansion (G*A rows)": gA_ms, "g step (G rows)": g1_ms},
-        "roofline": {"bound": "mfma", "kernel": "k_wide<4,4> [fc_merge latent half]",
+        "roofline": {"bound": "mfma", "kernel": "k_wide<4,4,true> + k_wide_finish [fc_merge latent half]",
                      "achieved": merge_flop / merge_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": merge_flop / merge_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": merge_ms * 1e3,
-                     "flop_per_launch": merge_flop, "traffic": None},
+                     "flop_per_launch": merge_flop, "traffic": pmc_traffic() if (G, D) == (256, 9216) else None},
         "build_s": t_build,
     }))
 
