@@ -44,10 +44,42 @@ class DeviceHistory:
         return self.out
 
 
+def _batchnorm_per_sample(bn: torch.nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
+    """BatchNorm2d in train mode applied to every sample of the batch on its own: folding the
+    batch into the channel axis gives each (sample, channel) plane its own mean and biased
+    variance, which is what B separate calls with batch size 1 compute."""
+    G, Cn, H, W = x.shape
+    w = bn.weight.repeat(G) if bn.weight is not None else None
+    b = bn.bias.repeat(G) if bn.bias is not None else None
+    y = torch.nn.functional.batch_norm(x.reshape(1, G * Cn, H, W), None, None, w, b, True, 0.0, bn.eps)
+    return y.reshape(G, Cn, H, W)
+
+
+class per_call_statistics:
+    """Context manager: inside it every BatchNorm2d of `module` normalises each sample with that
+    sample's own statistics.  The reference evaluates h once per game and move with batch size 1
+    and never leaves train mode (src/training_data_generator.py:114-118, main.py:39), so a batch
+    of G games must not share statistics.  Running statistics are left untouched."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.bns = [m for m in module.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+
+    def __enter__(self):
+        for bn in self.bns:
+            bn.forward = (lambda x, _bn=bn: _batchnorm_per_sample(_bn, x))
+        return self
+
+    def __exit__(self, *exc):
+        for bn in self.bns:
+            del bn.forward
+        return False
+
+
 class RepresentationRunner:
     """h on the GPU.  MLP-style configs (`downsample: [], res_net: []`, latent H, W equal to the
     observation's) are one 1x1 convolution and run the HIP kernel; every other configuration
-    runs the torch module on the GPU (its convolutions are not part of this path yet)."""
+    runs the torch module on the GPU (its convolutions are not part of this path yet), with the
+    per-game batch statistics of the reference's one-game-at-a-time calls."""
 
     def __init__(self, repr_net: torch.nn.Module, device="cuda"):
         self.net = repr_net
@@ -70,7 +102,7 @@ class RepresentationRunner:
             _hip.check(_hip.lib().mz_repr_pointwise(ptr(x), ptr(self.weight), ptr(self.bias), G, cin, cout, H * W,
                                                     ptr(out), _stream()), "mz_repr_pointwise")
             return out
-        with torch.no_grad():
+        with torch.no_grad(), per_call_statistics(self.net):
             return self.net.to(self.device)(history.to(self.device))
 
 
@@ -84,8 +116,11 @@ def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_act
 
 class SelfPlayEngine:
     def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0,
-                 device_rng: bool = False):
+                 device_rng: bool = False, env=None):
         """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps).
+        `env`: a batched environment (`observe`, `step`, `reset(mask)`, `num_actions`,
+        `observation_space`); default: G Connect-Four games on the GPU.  Host-side simulators go
+        through `muzero_amd.environments.host_pool.HostEnvPool`.
 
         The search consumes no random numbers itself: the Dirichlet noise, the child draws and the
         exploration decisions of a move are inputs.  By default they come from a numpy generator on
@@ -96,7 +131,8 @@ class SelfPlayEngine:
         m = config.mcts
         if m.max_iterations <= 0:
             raise ValueError("batched self-play needs max_iterations > 0 (the time-bounded mode is single-game only)")
-        self.env = BatchedConnectFour(G, device=device)
+        self.env = env if env is not None else BatchedConnectFour(G, device=device)
+        assert getattr(self.env, "G", G) == G, "the environment batch must hold G games"
         self.A = self.env.num_actions
         self.h = RepresentationRunner(repr_net, device=device)
         self.nets = make_networks(dyn_net, pred_net, device=device)

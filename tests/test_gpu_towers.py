@@ -256,3 +256,65 @@ def test_dropin_expand_and_simulate_with_towers(ni):
         nl, r = g(lat[3:4], a)
         v = f(nl)[1]
     np.testing.assert_allclose(out, [float(r), float(v)], rtol=1e-5, atol=2e-6)
+
+
+def test_selfplay_with_host_environments_conv_h_and_towers():
+    """Configs 3-4 in small: single-player simulators on the host (to_play 0), a convolutional h with
+    BatchNorm evaluated with per-game statistics, residual-tower g / f in the lock-step search.
+    The first move of every game is recomputed by hand: h one game at a time on the CPU, then the
+    drop-in MCTS.run fed with the engine's own random streams."""
+    from muzero_amd.config import (ConvLayerConfig, MCTSConfig, RepresentationNetworkConfig, ResBlockConfig,
+                                   TrainingDataGeneratorConfig)
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.environments.host_pool import HostEnvPool
+    from muzero_amd.neural_networks import RepresentationNetwork
+    from muzero_amd.selfplay import SelfPlayEngine
+    from muzero_amd.towers import TowerNetworks
+    from tests.test_host_pool import CountingEnv
+    g, f, A, shape = load_tower_nets(0)          # latent (16, 4, 4), 5 actions
+    torch.manual_seed(4)
+    rb = ResBlockConfig(out_channels=6, kernel_size=3, stride=1, padding=1, activation="relu", pool_kernel_size=1,
+                        pool_stride=1)
+    K = 2
+    h = RepresentationNetwork((2, 8, 8), shape, RepresentationNetworkConfig(history_length=K, downsample=[
+        ConvLayerConfig(out_channels=6, kernel_size=2, stride=2, padding=0, activation="relu"), rb], res_net=[]))
+
+    class Env(CountingEnv):
+        def get_to_play(self):
+            return 0
+
+        def _obs(self):
+            gen = torch.Generator().manual_seed(self.gid * 1000 + self.t)
+            return torch.rand((1,) + self.shape, generator=gen)
+
+    G, S = 6, 12
+    envs = [Env(gi, 3 + gi % 3, shape=(2, 8, 8), actions=A) for gi in range(G)]
+    cfg = TrainingDataGeneratorConfig(
+        num_episodes=1, max_steps_per_episode=50, total_time=0, epsilon=0.0, epsilon_decay=1.0, min_epsilon=0.0,
+        mcts=MCTSConfig(selection_strategy="puct", max_iterations=S, max_time=0, model_look_ahead=1,
+                        discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
+    eng = SelfPlayEngine(h, g, f, G, cfg, seed=3, env=HostEnvPool(envs, workers=2))
+    assert isinstance(eng.nets, TowerNetworks)
+    # replay the engine's streams for the first move
+    rng = np.random.default_rng(3)
+    rand = rng.integers(0, A, size=(G, S + 1), dtype=np.int32)
+    eta = rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)
+    first_obs = torch.cat([Env(gi, 9, shape=(2, 8, 8), actions=A)._obs() for gi in range(G)])
+    obs, policy32, value, action, reward, ended = eng.move()
+    torch.cuda.synchronize()
+    assert torch.equal(obs.cpu(), first_obs)
+    hist = torch.cat([first_obs.repeat(1, K, 1, 1), torch.zeros(G, K, 8, 8)], dim=1)  # K copies + zero action planes
+    with torch.no_grad():
+        lat = torch.cat([h.cpu()(hist[i:i + 1]) for i in range(G)]).reshape(G, -1)   # one game per call
+    mcts = BatchedMCTS(eng.nets, G, S, 1, discount=0.998, noise_frac=0.25)
+    res = mcts.run(lat.cuda(), torch.zeros(G, dtype=torch.int8, device="cuda"), torch.from_numpy(eta).cuda(),
+                   torch.from_numpy(rand).cuda())
+    np.testing.assert_allclose(policy32.cpu().numpy(), res.policy32.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert torch.equal(action.cpu(), res.policy32.argmax(dim=1).to(torch.int32).cpu())
+    assert reward.cpu().tolist() == [float(a) for a in action.cpu().tolist()]
+    # play on: episodes end where the simulators say and restart in place
+    episodes = eng.generate(num_moves=9)
+    assert len(episodes) >= G
+    lengths = sorted({len(ep.chunks) for ep in episodes})
+    assert set(lengths) <= {2, 3, 4, 5} and all(abs(float(c.policy.sum()) - 1) < 1e-5 for ep in episodes for c in ep.chunks)
+    eng.env.close()
