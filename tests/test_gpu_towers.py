@@ -318,3 +318,117 @@ def test_selfplay_with_host_environments_conv_h_and_towers():
     lengths = sorted({len(ep.chunks) for ep in episodes})
     assert set(lengths) <= {2, 3, 4, 5} and all(abs(float(c.policy.sum()) - 1) < 1e-5 for ep in episodes for c in ep.chunks)
     eng.env.close()
+
+
+def _random_tower_nets(shape, A, g_blocks, f_blocks, act, seed):
+    """g / f with residual blocks given as (out_channels, kernel_size) pairs, non-trivial BatchNorm affines."""
+    from muzero_amd.config import DenseLayerConfig, DynamicsNetworkConfig, PredictionNetworkConfig, ResBlockConfig
+    from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork
+    d = lambda n: DenseLayerConfig(out_features=n, activation="relu")  # noqa: E731
+    rb = lambda c, k: ResBlockConfig(out_channels=c, kernel_size=k, stride=1, padding=(k - 1) // 2, activation=act,  # noqa: E731
+                                     pool_kernel_size=1, pool_stride=1)
+    torch.manual_seed(seed)
+    g = DynamicsNetwork(shape, A, DynamicsNetworkConfig(res_net=[rb(c, k) for c, k in g_blocks], reward_net=[d(24)]))
+    f = PredictionNetwork(shape, A, PredictionNetworkConfig(res_net=[rb(c, k) for c, k in f_blocks],
+                                                            value_net=[d(16)], policy_net=[d(16)]))
+    with torch.no_grad():
+        for m in list(g.modules()) + list(f.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    return g, f
+
+
+@pytest.mark.parametrize("shape,A,g_blocks,f_blocks,act", [
+    ((4, 12, 12), 7, [(4, 3), (4, 5)], [(4, 1)], "relu"),            # 1008 positions per expansion call: several passes; identity skips; k = 1, 5
+    ((40, 5, 5), 3, [(40, 3)], [(12, 3), (40, 3), (7, 3), (40, 3)], "tanh"),  # 40 channels: 10 output-channel passes; 4 blocks; tanh
+    ((3, 7, 9), 4, [(9, 5), (3, 3)], [(3, 3)], "sigmoid"),            # odd H x W (no 16-byte rows), ends on C channels without res_final
+    ((130, 6, 6), 2, [(3, 3)], [(3, 3)], "relu"),                     # the shipped form with a channel count that is no multiple of 4
+])
+def test_tower_kernel_general_shapes_match_torch(shape, A, g_blocks, f_blocks, act):
+    """Towers the golden file does not hold (kernel sizes 1 and 5, other activations, many positions
+    or channels per call, up to four blocks) against the torch modules evaluated call by call."""
+    from muzero_amd.towers import TowerNetworks
+    g, f = _random_tower_nets(shape, A, g_blocks, f_blocks, act, seed=sum(shape) + A)
+    D = int(np.prod(shape))
+    nets = TowerNetworks(g, f)
+    B = 3
+    torch.manual_seed(1)
+    lat = torch.randn(B, *shape)
+    act_t = torch.randint(0, A, (B,))
+    with torch.no_grad():
+        want_g1 = [g(lat[i:i + 1], act_t[i:i + 1]) for i in range(B)]
+        want_gA = [g(lat[i:i + 1].repeat(A, 1, 1, 1), torch.arange(A)) for i in range(B)]
+        want_f = [f(lat[i:i + 1]) for i in range(B)]
+    x = lat.reshape(B, D).cuda().contiguous()
+    nxt = torch.zeros(B, D, device="cuda")
+    rew = torch.zeros(B, device="cuda")
+    nets.dynamics(x, B, action=act_t.to(torch.int32).cuda(), next_latent=nxt, reward=rew)
+    nxtA = torch.zeros(B * A, D, device="cuda")
+    rewA = torch.zeros(B, A, device="cuda")
+    nets.dynamics(x, B * A, rows=torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(A), action=None,
+                  next_latent=nxtA, reward=rewA)
+    pol = torch.zeros(B, A, device="cuda")
+    val = torch.zeros(B, device="cuda")
+    nets.prediction(x, B, policy=pol, value=val)
+    torch.cuda.synchronize()
+    # 1e-5 relative, with the absolute floor at 1e-5 of the output's scale: BatchNorm divides by the
+    # standard deviation of a few dozen values, which amplifies the last bit of near-zero outputs
+    def close(got, want):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy().reshape(want.shape), want, rtol=1e-5,
+                                   atol=1e-5 * float(np.abs(want).max()))
+
+    close(nxt, torch.cat([w[0] for w in want_g1]))
+    close(rew, torch.cat([w[1] for w in want_g1])[:, 0])
+    close(nxtA, torch.cat([w[0] for w in want_gA]))
+    close(rewA, torch.stack([w[1][:, 0] for w in want_gA]))
+    close(pol, torch.cat([w[0] for w in want_f]))
+    close(val, torch.cat([w[1] for w in want_f])[:, 0])
+
+
+def test_shipped_shape_matches_torch():
+    """The shipped g / f (latent [256, 6, 6], fc_merge 18432 -> 9216, one 256 -> 3 block, res_final, heads on
+    9216 inputs) at full size against the torch modules on the CPU: 1e-5 of each output's scale."""
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    shape, A = (256, 6, 6), 5
+    g, f = build_nets(shape, A)
+    with torch.no_grad():
+        for m in list(g.modules()) + list(f.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    D = 9216
+    nets = TowerNetworks(g, f)
+    B = 2
+    torch.manual_seed(2)
+    lat = torch.randn(B, *shape)
+    with torch.no_grad():
+        want_gA = [g(lat[i:i + 1].repeat(A, 1, 1, 1), torch.arange(A)) for i in range(B)]
+        want_g1 = [g(lat[i:i + 1], torch.tensor([i + 1])) for i in range(B)]
+        want_f = [f(lat[i:i + 1]) for i in range(B)]
+    x = lat.reshape(B, D).cuda().contiguous()
+    nxtA = torch.zeros(B * A, D, device="cuda")
+    rewA = torch.zeros(B, A, device="cuda")
+    nets.dynamics(x, B * A, rows=torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(A), action=None,
+                  next_latent=nxtA, reward=rewA)
+    nxt = torch.zeros(B, D, device="cuda")
+    rew = torch.zeros(B, device="cuda")
+    nets.dynamics(x, B, action=torch.tensor([1, 2], dtype=torch.int32, device="cuda"), next_latent=nxt, reward=rew)
+    pol = torch.zeros(B, A, device="cuda")
+    val = torch.zeros(B, device="cuda")
+    nets.prediction(x, B, policy=pol, value=val)
+    torch.cuda.synchronize()
+
+    def close(got, want):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy().reshape(want.shape), want, rtol=1e-5,
+                                   atol=1e-5 * float(np.abs(want).max()))
+
+    close(nxtA, torch.cat([w[0] for w in want_gA]))
+    close(rewA, torch.stack([w[1][:, 0] for w in want_gA]))
+    close(nxt, torch.cat([w[0] for w in want_g1]))
+    close(rew, torch.cat([w[1] for w in want_g1])[:, 0])
+    close(pol, torch.cat([w[0] for w in want_f]))
+    close(val, torch.cat([w[1] for w in want_f])[:, 0])
