@@ -1,9 +1,10 @@
 """Batched and data-parallel learner step.
 
 The reference trains one window at a time at batch size 1 (src/training.py:131-172, bptt
-:244-305) and sums the per-window losses before one optimizer step.  For tower-less (MLP)
-configurations the same loss and the same gradient come from ONE batched unroll over all
-windows -- no layer mixes rows (no BatchNorm) -- which is what `batched_unroll_loss` computes;
+:244-305) and sums the per-window losses before one optimizer step.  The same loss and the same gradient come
+from ONE batched unroll over all windows: no layer of the MLP configurations mixes rows, and the
+BatchNorm layers of residual configurations are given per-window statistics
+(muzero_amd.neural_networks.per_call) -- which is what `batched_unroll_loss` computes;
 `DataParallelLearner` then splits the windows over ranks (one process per GPU), all-reduces
 the flat gradient once per optimizer step (RCCL over xGMI with the `nccl` backend, gloo on
 the CPU) and keeps the actors' packed weights in step with `broadcast_weights`.
@@ -19,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from muzero_amd.neural_networks.per_call import per_call_statistics
 from muzero_amd.ring_buffer import Frame, FrameRingBuffer, make_history_tensor
 
 
@@ -69,8 +71,14 @@ def batched_unroll_loss(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ah
     """Returns (weighted_sum, per_window_loss[B], (policy_sum, value_sum, reward_sum)).
 
     weighted_sum = sum_b is_weights[b] * loss_b, NOT yet divided by sum(is_weights): the caller
-    normalises (a data-parallel caller after summing over ranks)."""
+    normalises (a data-parallel caller after summing over ranks).  Networks with BatchNorm layers
+    are evaluated with per-window statistics: the reference unrolls one window per call."""
     cp, cv, cr = coeff
+    with per_call_statistics(repr_net), per_call_statistics(dyn_net), per_call_statistics(pred_net):
+        return _unroll(repr_net, dyn_net, pred_net, batch, roll_ahead, cp, cv, cr)
+
+
+def _unroll(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, cp: float, cv: float, cr: float):
     latent = repr_net(batch.history)
     B = len(batch)
     lp = torch.zeros(B, dtype=torch.float32, device=latent.device)

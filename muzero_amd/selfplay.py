@@ -22,6 +22,7 @@ from muzero_amd import _hip
 from muzero_amd._hip import ptr
 from muzero_amd.engine import BatchedMCTS, _stream, make_networks
 from muzero_amd.environments.connect_four import BatchedConnectFour
+from muzero_amd.neural_networks.per_call import per_call_statistics  # noqa: F401  (re-exported)
 
 
 class DeviceHistory:
@@ -42,37 +43,6 @@ class DeviceHistory:
                                                        ptr(step), self.G, self.K, self.C, self.H, self.W, ptr(self.out),
                                                        _stream()), "mz_history_push_assemble")
         return self.out
-
-
-def _batchnorm_per_sample(bn: torch.nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
-    """BatchNorm2d in train mode applied to every sample of the batch on its own: folding the
-    batch into the channel axis gives each (sample, channel) plane its own mean and biased
-    variance, which is what B separate calls with batch size 1 compute."""
-    G, Cn, H, W = x.shape
-    w = bn.weight.repeat(G) if bn.weight is not None else None
-    b = bn.bias.repeat(G) if bn.bias is not None else None
-    y = torch.nn.functional.batch_norm(x.reshape(1, G * Cn, H, W), None, None, w, b, True, 0.0, bn.eps)
-    return y.reshape(G, Cn, H, W)
-
-
-class per_call_statistics:
-    """Context manager: inside it every BatchNorm2d of `module` normalises each sample with that
-    sample's own statistics.  The reference evaluates h once per game and move with batch size 1
-    and never leaves train mode (src/training_data_generator.py:114-118, main.py:39), so a batch
-    of G games must not share statistics.  Running statistics are left untouched."""
-
-    def __init__(self, module: torch.nn.Module):
-        self.bns = [m for m in module.modules() if isinstance(m, torch.nn.BatchNorm2d)]
-
-    def __enter__(self):
-        for bn in self.bns:
-            bn.forward = (lambda x, _bn=bn: _batchnorm_per_sample(_bn, x))
-        return self
-
-    def __exit__(self, *exc):
-        for bn in self.bns:
-            del bn.forward
-        return False
 
 
 class RepresentationRunner:

@@ -152,3 +152,45 @@ def test_two_rank_data_parallel_step_equals_single_rank(tmp_path):
     for a, b, c in zip(r0["params"], r1["params"], params):
         assert torch.equal(a, b)  # ranks in step after the broadcast
         torch.testing.assert_close(a, c.detach(), rtol=1e-4, atol=1e-6)
+
+
+def test_batched_unroll_with_residual_towers_equals_per_window_loop():
+    """Networks with BatchNorm (conv h with a ResBlock, residual-tower g / f): the batched unroll
+    normalises every window with its own statistics, so it still equals the reference's loop of
+    batch-size-1 unrolls in loss and gradient."""
+    from muzero_amd.config import (ConvLayerConfig, DenseLayerConfig, DynamicsNetworkConfig, PredictionNetworkConfig,
+                                   RepresentationNetworkConfig, ResBlockConfig, load_config)
+    from muzero_amd.learner import batched_unroll_loss, windows_to_batch
+    from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork, RepresentationNetwork
+    from muzero_amd.training import NeuralNetworkManager
+    cfg = load_config("config_c4_mlp.yaml")
+    rb = lambda c: ResBlockConfig(out_channels=c, kernel_size=3, stride=1, padding=1, activation="relu",  # noqa: E731
+                                  pool_kernel_size=1, pool_stride=1)
+    d = lambda n: DenseLayerConfig(out_features=n, activation="relu")  # noqa: E731
+    torch.manual_seed(5)
+    shape = (5, 6, 7)
+    h = RepresentationNetwork((2, 6, 7), shape, RepresentationNetworkConfig(
+        history_length=cfg.networks.representation.history_length,
+        downsample=[ConvLayerConfig(out_channels=6, kernel_size=3, stride=1, padding=1, activation="relu"), rb(6)],
+        res_net=[rb(4)]))
+    g = DynamicsNetwork(shape, A, DynamicsNetworkConfig(res_net=[rb(3)], reward_net=[d(16)]))
+    f = PredictionNetwork(shape, A, PredictionNetworkConfig(res_net=[rb(3)], value_net=[d(16)], policy_net=[d(16)]))
+    mgr = NeuralNetworkManager(cfg.training, h, g, f)
+    wins, R, V, isw = _windows(4)
+    Z = _z_targets(R, V)
+    want = _reference_style_loss(mgr, wins, Z, R, isw)
+    for n in (h, g, f):
+        n.zero_grad()
+    want.backward()
+    params = [p for n in (h, g, f) for p in n.parameters()]
+    want_grads = [p.grad.clone() for p in params]
+    for n in (h, g, f):
+        n.zero_grad()
+    batch = windows_to_batch(wins, Z, R, isw, h.history_length, LOOKBACK, W)
+    wsum, per_window, _ = batched_unroll_loss(h, g, f, batch, W)
+    got = wsum / batch.is_weights.sum()
+    got.backward()
+    assert abs(got.item() - want.item()) <= 2e-5 * abs(want.item())
+    for p, wg in zip(params, want_grads):
+        torch.testing.assert_close(p.grad, wg, rtol=2e-3, atol=2e-5)
+    assert all("forward" not in m.__dict__ for n in (h, g, f) for m in n.modules())
