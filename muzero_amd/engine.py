@@ -219,16 +219,27 @@ class BatchedMCTS:
         self.stamps = None  # set to an int64[32] device tensor to collect per-stage cycle counts
         self.tree_base = (torch.arange(G, **i32) * self.pool.cap)
         self.arange_a = torch.arange(A, **i32)
+        # networks evaluated by several kernels per call (residual towers) run f next to the part of g
+        # that does not need f's result, on a second stream
+        self.side = torch.cuda.Stream(device=dev) if getattr(nets, "concurrent", False) and dev.type == "cuda" else None
 
     def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor) -> None:
         """expand_node (src/search/expansion.py:9-35) for one node per tree."""
         pool, nets, G, A = self.pool, self.nets, self.G, self.A
         rows = self.tree_base + node
-        nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
         rows_rep = rows.repeat_interleave(A)
         next_rows = ((self.tree_base + pool.n_nodes)[:, None] + self.arange_a[None, :]).reshape(-1).contiguous()
+        main = torch.cuda.current_stream()
+        if self.side is not None:  # the priors and the children both depend on the leaf only
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
+        else:
+            nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
         nets.dynamics(pool.latent, G * A, rows=rows_rep, action=None, next_latent=pool.latent, next_rows=next_rows,
                       reward=self.reward)
+        if self.side is not None:
+            main.wait_stream(self.side)
         pool.expand_commit(node, self.prior, self.reward, rand_child, out_child)
 
     def _simulate(self, child: torch.Tensor) -> torch.Tensor:
@@ -236,10 +247,19 @@ class BatchedMCTS:
         returns rollout f32[G, depth+1]."""
         pool, nets, G = self.pool, self.nets, self.G
         cur, rows = pool.latent, self.tree_base + child
+        main = torch.cuda.current_stream()
         for d in range(self.depth):
-            nets.prediction(cur, G, rows=rows, argmax=self.act)
             nxt = self.tmp[d & 1]
-            nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d])
+            if self.side is not None:  # fc_merge's latent half needs no action: it runs next to f
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    nets.prediction(cur, G, rows=rows, argmax=self.act)
+                base = nets.merge_rows(cur, G, rows=rows)
+                main.wait_stream(self.side)
+                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], base=base)
+            else:
+                nets.prediction(cur, G, rows=rows, argmax=self.act)
+                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d])
             cur, rows = nxt, None
         nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth])
         return self.rollout_t.t().contiguous()

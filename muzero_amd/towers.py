@@ -55,7 +55,8 @@ class TowerNetworks:
     `wide_above`: heads whose input is wider than this use the chunked wide-layer kernel for
     their first layer (the LDS-resident MLP kernels hold rows of at most 4096 floats)."""
 
-    fusable = False  # no single-launch search for these networks: BatchedMCTS runs in lock step
+    fusable = False     # no single-launch search for these networks: BatchedMCTS runs in lock step
+    concurrent = True   # f and the fc_merge product of g may run on two streams (scratch is per stream)
 
     def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096):
         self.device = torch.device(device)
@@ -190,6 +191,8 @@ class TowerNetworks:
 
     # ---- scratch ----------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        """Scratch tensor, one per (name, current stream): calls on different streams never share it."""
+        name = (name, _stream())
         t = self._bufs.get(name)
         n = 1
         for s in shape:
@@ -237,8 +240,15 @@ class TowerNetworks:
                    "mz_tower_forward")
 
     # ---- batched g / f (same calls as PackedNetworks) -----------------------------------------
+    def merge_rows(self, latent, B, *, ld=None, rows=None) -> torch.Tensor:
+        """fc_merge's latent half for B rows (needs no action): pass the result to
+        `dynamics(..., action=..., base=...)` to overlap it with the f call that picks the action."""
+        base = self._buf("merge_base", (B, self.D))
+        self._wide(self.merge, latent, ld or self.D, rows, base, B)
+        return base
+
     def dynamics(self, latent, B, *, ld=None, rows=None, action=None, next_latent=None, ld_next=None, next_rows=None,
-                 reward=None) -> None:
+                 reward=None, base=None) -> None:
         """action None: the expansion pattern -- consecutive groups of A rows share one latent and
         take actions 0..A-1; each group is one call of the reference (shared batch statistics).
         action i32[B]: B independent calls of batch size 1."""
@@ -253,8 +263,8 @@ class TowerNetworks:
             self._wide(self.merge, latent, ld, base_rows, base, U)
             x_rows, row_sel, group = self._group_index(B, A), None, A
         else:
-            base = self._buf("merge_base", (B, D))
-            self._wide(self.merge, latent, ld, rows, base, B)
+            if base is None:
+                base = self.merge_rows(latent, B, ld=ld, rows=rows)
             x_rows, row_sel, group = None, action, 1
         if next_latent is None:
             next_latent, ld_next, next_rows = self._buf("g_next", (B, D)), D, None
