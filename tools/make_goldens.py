@@ -440,8 +440,71 @@ def make_towers():
     print("towers.npz ok")
 
 
+# ----------------------------------------------------------------------------------------
+# the same single-game self-play + learner with BatchNorm everywhere: convolutional h with a
+# residual block, residual-tower g / f
+# ----------------------------------------------------------------------------------------
+from make_goldens_shapes import tower_selfplay_nets  # noqa: E402
+
+
+def make_selfplay_towers():
+    from oracle.c4 import C4Env
+    from src.replay_buffer import ReplayBuffer as RefReplay
+    from src.training import NeuralNetworkManager as RefManager
+    from src.training_data_generator import TrainingDataGenerator as RefGen
+
+    out = {}
+    torch.manual_seed(21)
+    h, g, f = tower_selfplay_nets(RefH, RefG, RefF, rcfg)
+    with torch.no_grad():
+        for net in (h, g, f):
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+    for tag, net in (("h", h), ("g", g), ("f", f)):
+        out.update(sd_arrays(f"init_{tag}.", net))
+    gen_cfg = rcfg.TrainingDataGeneratorConfig(
+        num_episodes=3, max_steps_per_episode=8, total_time=0, epsilon=0.5, epsilon_decay=1.0, min_epsilon=0.25,
+        mcts=rcfg.MCTSConfig(selection_strategy="puct", max_iterations=10, max_time=0, model_look_ahead=1,
+                             discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
+    random.seed(6)
+    np.random.seed(6)
+    torch.manual_seed(6)
+    with torch.no_grad():
+        episodes = RefGen(C4Env(), h, g, f, gen_cfg).generate_training_data(training_steps=0)
+    out["n_episodes"] = np.int32(len(episodes))
+    for e, ep in enumerate(episodes):
+        out[f"ep{e}_state"] = np.stack([c.state.numpy()[0] for c in ep.chunks])
+        out[f"ep{e}_policy"] = np.stack([c.policy.numpy() for c in ep.chunks])
+        out[f"ep{e}_reward"] = np.array([c.reward for c in ep.chunks], np.float64)
+        out[f"ep{e}_value"] = np.array([c.value for c in ep.chunks], np.float64)
+        out[f"ep{e}_action"] = np.array([c.best_action for c in ep.chunks], np.int64)
+    # self-play mutated the running statistics: the learner starts from the networks as they are now
+    for tag, net in (("h", h), ("g", g), ("f", f)):
+        out.update(sd_arrays(f"played_{tag}.", net))
+    tcfg = rcfg.TrainingConfig(
+        learning_rate=0.01, weight_decay=1e-4, batch_size=3, replay_buffer_size=8, alpha=0.6, discount_factor=0.9,
+        epochs=1, betas=(0.9, 0.999), roll_ahead=2, look_back=2, mini_batch_size=3, reward_coefficient=1.0,
+        value_coefficient=0.5, policy_coefficient=0.25, min_learning_rate=0.0, total_training_steps=10,
+        lr_schedule="cosine", optimizer="sgd", momentum=0.9)
+    random.seed(10)
+    np.random.seed(10)
+    rb = RefReplay(buffer_size=8, batch_size=3, alpha=0.6, beta=1.0)
+    rb.add_episodes(episodes)
+    mgr = RefManager(tcfg, h, g, f)
+    last = mgr.train(rb)
+    out["learner_losses"] = np.array(mgr.loss_history, np.float64)
+    out["learner_last"] = np.float64(last)
+    out["learner_priorities"] = np.array([p for _, p in rb.episode_buffer], np.float64)
+    for tag, net in (("h", h), ("g", g), ("f", f)):
+        out.update(sd_arrays(f"trained_{tag}.", net))
+    np.savez_compressed(os.path.join(OUT, "selfplay_towers.npz"), **out)
+    print("selfplay_towers.npz ok:", [len(ep.chunks) for ep in episodes], mgr.loss_history)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay", "towers"]
+    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay", "towers", "selfplay_towers"]
     if "trees" in which:
         make_trees()
     if "c4" in which:
@@ -452,3 +515,5 @@ if __name__ == "__main__":
         make_selfplay_and_learner()
     if "towers" in which:
         make_towers()
+    if "selfplay_towers" in which:
+        make_selfplay_towers()
