@@ -260,3 +260,46 @@ def test_actor_store_learner_loop_on_device():
     with torch.no_grad():
         want = torch.softmax(f(lat.reshape(G, 4, 6, 7))[0], dim=1)
     torch.testing.assert_close(pol_new, want, rtol=1e-5, atol=2e-6)
+
+
+def test_validation_rollout_matches_reference():
+    """model_simulation (src/inference.py:20-87): a greedy episode with the real actions in the
+    history ring, global RNGs seeded as the reference's runs."""
+    from muzero_amd.config import DenseLayerConfig as D, DynamicsNetworkConfig, MCTSConfig, PredictionNetworkConfig, \
+        RepresentationNetworkConfig
+    from muzero_amd.inference import model_simulation
+    from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork, RepresentationNetwork
+    from oracle.c4 import C4Env
+    z = np.load(os.path.join(GOLDEN, "validation.npz"))
+    torch.manual_seed(0)
+    h = RepresentationNetwork((2, 6, 7), (4, 6, 7), RepresentationNetworkConfig(history_length=3, downsample=[], res_net=[]))
+    g = DynamicsNetwork((4, 6, 7), 7, DynamicsNetworkConfig(res_net=[], reward_net=[D(out_features=128)]))
+    f = PredictionNetwork((4, 6, 7), 7, PredictionNetworkConfig(
+        res_net=[], value_net=[D(out_features=256), D(out_features=128)], policy_net=[D(out_features=256), D(out_features=256)]))
+    cfg = MCTSConfig(selection_strategy="puct", max_iterations=16, max_time=0, model_look_ahead=1,
+                     discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25)
+
+    class Recording(C4Env):
+        def __init__(self):
+            super().__init__()
+            self.actions, self.rewards = [], []
+
+        def step(self, action):
+            res = super().step(action)
+            self.actions.append(int(action))
+            self.rewards.append(float(res[1]))
+            return res
+
+    for ri in range(int(z["n_runs"])):
+        env = Recording()
+        seed = int(z[f"run{ri}_seed"])
+        random.seed(seed)
+        torch.manual_seed(seed)
+        total = model_simulation(env, h, g, f, 30, cfg, device="cpu", human_mode=False)
+        want = z[f"run{ri}_actions"].tolist()
+        # a near-tie in the search policy may flip one arg-max; everything before it must agree
+        same = next((i for i, (a, b) in enumerate(zip(env.actions, want)) if a != b), min(len(want), len(env.actions)))
+        assert same >= len(want) - 2, f"run {ri}: actions diverge at move {same}: {env.actions} vs {want}"
+        if env.actions == want:
+            assert env.rewards == z[f"run{ri}_rewards"].tolist()
+            assert total == float(z[f"run{ri}_total"])

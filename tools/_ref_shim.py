@@ -2,7 +2,7 @@
 
 Only used by tools/make_goldens.py (golden-vector generation).  It registers empty
 stand-in modules for third-party packages the reference imports at module scope but
-that this container lacks (pygame, wandb, gym, gymnasium, pettingzoo,
+that this container lacks (pygame, imageio, wandb, gym, gymnasium, pettingzoo,
 flappy_bird_gymnasium), back-fills enum.StrEnum for Python 3.10 and puts the reference
 checkout on sys.path.  Nothing here is shipped to, or usable on, the GPU box.
 """
@@ -32,6 +32,7 @@ def install() -> None:
             pass
 
     stub("pygame")
+    stub("imageio", mimsave=lambda *a, **k: None)
     stub("wandb", log=lambda *a, **k: None, init=lambda *a, **k: None, finish=lambda *a, **k: None)
     stub("gym"); stub("gym.envs"); stub("gym.envs.box2d")
     stub("gym.envs.box2d.car_racing", CarRacing=_Dummy)

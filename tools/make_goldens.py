@@ -503,8 +503,53 @@ def make_selfplay_towers():
     print("selfplay_towers.npz ok:", [len(ep.chunks) for ep in episodes], mgr.loss_history)
 
 
+# ----------------------------------------------------------------------------------------
+# validation rollout (src/inference.py): greedy episode with real actions in the history
+# ----------------------------------------------------------------------------------------
+def make_validation():
+    from oracle.c4 import C4Env
+    from src.inference import model_simulation as ref_simulation
+
+    out = {}
+    A = 7
+    h, g, f = build_ref_nets((2, 6, 7), (4, 6, 7), A, 3, [128], [256, 128], [256, 256], seed=0)
+    out["weights_sha256"] = np.array(sd_hash(h, g, f))
+    cfg = rcfg.MCTSConfig(selection_strategy="puct", max_iterations=16, max_time=0, model_look_ahead=1,
+                          discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25)
+
+    class Recording(C4Env):
+        def __init__(self):
+            super().__init__()
+            self.actions, self.rewards = [], []
+
+        def step(self, action):
+            res = super().step(action)
+            self.actions.append(int(action))
+            self.rewards.append(float(res[1]))
+            return res
+
+        def render(self):
+            return None
+
+    for ri, seed in enumerate((3, 4)):
+        env = Recording()
+        random.seed(seed)
+        torch.manual_seed(seed)
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            total = ref_simulation(env, h, g, f, 30, cfg, device="cpu", human_mode=False,
+                                   video_path=os.path.join(tmp, "v.mp4"))
+        out[f"run{ri}_seed"] = np.int32(seed)
+        out[f"run{ri}_actions"] = np.array(env.actions, np.int64)
+        out[f"run{ri}_rewards"] = np.array(env.rewards, np.float64)
+        out[f"run{ri}_total"] = np.float64(total)
+    out["n_runs"] = np.int32(2)
+    np.savez_compressed(os.path.join(OUT, "validation.npz"), **out)
+    print("validation.npz ok:", [out[f"run{r}_actions"].tolist() for r in range(2)])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay", "towers", "selfplay_towers"]
+    which = sys.argv[1:] or ["trees", "c4", "data", "selfplay", "towers", "selfplay_towers", "validation"]
     if "trees" in which:
         make_trees()
     if "c4" in which:
@@ -517,3 +562,5 @@ if __name__ == "__main__":
         make_towers()
     if "selfplay_towers" in which:
         make_selfplay_towers()
+    if "validation" in which:
+        make_validation()
