@@ -356,10 +356,16 @@ typedef struct mz_tower {
  * running statistics are not updated (nothing on the search path reads them).
  * Input: x_r = x[x_rows[r]] (gather optional); with row_add != NULL the fc_merge split is
  * applied while loading, x_r = relu(x[x_rows[r]] + row_add[row_sel[r]]) (row_sel NULL: r % group).
- * y_rows NULL: row r; negative entries are skipped. */
+ * y_rows NULL: row r; negative entries are skipped.
+ * t_out (optional, row stride ld_t, same row scatter as y): the last block's output, i.e. the
+ * input of res_final, [last out_channels][H][W] per row.  res_final is linear, so a consumer
+ * whose first operation on the latent is linear as well (fc_merge, the first Linear of a head)
+ * can be evaluated on these few values with pre-multiplied weights instead of on the C*H*W
+ * latent.  y may be NULL when only t_out is wanted. */
 int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
                      const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
-                     int64_t ldy, const int32_t *y_rows, int32_t B, int32_t group, void *stream);
+                     int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B,
+                     int32_t group, void *stream);
 
 /* table[a][:] = fc_merge.weight[:, D:] @ action_embedding[a] + fc_merge.bias for a < A
  * (f32[A][D]): the per-action half of fc_merge, neural_network.py:168-172. */

@@ -132,7 +132,7 @@ _SIGS = {
     "mz_wide_forward": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P,
                                   C.c_int64, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
-                                   C.c_int32, C.c_int32, _P]),
+                                   _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "mz_policy_post": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
 }

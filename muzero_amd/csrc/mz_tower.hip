@@ -423,7 +423,8 @@ __device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int 
 __global__ void __launch_bounds__(kTT)
 k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
         const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
-        float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, int group) {
+        float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, float *__restrict__ t_out,
+        long long ld_t, int group) {
     extern __shared__ __align__(16) float smem[];
     lds_f *S = to_lds(smem);
     lds_f *cur = S + G.off_a, *mid = S + G.off_b, *aux = S + G.off_c, *red = S + G.off_red, *stage = S + G.off_stage;
@@ -610,6 +611,16 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     MZ_TT(8)
     const int Cl = T.n_blocks ? T.block[T.n_blocks - 1].out_channels : G.C;
     const int wv = tid >> 6;
+    // the last block's output (the input of res_final), same row scatter as y
+    if (t_out != nullptr && T.n_blocks) {
+        for (int i = tid; i < Cl * P; i += kTT) {
+            const int ci = i / P, p = i - ci * P;
+            const int r = p / HW, s = p - r * HW;
+            const long long dr = y_rows ? (long long)y_rows[r0 + r] : (long long)(r0 + r);
+            if (dr >= 0) t_out[dr * ld_t + ci * HW + s] = cur[i];
+        }
+    }
+    if (y == nullptr) return;
     // res_final's weights and bias, one row of `fs` floats per output channel (bias last)
     const int fs = Cl <= 3 ? 4 : Cl + 1;
     lds_f *wfin = stage;
@@ -810,20 +821,26 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
 
 int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
                      const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
-                     int64_t ldy, const int32_t *y_rows, int32_t B, int32_t group, void *stream) {
+                     int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B, int32_t group,
+                     void *stream) {
     TowerGeom g;
     size_t lds = 0;
     MZ_TRY(tower_geometry(h_tower, group, &g, &lds));
     const int D = g.C * g.HW;
-    if (!x || !y || B < 0 || ldx < D || ldy < D || (row_add && ld_add < D))
+    if (!x || (!y && !t_out) || B < 0 || ldx < D || (y && ldy < D) || (row_add && ld_add < D))
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: NULL argument, negative B or a row stride below C*H*W=%d", D);
+    if (t_out) {
+        if (!h_tower->n_blocks) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: t_out needs at least one block");
+        const int dt = h_tower->block[h_tower->n_blocks - 1].out_channels * g.HW;
+        if (ld_t < dt) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: ld_t below the last block's %d values per row", dt);
+    }
     if (B % group) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: B=%d is not a multiple of group=%d", B, group);
     if (B == 0) return MZ_OK;
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     g.vec_ok = g.HW % 4 == 0 && ldx % 4 == 0 && aligned(x) && (!row_add || (ld_add % 4 == 0 && aligned(row_add)));
     MZ_TRY(allow_lds(k_tower, lds, "k_tower"));
     hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
-                       x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, group);
+                       x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, t_out, (long long)ld_t, group);
     return mz::check_launch("k_tower");
 }
 

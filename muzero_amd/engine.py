@@ -222,9 +222,15 @@ class BatchedMCTS:
         # networks evaluated by several kernels per call (residual towers) run f next to the part of g
         # that does not need f's result, on a second stream
         self.side = torch.cuda.Stream(device=dev) if getattr(nets, "concurrent", False) and dev.type == "cuda" else None
+        # networks whose latents are an affine image of a few values (see muzero_amd.towers) keep those
+        # values for every node next to the latent
+        dt = getattr(nets, "bottleneck_g", 0)
+        self.t_pool = torch.zeros((G * self.pool.cap, dt), **f32) if dt else None
+        self.tmp_t = [torch.zeros((G, dt), **f32) for _ in range(2)] if dt else None
 
-    def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor) -> None:
-        """expand_node (src/search/expansion.py:9-35) for one node per tree."""
+    def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor, root: bool = False) -> None:
+        """expand_node (src/search/expansion.py:9-35) for one node per tree (`root`: the nodes are
+        the roots, whose latents come from h and have no stored bottleneck values)."""
         pool, nets, G, A = self.pool, self.nets, self.G, self.A
         rows = self.tree_base + node
         rows_rep = rows.repeat_interleave(A)
@@ -236,8 +242,11 @@ class BatchedMCTS:
                 nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
         else:
             nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
+        extra = {}
+        if self.t_pool is not None:
+            extra = dict(t_in=None if root else (self.t_pool, rows_rep), t_out=self.t_pool)
         nets.dynamics(pool.latent, G * A, rows=rows_rep, action=None, next_latent=pool.latent, next_rows=next_rows,
-                      reward=self.reward)
+                      reward=self.reward, **extra)
         if self.side is not None:
             main.wait_stream(self.side)
         pool.expand_commit(node, self.prior, self.reward, rand_child, out_child)
@@ -248,19 +257,24 @@ class BatchedMCTS:
         pool, nets, G = self.pool, self.nets, self.G
         cur, rows = pool.latent, self.tree_base + child
         main = torch.cuda.current_stream()
+        t_in = (self.t_pool, rows) if self.t_pool is not None else None
         for d in range(self.depth):
             nxt = self.tmp[d & 1]
+            extra = dict(t_in=t_in, t_out=self.tmp_t[d & 1]) if self.t_pool is not None else {}
             if self.side is not None:  # fc_merge's latent half needs no action: it runs next to f
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
                     nets.prediction(cur, G, rows=rows, argmax=self.act)
-                base = nets.merge_rows(cur, G, rows=rows)
+                base = nets.merge_rows(cur, G, rows=rows, **({"t_in": t_in} if t_in is not None else {}))
                 main.wait_stream(self.side)
-                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], base=base)
+                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], base=base,
+                              **extra)
             else:
                 nets.prediction(cur, G, rows=rows, argmax=self.act)
-                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d])
+                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], **extra)
             cur, rows = nxt, None
+            if self.t_pool is not None:
+                t_in = (self.tmp_t[d & 1], None)
         nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth])
         return self.rollout_t.t().contiguous()
 
@@ -271,7 +285,7 @@ class BatchedMCTS:
         pool = self.pool
         pool.init(root_to_play, root_latent.reshape(self.G, self.D).contiguous())
         self.leaf.zero_()
-        self._expand(self.leaf, rand_root.reshape(self.G).contiguous(), self.child)
+        self._expand(self.leaf, rand_root.reshape(self.G).contiguous(), self.child, root=True)
         pool.root_noise(eta.contiguous(), self.noise_frac)
 
     def advance(self, rand_child: torch.Tensor, trace: dict | None = None) -> None:

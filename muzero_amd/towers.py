@@ -15,6 +15,15 @@ src/neural_networks/neural_network.py:152-188 (g) and :234-262 (f):
 * heads: the first Linear of a head reads D inputs (`mz_wide_forward` when D exceeds the
   LDS-resident MLP kernels' width, else the whole head goes through `mz_mlp_forward`).
 
+Bottleneck form.  In every shipped configuration the towers end in a narrow block (3 channels)
+followed by `res_final`, a 1x1 convolution back to 256 channels: a latent produced by g is an
+affine image `F t + b` of the block output t (3 x 6 x 6 = 108 values).  Whatever consumes a latent
+linearly first -- fc_merge's latent half, the first Linear of a head -- is therefore evaluated on
+t with weights multiplied by F once per weight update (`W F`, `W b` folded into the bias): the
+9216 x 9216 product per row becomes 9216 x 108.  Exact up to float32 rounding.  The search keeps t
+for every non-root node next to its latent (`bottleneck_g` values per node); callers that have
+no t (the root, the drop-in `expand_node`) use the plain form.
+
 There is no CPU fallback: every call goes through libmuzero_hip.so.
 """
 from __future__ import annotations
@@ -147,8 +156,8 @@ class TowerNetworks:
             nonlocal off
             m = _hip.Mlp()
             m.n_layers = len(layers)
-            for i, (lin, act) in enumerate(layers):
-                m.layer[i] = self._dense(lin, act)
+            for i, entry in enumerate(layers):
+                m.layer[i] = entry if isinstance(entry, _hip.Dense) else self._dense(*entry)
             pm = _hip.PackedMlp()
             n = lib.mz_mlp_plan(C.byref(m), off, C.byref(pm))
             if n < 0:
@@ -177,6 +186,51 @@ class TowerNetworks:
         self.reward_head = plan_head(g.reward_mlp)
         self.value_head = plan_head(f.value_mlp)
         self.policy_head = plan_head(f.policy_mlp)
+        # ---- bottleneck form: consumers of a latent that is res_final(t), evaluated on t
+        def bottleneck(net):
+            """(Cl, Wf [C, Cl] f64, bf [C] f64) when the tower ends in a narrowing res_final, else None."""
+            fin = net.res_final
+            if isinstance(fin, torch.nn.Identity) or len(net.res_blocks) == 0:
+                return None
+            Cl = fin.in_channels
+            dt = Cl * self.shape[1] * self.shape[2]
+            if dt >= D or dt > 4096:
+                return None
+            wf = fin.weight.detach().to(self.device, torch.float64).reshape(fin.out_channels, Cl)
+            bf = (fin.bias.detach().to(self.device, torch.float64) if fin.bias is not None
+                  else torch.zeros(fin.out_channels, dtype=torch.float64, device=self.device))
+            return Cl, wf, bf
+
+        def through(w: torch.Tensor, bias, bn):
+            """Weights [N, D] and bias of a Linear on res_final(t) -> weights [N, Cl*HW] and bias on t."""
+            Cl, wf, bf = bn
+            hw = self.shape[1] * self.shape[2]
+            w3 = w.detach().to(self.device, torch.float64).reshape(w.shape[0], self.shape[0], hw)
+            wt = torch.einsum("ncp,cj->njp", w3, wf).reshape(w.shape[0], Cl * hw)
+            bt = torch.einsum("ncp,c->n", w3, bf)
+            if bias is not None:
+                bt = bt + bias.detach().to(self.device, torch.float64)
+            return self._dev(wt.to(torch.float32)), self._dev(bt.to(torch.float32))
+
+        def head_on_t(seq, bn):
+            layers = self._layers(seq)
+            lin, act = layers[0]
+            wt, bt = through(lin.weight, lin.bias, bn)
+            first = _hip.Dense(ptr(wt), ptr(bt), wt.shape[1], wt.shape[0], _hip.ACT[act], 0)
+            return plan_mlp([first] + layers[1:])
+
+        bn_g, bn_f = bottleneck(g), bottleneck(f)
+        self.bottleneck_g = bn_g[0] * self.shape[1] * self.shape[2] if bn_g else 0
+        self.bottleneck_f = bn_f[0] * self.shape[1] * self.shape[2] if bn_f else 0
+        self.merge_t = self.reward_t = self.value_t = self.policy_t = None
+        merge_const = None
+        if bn_g:
+            wt, merge_const = through(g.fc_merge.weight[:, :D], None, bn_g)
+            self.merge_t = plan_wide(_hip.Dense(ptr(wt), None, wt.shape[1], D, _hip.ACT["none"], 0))
+            self.reward_t = head_on_t(g.reward_mlp, bn_g)
+        if bn_f:
+            self.value_t = head_on_t(f.value_mlp, bn_f)
+            self.policy_t = head_on_t(f.policy_mlp, bn_f)
         if self.blob is None or self.blob.numel() != off:
             self.blob = torch.empty(off, dtype=torch.float32, device=self.device)
         for kind, src, pl in plans:
@@ -188,6 +242,8 @@ class TowerNetworks:
         _hip.check(lib.mz_action_table(ptr(self._dev(g.action_embedding.weight)), ptr(self._dev(g.fc_merge.weight)),
                                        ptr(self._dev(g.fc_merge.bias)) if g.fc_merge.bias is not None else None,
                                        D, A, ptr(self.table), _stream()), "mz_action_table")
+        # per-action table of the bottleneck form: the constant part W b of the folded res_final included
+        self.table_t = (self.table + merge_const[None, :]).contiguous() if merge_const is not None else None
 
     # ---- scratch ----------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
@@ -234,56 +290,95 @@ class TowerNetworks:
                        "mz_policy_post")
         return out
 
-    def _tower_call(self, tower, x, ldx, x_rows, row_add, row_sel, y, ldy, y_rows, B, group) -> None:
+    def _tower_call(self, tower, x, ldx, x_rows, row_add, row_sel, y, ldy, y_rows, B, group, t_out=None) -> None:
         _hip.check(_hip.lib().mz_tower_forward(C.byref(tower), ptr(x), ldx, ptr(x_rows), ptr(row_add), self.D,
-                                               ptr(row_sel), ptr(y), ldy, ptr(y_rows), B, group, _stream()),
+                                               ptr(row_sel), ptr(y), ldy, ptr(y_rows), ptr(t_out),
+                                               t_out.shape[-1] if t_out is not None else 0, B, group, _stream()),
                    "mz_tower_forward")
 
+    def _mlp_on(self, plan, name: str, x, ldx, x_rows, B) -> torch.Tensor:
+        out = self._buf(name + "_out", (B, plan.out_features))
+        _hip.check(_hip.lib().mz_mlp_forward(C.byref(plan), ptr(self.blob), ptr(x), ldx, ptr(x_rows), ptr(out),
+                                             plan.out_features, B, _stream()), "mz_mlp_forward")
+        return out
+
     # ---- batched g / f (same calls as PackedNetworks) -----------------------------------------
-    def merge_rows(self, latent, B, *, ld=None, rows=None) -> torch.Tensor:
+    def merge_rows(self, latent, B, *, ld=None, rows=None, t_in=None) -> torch.Tensor:
         """fc_merge's latent half for B rows (needs no action): pass the result to
-        `dynamics(..., action=..., base=...)` to overlap it with the f call that picks the action."""
+        `dynamics(..., action=..., base=...)` to overlap it with the f call that picks the action.
+        t_in = (t, rows): evaluate it on the bottleneck values of those latents instead."""
         base = self._buf("merge_base", (B, self.D))
-        self._wide(self.merge, latent, ld or self.D, rows, base, B)
+        if t_in is not None:
+            t, t_rows = t_in
+            self._wide(self.merge_t, t, t.shape[-1], t_rows, base, B)
+        else:
+            self._wide(self.merge, latent, ld or self.D, rows, base, B)
         return base
 
     def dynamics(self, latent, B, *, ld=None, rows=None, action=None, next_latent=None, ld_next=None, next_rows=None,
-                 reward=None, base=None) -> None:
+                 reward=None, base=None, t_in=None, t_out=None) -> None:
         """action None: the expansion pattern -- consecutive groups of A rows share one latent and
         take actions 0..A-1; each group is one call of the reference (shared batch statistics).
-        action i32[B]: B independent calls of batch size 1."""
+        action i32[B]: B independent calls of batch size 1.
+        Bottleneck form (only when `bottleneck_g` > 0): t_in = (t f32[*, bottleneck_g], rows) holds the
+        bottleneck values of the source latents (row index like `rows`; for the expansion pattern one
+        entry per group is read, `rows[::A]`); t_out f32[*, bottleneck_g] receives those of the results,
+        scattered by next_rows like next_latent."""
         D, A = self.D, self.A
         ld = ld or D
+        use_t = t_in is not None and self.merge_t is not None
         if action is None:
             assert B % A == 0, "expansion rows come in groups of A"
             U = B // A
-            base_rows = rows[::A].contiguous() if rows is not None else \
-                (torch.arange(U, dtype=torch.int32, device=self.device) * A)
-            base = self._buf("merge_base", (U, D))
-            self._wide(self.merge, latent, ld, base_rows, base, U)
+            if use_t:
+                t, t_rows = t_in
+                base = self.merge_rows(None, U, t_in=(t, t_rows[::A].contiguous() if t_rows is not None else
+                                                      torch.arange(U, dtype=torch.int32, device=self.device) * A))
+            else:
+                base_rows = rows[::A].contiguous() if rows is not None else \
+                    (torch.arange(U, dtype=torch.int32, device=self.device) * A)
+                base = self.merge_rows(latent, U, ld=ld, rows=base_rows)
             x_rows, row_sel, group = self._group_index(B, A), None, A
         else:
             if base is None:
-                base = self.merge_rows(latent, B, ld=ld, rows=rows)
+                base = self.merge_rows(latent, B, ld=ld, rows=rows, t_in=t_in if use_t else None)
+            else:
+                assert t_in is None or use_t
             x_rows, row_sel, group = None, action, 1
         if next_latent is None:
             next_latent, ld_next, next_rows = self._buf("g_next", (B, D)), D, None
         ld_next = ld_next or D
-        self._tower_call(self.tower_g, base, D, x_rows, self.table, row_sel, next_latent, ld_next, next_rows, B, group)
+        if t_out is not None and not self.bottleneck_g:
+            t_out = None
+        self._tower_call(self.tower_g, base, D, x_rows, self.table_t if use_t else self.table, row_sel, next_latent,
+                         ld_next, next_rows, B, group, t_out=t_out)
         if reward is not None:
-            out = self._head(self.reward_head, "reward", next_latent, ld_next, next_rows, B)
+            if t_out is not None and self.reward_t is not None:
+                out = self._mlp_on(self.reward_t, "reward_t", t_out, t_out.shape[-1], next_rows, B)
+            else:
+                out = self._head(self.reward_head, "reward", next_latent, ld_next, next_rows, B)
             reward.view(-1)[:B].copy_(out.view(-1))
 
     def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None) -> None:
         if policy is None and value is None and argmax is None:
             return
         D = self.D
-        t = self._buf("f_tower", (B, D))
-        self._tower_call(self.tower_f, latent, ld or D, rows, None, None, t, D, None, B, 1)
+        if self.bottleneck_f:
+            # f's own tower ends in res_final too: its heads read the block output directly
+            dt = self.bottleneck_f
+            t = self._buf("f_t", (B, dt))
+            self._tower_call(self.tower_f, latent, ld or D, rows, None, None, None, 0, None, B, 1, t_out=t)
+            head = lambda plan, name: self._mlp_on(plan, name, t, dt, None, B)  # noqa: E731
+            p_plan, v_plan = self.policy_t, self.value_t
+        else:
+            t = self._buf("f_tower", (B, D))
+            self._tower_call(self.tower_f, latent, ld or D, rows, None, None, t, D, None, B, 1)
+            head = lambda hd, name: self._head(hd, name, t, D, None, B)  # noqa: E731
+            p_plan, v_plan = self.policy_head, self.value_head
         if policy is not None or argmax is not None:
-            p = self._head(self.policy_head, "policy", t, D, None, B)
+            p = head(p_plan, "policy")
             _hip.check(_hip.lib().mz_policy_post(ptr(p), B, self.A, softmax_times, ptr(policy), ptr(argmax), _stream()),
                        "mz_policy_post")
         if value is not None:
-            v = self._head(self.value_head, "value", t, D, None, B)
+            v = head(v_plan, "value")
             value.view(-1)[:B].copy_(v.view(-1))

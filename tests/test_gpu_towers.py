@@ -139,12 +139,12 @@ def test_tower_rejects_what_it_cannot_hold():
     x = torch.zeros(8, nets.D, device="cuda")
     # B not a multiple of the group
     rc = lib.mz_tower_forward(C.byref(nets.tower_g), x.data_ptr(), nets.D, None, None, 0, None, x.data_ptr(), nets.D,
-                              None, 7, 3, None)
+                              None, None, 0, 7, 3, None)
     assert rc < 0 and b"multiple" in lib.mz_last_error()
     # one value per channel: torch raises for it too (BatchNorm2d in train mode)
     t1 = _hip.Tower.from_buffer_copy(nets.tower_g)
     t1.H = t1.W = 1
-    rc = lib.mz_tower_forward(C.byref(t1), x.data_ptr(), nets.D, None, None, 0, None, x.data_ptr(), nets.D, None, 4, 1, None)
+    rc = lib.mz_tower_forward(C.byref(t1), x.data_ptr(), nets.D, None, None, 0, None, x.data_ptr(), nets.D, None, None, 0, 4, 1, None)
     assert rc < 0 and b"more than 1 value" in lib.mz_last_error()
 
 

@@ -28,7 +28,7 @@ ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=
 def timed(name, tower, B, group, x_rows=None, row_add=None):
     def call():
         _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(x_rows), ptr(row_add), D, None, ptr(y), D, None,
-                                        B, group, st), name)
+                                        None, 0, B, group, st), name)
     call()
     ev0.record()
     for _ in range(10):
@@ -53,8 +53,8 @@ if hasattr(lib, "mz_debug_tower_stamps"):  # diagnostics build only
              "after bn2", "before res_final", "end"]
     for label, tower, B, group, rows, add in (("f tower", nets.tower_f, G, 1, None, None),
                                                ("g expansion", nets.tower_g, G * A, A, gidx, nets.table)):
-        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(rows), ptr(add), D, None, ptr(y), D, None, B,
-                                        group, st), label)
+        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(rows), ptr(add), D, None, ptr(y), D, None, None, 0,
+                                        B, group, st), label)
         torch.cuda.synchronize()
         h = np.zeros(16, np.uint64)
         lib.mz_debug_tower_stamps(h.ctypes.data_as(C.c_void_p))
