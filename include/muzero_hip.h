@@ -327,12 +327,16 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
 /* ResBlock (src/neural_networks/network_builder.py:73-151) with stride 1, padding
  * (kernel_size-1)/2 and no pooling -- the only form that keeps the latent's H x W, which g and f
  * require.  Weights are device pointers in torch layout: conv [out][in][k][k] without bias,
- * BatchNorm2d weight/bias [out]; down_w (1x1 conv [out][in]) and its BatchNorm are NULL when
- * in_channels == out_channels. */
+ * BatchNorm2d weight/bias [out]; down_w (1x1 conv [out][in]) and its BatchNorm are required when
+ * in_channels != out_channels and NULL for an identity skip.  conv1_bias (optional, [out][H][W]) is
+ * added to conv1's output before bn1: a block whose input is itself an affine image of fewer
+ * channels (the previous network's res_final) can be given pre-multiplied weights on those
+ * channels, and the folded bias then depends on the position because of the zero padding. */
 typedef struct mz_resblock {
     const float *conv1_w, *bn1_w, *bn1_b;
     const float *conv2_w, *bn2_w, *bn2_b;
     const float *down_w, *dbn_w, *dbn_b;
+    const float *conv1_bias;
     int32_t in_channels, out_channels, kernel_size, activation;
     float eps1, eps2, epsd, _pad;
 } mz_resblock;

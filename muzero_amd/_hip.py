@@ -82,7 +82,7 @@ MAX_BLOCKS = 4
 class ResBlock(C.Structure):
     _fields_ = [("conv1_w", C.c_void_p), ("bn1_w", C.c_void_p), ("bn1_b", C.c_void_p), ("conv2_w", C.c_void_p),
                 ("bn2_w", C.c_void_p), ("bn2_b", C.c_void_p), ("down_w", C.c_void_p), ("dbn_w", C.c_void_p),
-                ("dbn_b", C.c_void_p), ("in_channels", C.c_int32), ("out_channels", C.c_int32),
+                ("dbn_b", C.c_void_p), ("conv1_bias", C.c_void_p), ("in_channels", C.c_int32), ("out_channels", C.c_int32),
                 ("kernel_size", C.c_int32), ("activation", C.c_int32), ("eps1", C.c_float), ("eps2", C.c_float),
                 ("epsd", C.c_float), ("_pad", C.c_float)]
 

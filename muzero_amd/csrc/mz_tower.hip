@@ -506,13 +506,14 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 acc[o] = s;
             }
     };
-    // accumulator of lane 4b+j, element i = position (wave's first position) + 4b+i, channel co0+j
-    auto store_acc = [&](lds_f *dst, const f32x4 &acc, int co0, int Cout, int first_pos) {
+    // accumulator of lane 4b+j, element i = position (wave's first position) + 4b+i, channel co0+j;
+    // bias_map (optional) adds a per-(channel, position-in-image) constant
+    auto store_acc = [&](lds_f *dst, const f32x4 &acc, int co0, int Cout, int first_pos, const float *bias_map) {
         const int co = co0 + (lane & 3);
         if (co >= Cout) return;
         for (int i = 0; i < 4; ++i) {
             const int pos = first_pos + (lane & ~3) + i;
-            if (pos < P) dst[co * P + pos] = acc[i];
+            if (pos < P) dst[co * P + pos] = acc[i] + (bias_map ? bias_map[co * HW + pos % HW] : 0.0f);
         }
     };
 
@@ -559,8 +560,8 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                     if (down) reduce_slices(accd, 1, slot);
                 }
                 if (ksi == 0) {
-                    store_acc(mid, acc, co0, Cout, pb + pwi * 64);
-                    if (down) store_acc(aux, accd, co0, Cout, pb + pwi * 64);
+                    store_acc(mid, acc, co0, Cout, pb + pwi * 64, R.conv1_bias);
+                    if (down) store_acc(aux, accd, co0, Cout, pb + pwi * 64, nullptr);
                 }
             }
         }
@@ -587,7 +588,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                     __syncthreads();
                     reduce_slices(acc, 0, slot);
                 }
-                if (ksi == 0) store_acc(dst, acc, co0, Cout, pb + pwi * 64);
+                if (ksi == 0) store_acc(dst, acc, co0, Cout, pb + pwi * 64, nullptr);
             }
         }
         __syncthreads();
@@ -693,9 +694,9 @@ int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes
                             "kernel_size %d (must be odd)", b, R.in_channels, cin, R.out_channels, R.kernel_size);
         if (!R.conv1_w || !R.bn1_w || !R.bn1_b || !R.conv2_w || !R.bn2_w || !R.bn2_b)
             return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d has a NULL weight", b);
-        if ((R.in_channels != R.out_channels) != (R.down_w != nullptr) || (R.down_w && (!R.dbn_w || !R.dbn_b)))
-            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d: the 1x1 skip convolution must be given exactly "
-                            "when the channel count changes", b);
+        if ((R.in_channels != R.out_channels && !R.down_w) || (R.down_w && (!R.dbn_w || !R.dbn_b)))
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d: a 1x1 skip convolution with its BatchNorm is "
+                            "needed when the channel count changes", b);
         if (R.activation < MZ_ACT_NONE || R.activation > MZ_ACT_SIGMOID)
             return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block %d has unsupported activation %d", b, R.activation);
         g->cmax = std::max(g->cmax, R.out_channels);

@@ -236,12 +236,13 @@ class BatchedMCTS:
         rows_rep = rows.repeat_interleave(A)
         next_rows = ((self.tree_base + pool.n_nodes)[:, None] + self.arange_a[None, :]).reshape(-1).contiguous()
         main = torch.cuda.current_stream()
+        f_extra = {"t_in": (self.t_pool, rows)} if self.t_pool is not None and not root else {}
         if self.side is not None:  # the priors and the children both depend on the leaf only
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
+                nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior, **f_extra)
         else:
-            nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior)
+            nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior, **f_extra)
         extra = {}
         if self.t_pool is not None:
             extra = dict(t_in=None if root else (self.t_pool, rows_rep), t_out=self.t_pool)
@@ -261,21 +262,22 @@ class BatchedMCTS:
         for d in range(self.depth):
             nxt = self.tmp[d & 1]
             extra = dict(t_in=t_in, t_out=self.tmp_t[d & 1]) if self.t_pool is not None else {}
+            f_extra = {"t_in": t_in} if t_in is not None else {}
             if self.side is not None:  # fc_merge's latent half needs no action: it runs next to f
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
-                    nets.prediction(cur, G, rows=rows, argmax=self.act)
+                    nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
                 base = nets.merge_rows(cur, G, rows=rows, **({"t_in": t_in} if t_in is not None else {}))
                 main.wait_stream(self.side)
                 nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], base=base,
                               **extra)
             else:
-                nets.prediction(cur, G, rows=rows, argmax=self.act)
+                nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
                 nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], **extra)
             cur, rows = nxt, None
             if self.t_pool is not None:
                 t_in = (self.tmp_t[d & 1], None)
-        nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth])
+        nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth], **({"t_in": t_in} if t_in is not None else {}))
         return self.rollout_t.t().contiguous()
 
     def begin(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,

@@ -231,6 +231,28 @@ class TowerNetworks:
         if bn_f:
             self.value_t = head_on_t(f.value_mlp, bn_f)
             self.policy_t = head_on_t(f.policy_mlp, bn_f)
+        # f's first block read through g's res_final: conv1 and the 1x1 skip convolution of a latent
+        # F t + b are convolutions of t with weights pre-multiplied by F.  The folded bias of conv1
+        # depends on the position (taps outside the image contribute nothing) -> conv1_bias map; the
+        # constant the skip convolution picks up cancels in its BatchNorm.
+        self.tower_f_t = None
+        blk0 = f.res_blocks[0] if len(f.res_blocks) else None
+        if bn_g and bn_f and blk0 is not None and blk0.downsample is not None:
+            Cl, wf, bf = bn_g
+            c, hgt, wid = self.shape
+            wc = blk0.conv1.weight.detach().to(self.device, torch.float64)          # [o, C, k, k]
+            w1 = torch.einsum("ocyx,cj->ojyx", wc, wf).contiguous()                 # [o, Cl, k, k]
+            pad = blk0.conv1.padding[0]
+            bias_map = torch.nn.functional.conv2d(bf.view(1, c, 1, 1).expand(1, c, hgt, wid), wc, padding=pad)[0]
+            wd = blk0.downsample[0].weight.detach().to(self.device, torch.float64).reshape(-1, c) @ wf  # [o, Cl]
+            t = _hip.Tower.from_buffer_copy(self.tower_f)
+            t.C = Cl
+            b0 = t.block[0]
+            b0.in_channels = Cl
+            b0.conv1_w = ptr(self._dev(w1.to(torch.float32)))
+            b0.conv1_bias = ptr(self._dev(bias_map.to(torch.float32)))
+            b0.down_w = ptr(self._dev(wd.to(torch.float32)))
+            self.tower_f_t = t
         if self.blob is None or self.blob.numel() != off:
             self.blob = torch.empty(off, dtype=torch.float32, device=self.device)
         for kind, src, pl in plans:
@@ -359,7 +381,10 @@ class TowerNetworks:
                 out = self._head(self.reward_head, "reward", next_latent, ld_next, next_rows, B)
             reward.view(-1)[:B].copy_(out.view(-1))
 
-    def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None) -> None:
+    def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None,
+                   t_in=None) -> None:
+        """t_in = (t f32[*, bottleneck_g], rows): the bottleneck values of the latents (non-root nodes of
+        the search); f's first block then reads them instead of the latents."""
         if policy is None and value is None and argmax is None:
             return
         D = self.D
@@ -367,7 +392,11 @@ class TowerNetworks:
             # f's own tower ends in res_final too: its heads read the block output directly
             dt = self.bottleneck_f
             t = self._buf("f_t", (B, dt))
-            self._tower_call(self.tower_f, latent, ld or D, rows, None, None, None, 0, None, B, 1, t_out=t)
+            if t_in is not None and self.tower_f_t is not None:
+                src, src_rows = t_in
+                self._tower_call(self.tower_f_t, src, src.shape[-1], src_rows, None, None, None, 0, None, B, 1, t_out=t)
+            else:
+                self._tower_call(self.tower_f, latent, ld or D, rows, None, None, None, 0, None, B, 1, t_out=t)
             head = lambda plan, name: self._mlp_on(plan, name, t, dt, None, B)  # noqa: E731
             p_plan, v_plan = self.policy_t, self.value_t
         else:
