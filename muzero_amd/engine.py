@@ -225,6 +225,9 @@ class BatchedMCTS:
         # networks whose latents are an affine image of a few values (see muzero_amd.towers) keep those
         # values for every node next to the latent
         dt = getattr(nets, "bottleneck_g", 0)
+        self.use_graph = True
+        self._graph, self._graph_version = None, -1
+        self.rand_static = torch.zeros(G, **i32)
         self.t_pool = torch.zeros((G * self.pool.cap, dt), **f32) if dt else None
         self.tmp_t = [torch.zeros((G, dt), **f32) for _ in range(2)] if dt else None
 
@@ -290,20 +293,49 @@ class BatchedMCTS:
         self._expand(self.leaf, rand_root.reshape(self.G).contiguous(), self.child, root=True)
         pool.root_noise(eta.contiguous(), self.noise_frac)
 
+    def _step(self, rand_column: torch.Tensor) -> torch.Tensor:
+        """One `_step` (src/search/mcts.py:76-83) for every tree; returns the rollouts."""
+        self.pool.select(self.leaf)
+        self._expand(self.leaf, rand_column, self.child)
+        rollout = self._simulate(self.child)
+        self.pool.backup(self.child, self.leaf, rollout, self.discount)
+        return rollout
+
     def advance(self, rand_child: torch.Tensor, trace: dict | None = None) -> None:
-        """One `_step` (src/search/mcts.py:76-83) per column of rand_child i32[G, n]."""
-        pool = self.pool
+        """One `_step` per column of rand_child i32[G, n].
+
+        With networks evaluated by many small kernels (`nets.concurrent`) a step is some 45 launches
+        and, at a few hundred trees, bound by the launch rate: the step is captured once as a HIP
+        graph (both streams included) and replayed; only the column of child draws changes between
+        replays, through a fixed buffer.  Tracing runs the launches one by one."""
         rand_t = rand_child.t().contiguous()
-        for s in range(rand_t.shape[0]):
-            pool.select(self.leaf)
-            self._expand(self.leaf, rand_t[s], self.child)
-            rollout = self._simulate(self.child)
-            pool.backup(self.child, self.leaf, rollout, self.discount)
-            if trace is not None:
-                trace.setdefault("leaf", []).append(self.leaf.clone())
-                trace.setdefault("child", []).append(self.child.clone())
-                trace.setdefault("rollout", []).append(rollout.clone())
-                trace.setdefault("prior", []).append(self.prior.clone())
+        n = rand_t.shape[0]
+        use_graph = self.use_graph and trace is None and self.side is not None and n > 2
+        if not use_graph:
+            for s in range(n):
+                rollout = self._step(rand_t[s])
+                if trace is not None:
+                    trace.setdefault("leaf", []).append(self.leaf.clone())
+                    trace.setdefault("child", []).append(self.child.clone())
+                    trace.setdefault("rollout", []).append(rollout.clone())
+                    trace.setdefault("prior", []).append(self.prior.clone())
+            return
+        version = getattr(self.nets, "version", 0)
+        first = 0
+        if self._graph is None or self._graph_version != version:
+            # the first step runs launch by launch (it also creates every scratch buffer), the
+            # second is recorded
+            self._step(rand_t[0])
+            first = 1
+            self.rand_static.copy_(rand_t[1])
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step(self.rand_static)
+            self._graph, self._graph_version = graph, version
+        for s in range(first, n):
+            self.rand_static.copy_(rand_t[s])
+            self._graph.replay()
 
     def finish(self) -> SearchResult:
         return SearchResult(*self.pool.result())

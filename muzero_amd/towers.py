@@ -133,6 +133,7 @@ class TowerNetworks:
     def refresh(self) -> None:
         """Re-reads the modules' weights (call after a weight update)."""
         self._keep = []
+        self.version = getattr(self, "version", 0) + 1  # captured launch graphs hold the old buffers' addresses
         lib = _hip.lib()
         g, f = self.dynamics_net, self.prediction_net
         D, A = self.D, self.A

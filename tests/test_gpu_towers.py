@@ -432,3 +432,38 @@ def test_shipped_shape_matches_torch():
     close(rew, torch.cat([w[1] for w in want_g1])[:, 0])
     close(pol, torch.cat([w[0] for w in want_f]))
     close(val, torch.cat([w[1] for w in want_f])[:, 0])
+
+
+def test_graph_replay_equals_launch_by_launch():
+    """The captured simulation step (HIP graph, two streams) leaves the same pool, bit for bit, as
+    launching its kernels one by one -- also on a second search that reuses the recorded graph, and
+    after a weight refresh (which re-records it)."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    g, f, A, shape = load_tower_nets(0)
+    D = int(np.prod(shape))
+    nets = TowerNetworks(g, f)
+    G, S = 9, 14
+    rng = np.random.default_rng(5)
+
+    def inputs():
+        lat = torch.from_numpy(rng.standard_normal((G, D)).astype(np.float32)).cuda()
+        eta = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).cuda()
+        rand = torch.from_numpy(rng.integers(0, A, size=(G, S + 1)).astype(np.int32)).cuda()
+        return lat, torch.ones(G, dtype=torch.int8, device="cuda"), eta, rand
+
+    eager = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25)
+    eager.use_graph = False
+    graphed = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25)
+    for round_ in range(3):
+        if round_ == 2:
+            with torch.no_grad():
+                g.fc_merge.bias.add_(0.01)
+            nets.refresh()
+        args = inputs()
+        a, b = eager.run(*args), graphed.run(*args)
+        torch.cuda.synchronize()
+        assert graphed._graph is not None
+        for name in ("visit", "value_sum", "prior", "reward", "first_child", "latent"):
+            assert torch.equal(getattr(eager.pool, name), getattr(graphed.pool, name)), (round_, name)
+        assert torch.equal(a.policy, b.policy) and torch.equal(a.value, b.value) and torch.equal(a.visits, b.visits)
