@@ -232,6 +232,13 @@ WideShape wide_shape(const mz_packed_layer &L, int B) {
     // would run as few, deeply split workgroups of three chunks each; 64 x 64 tiles give four times
     // the workgroups at a quarter of the partial-sum traffic (measured: 37 -> 23 us at 256 x 9216 x 256)
     if (s.big && (long long)((B + 127) / 128) * ((L.Np + 127) / 128) < 12) s.big = false;
+    // a short reduction (the bottleneck form of fc_merge: K = 108) is all prologue and epilogue per
+    // workgroup: more, smaller workgroups hide that latency better
+    static const int short_k = [] {
+        const char *e = getenv("MZ_WIDE_SHORT_K");  // tuning aid: chunks at or below which 64 x 64 tiles are used
+        return e ? atoi(e) : 4;
+    }();
+    if (s.big && (((L.Kp >> 4) + 3) >> 2) <= short_k) s.big = false;
     s.tm = s.tn = s.big ? 128 : 64;
     s.tiles_m = (B + s.tm - 1) / s.tm;
     s.tiles_n = (L.Np + s.tn - 1) / s.tn;

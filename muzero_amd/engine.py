@@ -225,6 +225,10 @@ class BatchedMCTS:
         # networks whose latents are an affine image of a few values (see muzero_amd.towers) keep those
         # values for every node next to the latent
         dt = getattr(nets, "bottleneck_g", 0)
+        self.rollout = torch.zeros((G, self.depth + 1), **f32)   # [r_1 .. r_depth, v] per tree
+        self.rows_buf = [torch.zeros(G, **i32) for _ in range(2)]
+        self.next_rows_buf = torch.zeros((G, A), **i32)
+        self.child_slots = (self.tree_base[:, None] + self.arange_a[None, :]).contiguous()
         self.use_graph = True
         self._graph, self._graph_version = None, -1
         self.rand_static = torch.zeros(G, **i32)
@@ -235,9 +239,9 @@ class BatchedMCTS:
         """expand_node (src/search/expansion.py:9-35) for one node per tree (`root`: the nodes are
         the roots, whose latents come from h and have no stored bottleneck values)."""
         pool, nets, G, A = self.pool, self.nets, self.G, self.A
-        rows = self.tree_base + node
-        rows_rep = rows.repeat_interleave(A)
-        next_rows = ((self.tree_base + pool.n_nodes)[:, None] + self.arange_a[None, :]).reshape(-1).contiguous()
+        rows = torch.add(self.tree_base, node, out=self.rows_buf[0])
+        next_rows = torch.add(self.child_slots, pool.n_nodes[:, None], out=self.next_rows_buf).view(-1)
+        rows_rep = rows if getattr(nets, "strided_outputs", False) else rows.repeat_interleave(A)  # per group is enough there
         main = torch.cuda.current_stream()
         f_extra = {"t_in": (self.t_pool, rows)} if self.t_pool is not None and not root else {}
         if self.side is not None:  # the priors and the children both depend on the leaf only
@@ -248,7 +252,7 @@ class BatchedMCTS:
             nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior, **f_extra)
         extra = {}
         if self.t_pool is not None:
-            extra = dict(t_in=None if root else (self.t_pool, rows_rep), t_out=self.t_pool)
+            extra = dict(t_in=None if root else (self.t_pool, rows), t_out=self.t_pool)
         nets.dynamics(pool.latent, G * A, rows=rows_rep, action=None, next_latent=pool.latent, next_rows=next_rows,
                       reward=self.reward, **extra)
         if self.side is not None:
@@ -259,7 +263,9 @@ class BatchedMCTS:
         """MuZeroSimulation (src/search/simulation.py:23-45) from one node per tree;
         returns rollout f32[G, depth+1]."""
         pool, nets, G = self.pool, self.nets, self.G
-        cur, rows = pool.latent, self.tree_base + child
+        cur, rows = pool.latent, torch.add(self.tree_base, child, out=self.rows_buf[1])
+        strided = getattr(nets, "strided_outputs", False)  # heads write into the columns of self.rollout directly
+        out_col = (lambda d: self.rollout[:, d]) if strided else (lambda d: self.rollout_t[d])
         main = torch.cuda.current_stream()
         t_in = (self.t_pool, rows) if self.t_pool is not None else None
         for d in range(self.depth):
@@ -272,16 +278,15 @@ class BatchedMCTS:
                     nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
                 base = nets.merge_rows(cur, G, rows=rows, **({"t_in": t_in} if t_in is not None else {}))
                 main.wait_stream(self.side)
-                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], base=base,
-                              **extra)
+                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), base=base, **extra)
             else:
                 nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
-                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=self.rollout_t[d], **extra)
+                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), **extra)
             cur, rows = nxt, None
             if self.t_pool is not None:
                 t_in = (self.tmp_t[d & 1], None)
-        nets.prediction(cur, G, rows=rows, value=self.rollout_t[self.depth], **({"t_in": t_in} if t_in is not None else {}))
-        return self.rollout_t.t().contiguous()
+        nets.prediction(cur, G, rows=rows, value=out_col(self.depth), **({"t_in": t_in} if t_in is not None else {}))
+        return self.rollout if strided else self.rollout_t.t().contiguous()
 
     def begin(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
               rand_root: torch.Tensor) -> None:

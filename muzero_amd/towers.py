@@ -66,6 +66,7 @@ class TowerNetworks:
 
     fusable = False     # no single-launch search for these networks: BatchedMCTS runs in lock step
     concurrent = True   # f and the fc_merge product of g may run on two streams (scratch is per stream)
+    strided_outputs = True  # reward / value may be 1-D views with a stride (a column of a [G, n] buffer)
 
     def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096):
         self.device = torch.device(device)
@@ -319,11 +320,25 @@ class TowerNetworks:
                                                t_out.shape[-1] if t_out is not None else 0, B, group, _stream()),
                    "mz_tower_forward")
 
-    def _mlp_on(self, plan, name: str, x, ldx, x_rows, B) -> torch.Tensor:
-        out = self._buf(name + "_out", (B, plan.out_features))
-        _hip.check(_hip.lib().mz_mlp_forward(C.byref(plan), ptr(self.blob), ptr(x), ldx, ptr(x_rows), ptr(out),
-                                             plan.out_features, B, _stream()), "mz_mlp_forward")
-        return out
+    def _mlp_on(self, plan, name: str, x, ldx, x_rows, B, out=None):
+        """Head on bottleneck values.  `out`: one-output heads may write straight into the caller's
+        tensor (flat contiguous, or a 1-D view with a stride); returns None then."""
+        ldy = plan.out_features
+        direct = out is not None and plan.out_features == 1 and out.dtype == torch.float32
+        if direct:
+            ldy = 1 if out.is_contiguous() else (out.stride(0) if out.dim() == 1 else 0)
+            direct = ldy > 0
+        if not direct:
+            res = self._buf(name + "_out", (B, plan.out_features))
+            ldy = plan.out_features
+        _hip.check(_hip.lib().mz_mlp_forward(C.byref(plan), ptr(self.blob), ptr(x), ldx, ptr(x_rows),
+                                             ptr(out if direct else res), ldy, B, _stream()), "mz_mlp_forward")
+        if direct:
+            return None
+        if out is not None:
+            out.view(-1)[:B].copy_(res.view(-1))
+            return None
+        return res
 
     # ---- batched g / f (same calls as PackedNetworks) -----------------------------------------
     def merge_rows(self, latent, B, *, ld=None, rows=None, t_in=None) -> torch.Tensor:
@@ -353,14 +368,17 @@ class TowerNetworks:
         if action is None:
             assert B % A == 0, "expansion rows come in groups of A"
             U = B // A
+
+            def per_group(r):  # one source row per group: given as such (U entries) or repeated A times (B entries)
+                if r is None:
+                    return torch.arange(U, dtype=torch.int32, device=self.device) * A
+                return r if r.numel() == U else r[::A].contiguous()
+
             if use_t:
                 t, t_rows = t_in
-                base = self.merge_rows(None, U, t_in=(t, t_rows[::A].contiguous() if t_rows is not None else
-                                                      torch.arange(U, dtype=torch.int32, device=self.device) * A))
+                base = self.merge_rows(None, U, t_in=(t, per_group(t_rows)))
             else:
-                base_rows = rows[::A].contiguous() if rows is not None else \
-                    (torch.arange(U, dtype=torch.int32, device=self.device) * A)
-                base = self.merge_rows(latent, U, ld=ld, rows=base_rows)
+                base = self.merge_rows(latent, U, ld=ld, rows=per_group(rows))
             x_rows, row_sel, group = self._group_index(B, A), None, A
         else:
             if base is None:
@@ -377,10 +395,10 @@ class TowerNetworks:
                          ld_next, next_rows, B, group, t_out=t_out)
         if reward is not None:
             if t_out is not None and self.reward_t is not None:
-                out = self._mlp_on(self.reward_t, "reward_t", t_out, t_out.shape[-1], next_rows, B)
+                self._mlp_on(self.reward_t, "reward_t", t_out, t_out.shape[-1], next_rows, B, out=reward)
             else:
                 out = self._head(self.reward_head, "reward", next_latent, ld_next, next_rows, B)
-            reward.view(-1)[:B].copy_(out.view(-1))
+                (reward if reward.dim() == 1 else reward.view(-1)[:B]).copy_(out.view(-1))
 
     def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None,
                    t_in=None) -> None:
@@ -410,5 +428,8 @@ class TowerNetworks:
             _hip.check(_hip.lib().mz_policy_post(ptr(p), B, self.A, softmax_times, ptr(policy), ptr(argmax), _stream()),
                        "mz_policy_post")
         if value is not None:
-            v = head(v_plan, "value")
-            value.view(-1)[:B].copy_(v.view(-1))
+            if self.bottleneck_f:
+                self._mlp_on(v_plan, "value", t, dt, None, B, out=value)
+            else:
+                v = head(v_plan, "value")
+                (value if value.dim() == 1 else value.view(-1)[:B]).copy_(v.view(-1))
