@@ -456,32 +456,57 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     // channels are contiguous in memory (cn * HW floats), so the copy is coalesced.
     auto load_input = [&](lds_f *dst, int cb, int cn) {
         const int n = cn * HW;
+        if (G.vec_ok) {
+            // all rows of the call as one index space of 16-byte items, four items per thread in
+            // flight: the loads of a batch are issued before any of them is used
+            const int per_row = n >> 2, total = group * per_row;
+            constexpr int UN = 4;
+            for (int i0 = tid; i0 < total; i0 += kTT * UN) {
+                f32x4 v[UN], a[UN];
+                int item[UN];
+                bool has_add[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    item[u] = i0 + u * kTT;
+                    v[u] = a[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    has_add[u] = false;
+                    if (item[u] < total) {
+                        const int r = item[u] / per_row, j = (item[u] - r * per_row) << 2;
+                        const float *xr = src_row(r), *ar = add_row(r);
+                        if (xr) v[u] = *reinterpret_cast<const f32x4 *>(xr + cb * HW + j);
+                        if (ar) {
+                            a[u] = *reinterpret_cast<const f32x4 *>(ar + cb * HW + j);
+                            has_add[u] = true;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    if (item[u] >= total) continue;
+                    const int r = item[u] / per_row, j = (item[u] - r * per_row) << 2;
+                    f32x4 w = v[u];
+                    if (has_add[u]) {
+                        w.x = fmaxf(w.x + a[u].x, 0.0f);
+                        w.y = fmaxf(w.y + a[u].y, 0.0f);
+                        w.z = fmaxf(w.z + a[u].z, 0.0f);
+                        w.w = fmaxf(w.w + a[u].w, 0.0f);
+                    }
+                    const int c = j / HW, s = j - c * HW;  // HW % 4 == 0: the four share a channel
+                    *reinterpret_cast<lds_f4 *>(dst + r * HW + c * P + s) = w;
+                }
+            }
+            return;
+        }
         for (int r = 0; r < group; ++r) {
             const float *xr = src_row(r), *ar = add_row(r);
             if (xr) xr += cb * HW;
             if (ar) ar += cb * HW;
             lds_f *d = dst + r * HW;
-            if (G.vec_ok) {
-                for (int j = tid * 4; j < n; j += kTT * 4) {
-                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (xr) v = *reinterpret_cast<const f32x4 *>(xr + j);
-                    if (ar) {
-                        const f32x4 a = *reinterpret_cast<const f32x4 *>(ar + j);
-                        v.x = fmaxf(v.x + a.x, 0.0f);
-                        v.y = fmaxf(v.y + a.y, 0.0f);
-                        v.z = fmaxf(v.z + a.z, 0.0f);
-                        v.w = fmaxf(v.w + a.w, 0.0f);
-                    }
-                    const int c = j / HW, s = j - c * HW;  // HW % 4 == 0: the four share a channel
-                    *reinterpret_cast<lds_f4 *>(d + c * P + s) = v;
-                }
-            } else {
-                for (int j = tid; j < n; j += kTT) {
-                    float v = xr ? xr[j] : 0.0f;
-                    if (ar) v = fmaxf(v + ar[j], 0.0f);
-                    const int c = j / HW, s = j - c * HW;
-                    d[c * P + s] = v;
-                }
+            for (int j = tid; j < n; j += kTT) {
+                float v = xr ? xr[j] : 0.0f;
+                if (ar) v = fmaxf(v + ar[j], 0.0f);
+                const int c = j / HW, s = j - c * HW;
+                d[c * P + s] = v;
             }
         }
     };

@@ -199,7 +199,10 @@ class BatchedMCTS:
     """MCTS.run for G trees at once (PUCT selection, `max_iterations` mode)."""
 
     def __init__(self, nets: PackedNetworks, G: int, num_simulations: int, model_look_ahead: int,
-                 discount: float, noise_frac: float, device="cuda"):
+                 discount: float, noise_frac: float, device="cuda", keep_latents: bool = True):
+        """keep_latents=False: with networks in bottleneck form (muzero_amd.towers) the non-root nodes'
+        latents are kept only as their bottleneck values (`t_pool`); `pool.latent` then holds the
+        roots alone.  The search result does not depend on it."""
         self.nets = nets
         self.G, self.S, self.depth = G, num_simulations, model_look_ahead
         self.discount, self.noise_frac = discount, noise_frac
@@ -229,6 +232,7 @@ class BatchedMCTS:
         self.rows_buf = [torch.zeros(G, **i32) for _ in range(2)]
         self.next_rows_buf = torch.zeros((G, A), **i32)
         self.child_slots = (self.tree_base[:, None] + self.arange_a[None, :]).contiguous()
+        self.keep_latents = keep_latents or not dt or getattr(nets, "tower_f_t", None) is None
         self.use_graph = True
         self._graph, self._graph_version = None, -1
         self.rand_static = torch.zeros(G, **i32)
@@ -252,7 +256,7 @@ class BatchedMCTS:
             nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior, **f_extra)
         extra = {}
         if self.t_pool is not None:
-            extra = dict(t_in=None if root else (self.t_pool, rows), t_out=self.t_pool)
+            extra = dict(t_in=None if root else (self.t_pool, rows), t_out=self.t_pool, want_latent=self.keep_latents)
         nets.dynamics(pool.latent, G * A, rows=rows_rep, action=None, next_latent=pool.latent, next_rows=next_rows,
                       reward=self.reward, **extra)
         if self.side is not None:
@@ -270,7 +274,8 @@ class BatchedMCTS:
         t_in = (self.t_pool, rows) if self.t_pool is not None else None
         for d in range(self.depth):
             nxt = self.tmp[d & 1]
-            extra = dict(t_in=t_in, t_out=self.tmp_t[d & 1]) if self.t_pool is not None else {}
+            extra = dict(t_in=t_in, t_out=self.tmp_t[d & 1], want_latent=self.keep_latents) \
+                if self.t_pool is not None else {}
             f_extra = {"t_in": t_in} if t_in is not None else {}
             if self.side is not None:  # fc_merge's latent half needs no action: it runs next to f
                 self.side.wait_stream(main)

@@ -107,7 +107,7 @@ class SelfPlayEngine:
         self.h = RepresentationRunner(repr_net, device=device)
         self.nets = make_networks(dyn_net, pred_net, device=device)
         self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
-                                device=device)
+                                device=device, keep_latents=False)  # nothing here reads the children's latents
         self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
         self.rng = np.random.default_rng(seed)
         self.device_rng = device_rng

@@ -354,14 +354,15 @@ class TowerNetworks:
         return base
 
     def dynamics(self, latent, B, *, ld=None, rows=None, action=None, next_latent=None, ld_next=None, next_rows=None,
-                 reward=None, base=None, t_in=None, t_out=None) -> None:
+                 reward=None, base=None, t_in=None, t_out=None, want_latent=True) -> None:
         """action None: the expansion pattern -- consecutive groups of A rows share one latent and
         take actions 0..A-1; each group is one call of the reference (shared batch statistics).
         action i32[B]: B independent calls of batch size 1.
         Bottleneck form (only when `bottleneck_g` > 0): t_in = (t f32[*, bottleneck_g], rows) holds the
         bottleneck values of the source latents (row index like `rows`; for the expansion pattern one
         entry per group is read, `rows[::A]`); t_out f32[*, bottleneck_g] receives those of the results,
-        scattered by next_rows like next_latent."""
+        scattered by next_rows like next_latent.  want_latent=False (bottleneck form only) skips
+        res_final and the store of the C*H*W latents: t_out is the result."""
         D, A = self.D, self.A
         ld = ld or D
         use_t = t_in is not None and self.merge_t is not None
@@ -386,13 +387,15 @@ class TowerNetworks:
             else:
                 assert t_in is None or use_t
             x_rows, row_sel, group = None, action, 1
-        if next_latent is None:
-            next_latent, ld_next, next_rows = self._buf("g_next", (B, D)), D, None
-        ld_next = ld_next or D
         if t_out is not None and not self.bottleneck_g:
             t_out = None
+        if not want_latent and t_out is not None and self.reward_t is not None:
+            next_latent = None
+        elif next_latent is None:
+            next_latent, ld_next, next_rows = self._buf("g_next", (B, D)), D, None
+        ld_next = ld_next or D
         self._tower_call(self.tower_g, base, D, x_rows, self.table_t if use_t else self.table, row_sel, next_latent,
-                         ld_next, next_rows, B, group, t_out=t_out)
+                         ld_next if next_latent is not None else 0, next_rows, B, group, t_out=t_out)
         if reward is not None:
             if t_out is not None and self.reward_t is not None:
                 self._mlp_on(self.reward_t, "reward_t", t_out, t_out.shape[-1], next_rows, B, out=reward)

@@ -455,14 +455,20 @@ def test_graph_replay_equals_launch_by_launch():
     eager = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25)
     eager.use_graph = False
     graphed = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25)
+    lean = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25, keep_latents=False)  # children kept as bottleneck values only
+    assert not lean.keep_latents
     for round_ in range(3):
         if round_ == 2:
             with torch.no_grad():
                 g.fc_merge.bias.add_(0.01)
             nets.refresh()
         args = inputs()
-        a, b = eager.run(*args), graphed.run(*args)
+        a, b, c = eager.run(*args), graphed.run(*args), lean.run(*args)
         torch.cuda.synchronize()
+        for name in ("visit", "value_sum", "prior", "reward", "first_child"):
+            assert torch.equal(getattr(eager.pool, name), getattr(lean.pool, name)), (round_, name, "lean")
+        assert torch.equal(a.policy, c.policy) and torch.equal(eager.t_pool, lean.t_pool)
+        assert float(lean.pool.latent[:, 1:].abs().max()) == 0.0
         assert graphed._graph is not None
         for name in ("visit", "value_sum", "prior", "reward", "first_child", "latent"):
             assert torch.equal(getattr(eager.pool, name), getattr(graphed.pool, name)), (round_, name)

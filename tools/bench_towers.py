@@ -64,7 +64,7 @@ def main() -> None:
     nets = TowerNetworks(g, f)
     torch.cuda.synchronize()
     t_build = time.time() - t0
-    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25)
+    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, keep_latents=False)
     gen = torch.Generator(device="cuda").manual_seed(0)
     lat = torch.randn(G, D, device="cuda", generator=gen)
     eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((G,)).float().cuda()
