@@ -527,17 +527,23 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         }
         return wdst;
     };
-    // sums the channel slices of acc in a fixed order (slice 0 ends up with the total)
-    auto reduce_slices = [&](f32x4 &acc, int which, int slot) {
+    // every wave leaves its slice's partial sums in `red`
+    auto put_partials = [&](const f32x4 &acc, int which, int slot) {
         for (int o = 0; o < COB; ++o) red[((ksi * 2 + which) * COB + o) * pstride + slot] = acc[o];
-        __syncthreads();
-        if (ksi == 0)
-            for (int o = 0; o < COB; ++o) {
-                float s = 0.0f;
-                for (int q = 0; q < G.ks; ++q) s += red[((q * 2 + which) * COB + o) * pstride + slot];
-                acc[o] = s;
-            }
     };
+    // all threads: sum the `ks` slices in a fixed order and store, same element -> (channel,
+    // position) map as store_acc
+    auto reduce_store = [&](lds_f *dst, int which, int ks, int co0, int Cout, int pb, const float *bias_map) {
+        for (int e = tid; e < COB * pstride; e += kTT) {
+            const int slot = e % pstride, o = e / pstride;
+            float s = 0.0f;
+            for (int q = 0; q < ks; ++q) s += red[((q * 2 + which) * COB + o) * pstride + slot];
+            const int ln = slot & 63, co = co0 + (ln & 3), pos = pb + (slot & ~63) + (ln & ~3) + o;
+            if (co < Cout && pos < P) dst[co * P + pos] = s + (bias_map ? bias_map[co * HW + pos % HW] : 0.0f);
+        }
+    };
+    // convolutions over a handful of input channels are not worth slicing
+    auto slices_for = [&](int cin) { return cin <= 8 ? 1 : G.ks; };
     // accumulator of lane 4b+j, element i = position (wave's first position) + 4b+i, channel co0+j;
     // bias_map (optional) adds a per-(channel, position-in-image) constant
     auto store_acc = [&](lds_f *dst, const f32x4 &acc, int co0, int Cout, int first_pos, const float *bias_map) {
@@ -562,6 +568,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 const bool live = p < P;
                 const int pc = live ? p : 0;
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accd = {0.0f, 0.0f, 0.0f, 0.0f};
+                const int ks1 = slices_for(from_global ? min(G.stage_c, Cin) : Cin);
                 if (from_global) {
                     for (int cb = 0; cb < Cin; cb += G.stage_c) {
                         const int cn = min(G.stage_c, Cin - cb);
@@ -571,8 +578,9 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                         const lds_f *wdn = load_weights(R.conv1_w, R.down_w, co0, Cout, Cin, cb, cn, k * k);
                         __syncthreads();
                         MZ_TT(2)
-                        const int per = (cn + G.ks - 1) / G.ks;
+                        const int per = (cn + ks1 - 1) / ks1;
                         const int lo = cb + min(cn, ksi * per), hi = cb + min(cn, (ksi + 1) * per);
+                        if (ksi >= ks1) continue;
                         if (down) conv_dispatch<true>(stage, cb, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
                         else conv_dispatch<false>(stage, cb, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
                     }
@@ -580,18 +588,22 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                     __syncthreads();
                     const lds_f *wdn = load_weights(R.conv1_w, R.down_w, co0, Cout, Cin, 0, Cin, k * k);
                     __syncthreads();
-                    const int per = (Cin + G.ks - 1) / G.ks;
+                    const int per = (Cin + ks1 - 1) / ks1;
                     const int lo = min(Cin, ksi * per), hi = min(Cin, (ksi + 1) * per);
-                    if (down) conv_dispatch<true>(cur, 0, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
-                    else conv_dispatch<false>(cur, 0, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
+                    if (ksi < ks1) {
+                        if (down) conv_dispatch<true>(cur, 0, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
+                        else conv_dispatch<false>(cur, 0, lo, hi, wst, wdn, k, G.H, G.W, P, pc, live, acc, accd);
+                    }
                 }
                 MZ_TT(3)
-                if (G.ks > 1) {
+                if (ks1 > 1) {
                     __syncthreads();  // earlier partials have been read
-                    reduce_slices(acc, 0, slot);
-                    if (down) reduce_slices(accd, 1, slot);
-                }
-                if (ksi == 0) {
+                    put_partials(acc, 0, slot);
+                    if (down) put_partials(accd, 1, slot);
+                    __syncthreads();
+                    reduce_store(mid, 0, ks1, co0, Cout, pb, R.conv1_bias);
+                    if (down) reduce_store(aux, 1, ks1, co0, Cout, pb, nullptr);
+                } else if (ksi == 0) {
                     store_acc(mid, acc, co0, Cout, pb + pwi * 64, R.conv1_bias);
                     if (down) store_acc(aux, accd, co0, Cout, pb + pwi * 64, nullptr);
                 }
@@ -610,17 +622,22 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 const int slot = pwi * 64 + lane, p = pb + slot;
                 const bool live = p < P;
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accd = {0.0f, 0.0f, 0.0f, 0.0f};
-                const int per = (Cout + G.ks - 1) / G.ks;
+                const int ks2 = slices_for(Cout);
+                const int per = (Cout + ks2 - 1) / ks2;
                 const int lo = min(Cout, ksi * per), hi = min(Cout, (ksi + 1) * per);
                 __syncthreads();
                 load_weights(R.conv2_w, nullptr, co0, Cout, Cout, 0, Cout, k * k);
                 __syncthreads();
-                conv_dispatch<false>(mid, 0, lo, hi, wst, wst, k, G.H, G.W, P, live ? p : 0, live, acc, accd);
-                if (G.ks > 1) {
+                if (ksi < ks2)
+                    conv_dispatch<false>(mid, 0, lo, hi, wst, wst, k, G.H, G.W, P, live ? p : 0, live, acc, accd);
+                if (ks2 > 1) {
                     __syncthreads();
-                    reduce_slices(acc, 0, slot);
+                    put_partials(acc, 0, slot);
+                    __syncthreads();
+                    reduce_store(dst, 0, ks2, co0, Cout, pb, nullptr);
+                } else if (ksi == 0) {
+                    store_acc(dst, acc, co0, Cout, pb + pwi * 64, nullptr);
                 }
-                if (ksi == 0) store_acc(dst, acc, co0, Cout, pb + pwi * 64, nullptr);
             }
         }
         __syncthreads();
