@@ -292,6 +292,8 @@ struct TowerGeom {
     int stage_c;         // input channels of the first block staged per pass
     int pw, ks;          // waves across positions / slices of the input channels (pw * ks = kTW)
     int vec_ok;          // rows may be read as 16-byte vectors
+    int gemm1;           // the first block's convolutions run as one matrix product (see gemm_conv1)
+    int y_ld;            // its result's row stride in LDS
     int off_a, off_b, off_c, off_red, off_stage, off_w;  // LDS offsets in floats
 };
 
@@ -423,6 +425,9 @@ __device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int 
     else if (k == 1) conv_accumulate<DOWN, 1>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
     else conv_accumulate<DOWN, 0>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
 }
+
+constexpr int kG1Cols = 32;  // columns of the first block's matrix product (two 16-wide tiles)
+constexpr int kG1Ld = 68;    // row stride of its per-wave partials: 64 positions + 4 (LDS banks)
 
 // One workgroup per group of rows (one network call of the reference).  LDS holds three
 // activation buffers of cmax x P floats (a: block input / result, b: after conv1, c: skip path
@@ -562,6 +567,119 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         const bool down = R.down_w != nullptr;
         const bool from_global = b == 0;
         // ---- conv1 -> mid, and the 1x1 skip convolution of the same input -> aux
+        if (from_global && G.gemm1) {
+            // The first block reads C channels and writes a few: as a matrix product
+            //   Yt[column][position] = sum_ci  W[ci][column] * input[ci][position],
+            // columns = (output channel, tap) pairs followed by the skip convolution's channels,
+            // the k x k convolution is the sum over taps of Yt shifted by the tap's offset.  The
+            // input goes from global memory straight into the matrix instruction's operand (no
+            // staging): lane (m, q) of v_mfma_f32_16x16x4 supplies positions 4m..4m+3 of channel
+            // 4*step + q, one 16-byte load, used by the four tiles t = 0..3 whose row m is position
+            // 4m + t.  The waves split the channels; their partial tiles are summed in wave order.
+            const int kk = k * k, ncol = Cout * kk + (down ? Cout : 0);
+            lds_f *part = stage, *Yt = stage + kTW * kG1Cols * kG1Ld;
+            const int m = lane & 15, q = lane >> 4;
+            const int nsteps = (Cin + 3) >> 2;
+            const float *wb[2];
+            int wstr[2];
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = nt * 16 + m;
+                wb[nt] = nullptr;
+                wstr[nt] = 0;
+                if (col < Cout * kk) {
+                    const int ch = col / kk;
+                    wb[nt] = R.conv1_w + (long long)ch * Cin * kk + (col - ch * kk);
+                    wstr[nt] = kk;
+                } else if (col < ncol) {
+                    wb[nt] = R.down_w + (long long)(col - Cout * kk) * Cin;
+                    wstr[nt] = 1;
+                }
+            }
+            for (int pb = 0; pb < P; pb += 64) {
+                MZ_TT(1)
+                const int p4 = pb + 4 * m;
+                const bool live = p4 < P;  // P % 4 == 0: the four positions are live together
+                const int r = live ? p4 / HW : 0, sp = live ? p4 - r * HW : 0;
+                const float *xr = live ? src_row(r) : nullptr, *ar = live ? add_row(r) : nullptr;
+                if (xr) xr += sp;
+                if (ar) ar += sp;
+                f32x4 acc[4][2];
+                for (int t = 0; t < 4; ++t)
+                    for (int nt = 0; nt < 2; ++nt) acc[t][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                constexpr int UN = 8;
+                for (int k0 = wave; k0 < nsteps; k0 += kTW * UN) {
+                    f32x4 xv[UN], av[UN];
+                    float wv[UN][2];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int ci = 4 * (k0 + u * kTW) + q;
+                        const bool ok = ci < Cin;
+                        xv[u] = av[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        if (ok && xr) xv[u] = *reinterpret_cast<const f32x4 *>(xr + (long long)ci * HW);
+                        if (ok && ar) av[u] = *reinterpret_cast<const f32x4 *>(ar + (long long)ci * HW);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            wv[u][nt] = (ok && wb[nt]) ? wb[nt][(long long)ci * wstr[nt]] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        f32x4 z = xv[u];
+                        if (ar) {
+                            z.x = fmaxf(z.x + av[u].x, 0.0f);
+                            z.y = fmaxf(z.y + av[u].y, 0.0f);
+                            z.z = fmaxf(z.z + av[u].z, 0.0f);
+                            z.w = fmaxf(z.w + av[u].w, 0.0f);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[t], wv[u][nt], acc[t][nt], 0, 0, 0);
+                    }
+                }
+                MZ_TT(2)
+                // element i of tile (t, nt) in lane (n, mq) is position 16 mq + 4 i + t, column 16 nt + n
+                __syncthreads();  // the previous pass's partials have been summed
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<lds_f4 *>(part + (wave * kG1Cols + nt * 16 + m) * kG1Ld + 16 * q + 4 * i) =
+                            f32x4{acc[0][nt][i], acc[1][nt][i], acc[2][nt][i], acc[3][nt][i]};
+                __syncthreads();
+                {
+                    const int col = tid >> 4, c4 = (tid & 15) << 2;  // kTT = 32 columns x 16 vectors
+                    f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int w = 0; w < kTW; ++w) {
+                        const f32x4 v = *reinterpret_cast<const lds_f4 *>(part + (w * kG1Cols + col) * kG1Ld + c4);
+                        sum.x += v.x;
+                        sum.y += v.y;
+                        sum.z += v.z;
+                        sum.w += v.w;
+                    }
+                    *reinterpret_cast<lds_f4 *>(Yt + col * G.y_ld + pb + c4) = sum;
+                }
+            }
+            __syncthreads();
+            const int pad = (k - 1) >> 1;
+            for (int e = tid; e < Cout * P; e += kTT) {
+                const int ch = e / P, p = e - ch * P;
+                const int r = p / HW, sp = p - r * HW, py = sp / G.W, px = sp - py * G.W;
+                float v = 0.0f;
+                for (int ky = 0; ky < k; ++ky) {
+                    const int yy = py + ky - pad;
+                    if (yy < 0 || yy >= G.H) continue;
+                    for (int kx = 0; kx < k; ++kx) {
+                        const int xx = px + kx - pad;
+                        if (xx >= 0 && xx < G.W) v += Yt[(ch * kk + ky * k + kx) * G.y_ld + r * HW + yy * G.W + xx];
+                    }
+                }
+                if (R.conv1_bias) v += R.conv1_bias[ch * HW + sp];
+                mid[e] = v;
+                if (down) aux[e] = Yt[(Cout * kk + ch) * G.y_ld + p];
+            }
+            MZ_TT(3)
+        } else
         for (int co0 = 0; co0 < Cout; co0 += COB) {
             for (int pb = 0; pb < P; pb += pstride) {
                 const int slot = pwi * 64 + lane, p = pb + slot;
@@ -722,7 +840,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     MZ_TT(9)
 }
 
-int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes) {
+int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
     if (!T || T->n_blocks < 0 || T->n_blocks > MZ_MAX_BLOCKS || T->C <= 0 || T->H <= 0 || T->W <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: bad tower (n_blocks 0..%d, positive C, H, W)", MZ_MAX_BLOCKS);
     if (group <= 0) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: group must be positive");
@@ -768,6 +886,31 @@ int tower_geometry(const mz_tower *T, int group, TowerGeom *g, size_t *lds_bytes
     const long long lds_floats = (long long)(kMaxLds / sizeof(float));
     const int cl = T->n_blocks ? T->block[T->n_blocks - 1].out_channels : T->C;
     const long long fin = T->final_w ? (long long)T->C * (cl <= 3 ? 4 : cl + 1) : 0;
+    // the first block as a matrix product: its columns fit two 16-wide tiles, rows are read as
+    // 16-byte vectors, and the per-wave partials plus the product fit next to the buffers
+    static const bool gemm_off = [] {
+        const char *e = getenv("MZ_TOWER_GEMM1");  // tuning aid: 0 keeps the staged form
+        return e && atoi(e) == 0;
+    }();
+    if (T->n_blocks && vec_ok && !gemm_off) {
+        const mz_resblock &R = T->block[0];
+        const int ncol = R.out_channels * R.kernel_size * R.kernel_size + (R.down_w ? R.out_channels : 0);
+        const long long y_ld = ((g->P + 63) & ~63) + 4;
+        const long long need = (long long)kTW * kG1Cols * kG1Ld + kG1Cols * y_ld;
+        const long long later = (long long)g->cmax * wpc;  // staged weights of the later convolutions
+        if (ncol <= kG1Cols && fixed + std::max(std::max(need, later), fin) <= lds_floats) {
+            g->gemm1 = 1;
+            g->y_ld = (int)y_ld;
+            g->off_a = 0;
+            g->off_b = (int)buf;
+            g->off_c = (int)(2 * buf);
+            g->off_red = (int)(3 * buf);
+            g->off_stage = g->off_w = (int)fixed;
+            g->stage_c = T->C;
+            *lds_bytes = (size_t)(fixed + std::max(std::max(need, later), fin)) * sizeof(float);
+            return MZ_OK;
+        }
+    }
     // the first block's input is staged `stage_c` channels at a time next to their weights
     int sc = 0;
     for (int c = T->C; c >= 1; --c)
@@ -875,7 +1018,10 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
                      void *stream) {
     TowerGeom g;
     size_t lds = 0;
-    MZ_TRY(tower_geometry(h_tower, group, &g, &lds));
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec_ok = h_tower && h_tower->H > 0 && h_tower->W > 0 && (h_tower->H * h_tower->W) % 4 == 0 &&
+                        ldx % 4 == 0 && aligned(x) && (!row_add || (ld_add % 4 == 0 && aligned(row_add)));
+    MZ_TRY(tower_geometry(h_tower, group, vec_ok, &g, &lds));
     const int D = g.C * g.HW;
     if (!x || (!y && !t_out) || B < 0 || ldx < D || (y && ldy < D) || (row_add && ld_add < D))
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: NULL argument, negative B or a row stride below C*H*W=%d", D);
@@ -886,8 +1032,7 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
     }
     if (B % group) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: B=%d is not a multiple of group=%d", B, group);
     if (B == 0) return MZ_OK;
-    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    g.vec_ok = g.HW % 4 == 0 && ldx % 4 == 0 && aligned(x) && (!row_add || (ld_add % 4 == 0 && aligned(row_add)));
+    g.vec_ok = vec_ok;
     MZ_TRY(allow_lds(k_tower, lds, "k_tower"));
     hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
                        x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, t_out, (long long)ld_t, group);

@@ -25,10 +25,17 @@ gidx = (torch.arange(G * A, dtype=torch.int32, device="cuda") // A).contiguous()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
-def timed(name, tower, B, group, x_rows=None, row_add=None):
+t_in = torch.randn(G, 108, device="cuda")
+t_out = torch.empty(G * A, 108, device="cuda")
+
+
+def timed(name, tower, B, group, x_rows=None, row_add=None, lean=False, src=None):
+    xs = x if src is None else src
+
     def call():
-        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(x_rows), ptr(row_add), D, None, ptr(y), D, None,
-                                        None, 0, B, group, st), name)
+        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(xs), xs.shape[1], ptr(x_rows), ptr(row_add), D, None,
+                                        None if lean else ptr(y), D, None, ptr(t_out) if lean else None, 108, B, group,
+                                        st), name)
     call()
     ev0.record()
     for _ in range(10):
@@ -41,6 +48,11 @@ def timed(name, tower, B, group, x_rows=None, row_add=None):
 timed("f tower, group 1", nets.tower_f, G, 1)
 timed("g tower, group 1, merge table", nets.tower_g, G, 1, row_add=nets.table)
 timed("g tower, group A (expansion), merge table", nets.tower_g, G * A, A, x_rows=gidx, row_add=nets.table)
+# the forms the lock-step search launches (last block's output only, no res_final)
+timed("g tower, group 1, bottleneck output only", nets.tower_g, G, 1, row_add=nets.table, lean=True)
+timed("g tower, group A, bottleneck output only", nets.tower_g, G * A, A, x_rows=gidx, row_add=nets.table, lean=True)
+if nets.tower_f_t is not None:
+    timed("f tower on the bottleneck (3 -> 3 block), group 1", nets.tower_f_t, G, 1, lean=True, src=t_in)
 copy = _hip.Tower.from_buffer_copy(nets.tower_f)
 copy.n_blocks = 0
 copy.final_w = copy.final_b = None
@@ -51,10 +63,12 @@ if hasattr(lib, "mz_debug_tower_stamps"):  # diagnostics build only
     import numpy as np
     names = ["start", "stage: begin", "stage: loaded", "conv1 done", "before bn1", "after bn1/skip bn", "conv2 done",
              "after bn2", "before res_final", "end"]
-    for label, tower, B, group, rows, add in (("f tower", nets.tower_f, G, 1, None, None),
-                                               ("g expansion", nets.tower_g, G * A, A, gidx, nets.table)):
-        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(x), D, ptr(rows), ptr(add), D, None, ptr(y), D, None, None, 0,
-                                        B, group, st), label)
+    for label, tower, B, group, rows, add, xs in (
+            ("g step, bottleneck output only", nets.tower_g, G, 1, None, nets.table, x),
+            ("g expansion, bottleneck output only", nets.tower_g, G * A, A, gidx, nets.table, x),
+            ("f on the bottleneck", nets.tower_f_t, G, 1, None, None, t_in)):
+        _hip.check(lib.mz_tower_forward(C.byref(tower), ptr(xs), xs.shape[1], ptr(rows), ptr(add), D, None, None, D, None,
+                                        ptr(t_out), 108, B, group, st), label)
         torch.cuda.synchronize()
         h = np.zeros(16, np.uint64)
         lib.mz_debug_tower_stamps(h.ctypes.data_as(C.c_void_p))
