@@ -294,10 +294,11 @@ struct TowerGeom {
     int vec_ok;          // rows may be read as 16-byte vectors
     int gemm1;           // the first block's convolutions run as one matrix product (see gemm_conv1)
     int y_ld;            // its result's row stride in LDS
-    int off_a, off_b, off_c, off_red, off_stage, off_w;  // LDS offsets in floats
+    int off_a, off_b, off_c, off_red, off_par, off_stage, off_w;  // LDS offsets in floats
 };
 
 constexpr int COB = 4;  // output channels accumulated together per pass
+constexpr int kPar = 512;  // floats of LDS for a block's small parameters (one per thread)
 
 // Diagnostics build (-DMZ_TOWER_TIMELINE): workgroup 0 records the shader clock at the marked
 // points of its last launch; mz_debug_tower_stamps copies them out.
@@ -321,25 +322,45 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // In-place BatchNorm2d with the statistics of the P values of each channel (mean and biased
-// variance, accumulated in double as torch's CPU kernels do), then the activation.
-__device__ void bn_act(lds_f *buf, int C, int P, const float *__restrict__ gamma, const float *__restrict__ beta,
-                       float eps, int act) {
+// variance, accumulated in double as torch's CPU kernels do), then the activation.  One wave per
+// channel; a second buffer (the skip path), if given, is normalised by other waves at the same
+// time.  gamma/beta come from LDS (lg/lb, fetched earlier) when given, else from global memory.
+struct BnJob {
+    lds_f *buf;
+    const float *gamma, *beta;
+    const lds_f *lg, *lb;
+    float eps;
+    int act;
+};
+__device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = wave; c < C; c += kTW) {
-        lds_f *v = buf + c * P;
-        double s = 0.0;
-        for (int p = lane; p < P; p += 64) s += (double)v[p];
-        const double mean = wave_sum(s) / P;
-        double q = 0.0;
+    const int jobs = j1.buf ? 2 * C : C;
+    for (int job = wave; job < jobs; job += kTW) {
+        const bool second = job >= C;
+        const BnJob &J = second ? j1 : j0;
+        const int c = second ? job - C : job;
+        lds_f *v = J.buf + c * P;
+        // one sweep: sums of (x - pivot) and (x - pivot)^2, the pivot (the channel's first value)
+        // keeping the squares small; the two wave reductions overlap
+        const double pivot = (double)v[0];
+        double s = 0.0, q = 0.0;
         for (int p = lane; p < P; p += 64) {
-            const double d = (double)v[p] - mean;
+            const double d = (double)v[p] - pivot;
+            s += d;
             q += d * d;
         }
-        const double invstd = 1.0 / sqrt(wave_sum(q) / P + (double)eps);
-        const double ga = (double)as_constant(gamma)[c], be = (double)as_constant(beta)[c];
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        const double ds = s / P, mean = pivot + ds;
+        const double var = fmax(q / P - ds * ds, 0.0);
+        const double invstd = 1.0 / sqrt(var + (double)J.eps);
+        const double ga = J.lg ? (double)J.lg[c] : (double)as_constant(J.gamma)[c];
+        const double be = J.lb ? (double)J.lb[c] : (double)as_constant(J.beta)[c];
         const float scale = (float)(ga * invstd);
         const float shift = (float)(be - mean * ga * invstd);
-        for (int p = lane; p < P; p += 64) v[p] = activate(v[p] * scale + shift, act);
+        for (int p = lane; p < P; p += 64) v[p] = activate(v[p] * scale + shift, J.act);
     }
 }
 
@@ -426,6 +447,47 @@ __device__ __forceinline__ void conv_dispatch(const lds_f *src, int c_base, int 
     else conv_accumulate<DOWN, 0>(src, c_base, c_lo, c_hi, wk, wd, k, H, W, P, p, live, acc, accd);
 }
 
+// Sum over the taps of a k x k window for one output value, inputs and weights in LDS:
+//   sum_t  wsrc[t * w_stride] * src[(tap t's position) ... ]  with src advanced by `src_tap` per tap
+// (src_tap = 0: one plane, taps select positions only; otherwise tap t reads plane t).  KF = k
+// when known at compile time: the reads are then unconditional (a tap outside the image reads the
+// centre and is dropped by a select) and issued together.
+template <int KF>
+__device__ __forceinline__ float window_sum(const lds_f *src, int src_tap, const lds_f *wsrc, int k_rt, int H, int W,
+                                            int py, int px) {
+    const int k = KF ? KF : k_rt, pad = (k - 1) >> 1;
+    float v = 0.0f;
+    if (KF) {
+        constexpr int KK = KF ? KF * KF : 1;
+        float x[KK], w[KK];
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            const int yy = py + t / KF - pad, xx = px + t % KF - pad;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            x[t] = src[t * src_tap + (ok ? yy * W + xx : py * W + px)];
+            w[t] = ok ? (wsrc ? wsrc[t] : 1.0f) : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < KK; ++t) v += w[t] * x[t];
+        return v;
+    }
+    for (int ky = 0; ky < k; ++ky) {
+        const int yy = py + ky - pad;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int xx = px + kx - pad, t = ky * k + kx;
+            if (xx >= 0 && xx < W) v += (wsrc ? wsrc[t] : 1.0f) * src[t * src_tap + yy * W + xx];
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ float window_sum_k(const lds_f *src, int src_tap, const lds_f *wsrc, int k, int H, int W,
+                                              int py, int px) {
+    if (k == 3) return window_sum<3>(src, src_tap, wsrc, k, H, W, py, px);
+    if (k == 1) return window_sum<1>(src, src_tap, wsrc, k, H, W, py, px);
+    return window_sum<0>(src, src_tap, wsrc, k, H, W, py, px);
+}
+
 constexpr int kG1Cols = 32;  // columns of the first block's matrix product (two 16-wide tiles)
 constexpr int kG1Ld = 68;    // row stride of its per-wave partials: 64 positions + 4 (LDS banks)
 
@@ -441,6 +503,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     lds_f *S = to_lds(smem);
     lds_f *cur = S + G.off_a, *mid = S + G.off_b, *aux = S + G.off_c, *red = S + G.off_red, *stage = S + G.off_stage;
     lds_f *wst = S + G.off_w;  // staged convolution weights
+    lds_f *par = S + G.off_par;  // the current block's small parameters
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = G.HW, P = G.P;
@@ -566,6 +629,22 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         const int Cin = R.in_channels, Cout = R.out_channels, k = R.kernel_size;
         const bool down = R.down_w != nullptr;
         const bool from_global = b == 0;
+        // A block with few channels: its second convolution's weights and the BatchNorm
+        // parameters are fetched now, one value per thread, and parked in LDS after conv1, so
+        // that the later stages do not wait on global memory.
+        const int n2 = Cout * Cout * k * k, npar = n2 + 6 * Cout;
+        const bool small = npar <= kPar && Cout * k * k <= 128;
+        float pv = 0.0f;
+        if (small && tid < npar) {
+            if (tid < n2) pv = R.conv2_w[tid];
+            else {
+                const int j = (tid - n2) / Cout, c = (tid - n2) - j * Cout;
+                const float *src = j == 0 ? R.bn1_w : j == 1 ? R.bn1_b : j == 2 ? R.bn2_w : j == 3 ? R.bn2_b
+                                   : j == 4 ? R.dbn_w : R.dbn_b;
+                if (src) pv = src[c];
+            }
+        }
+        const lds_f *pg = small ? par + n2 : nullptr;  // [bn1_w, bn1_b, bn2_w, bn2_b, dbn_w, dbn_b][Cout]
         // ---- conv1 -> mid, and the 1x1 skip convolution of the same input -> aux
         if (from_global && G.gemm1) {
             // The first block reads C channels and writes a few: as a matrix product
@@ -661,19 +740,11 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 }
             }
             __syncthreads();
-            const int pad = (k - 1) >> 1;
             for (int e = tid; e < Cout * P; e += kTT) {
                 const int ch = e / P, p = e - ch * P;
                 const int r = p / HW, sp = p - r * HW, py = sp / G.W, px = sp - py * G.W;
-                float v = 0.0f;
-                for (int ky = 0; ky < k; ++ky) {
-                    const int yy = py + ky - pad;
-                    if (yy < 0 || yy >= G.H) continue;
-                    for (int kx = 0; kx < k; ++kx) {
-                        const int xx = px + kx - pad;
-                        if (xx >= 0 && xx < G.W) v += Yt[(ch * kk + ky * k + kx) * G.y_ld + r * HW + yy * G.W + xx];
-                    }
-                }
+                // tap t of channel ch is row ch * kk + t of the product
+                float v = window_sum_k(Yt + ch * kk * G.y_ld + r * HW, G.y_ld, nullptr, k, G.H, G.W, py, px);
                 if (R.conv1_bias) v += R.conv1_bias[ch * HW + sp];
                 mid[e] = v;
                 if (down) aux[e] = Yt[(Cout * kk + ch) * G.y_ld + p];
@@ -727,14 +798,28 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 }
             }
         }
+        if (small && tid < npar) par[tid] = pv;
         __syncthreads();
         MZ_TT(4)
-        bn_act(mid, Cout, P, R.bn1_w, R.bn1_b, R.eps1, R.activation);
-        if (down) bn_act(aux, Cout, P, R.dbn_w, R.dbn_b, R.epsd, MZ_ACT_NONE);
+        bn_act(BnJob{mid, R.bn1_w, R.bn1_b, pg, pg ? pg + Cout : nullptr, R.eps1, R.activation},
+               BnJob{down ? aux : nullptr, R.dbn_w, R.dbn_b, pg ? pg + 4 * Cout : nullptr,
+                     pg ? pg + 5 * Cout : nullptr, R.epsd, MZ_ACT_NONE}, Cout, P);
         __syncthreads();
         MZ_TT(5)
         // ---- conv2: mid -> dst.  `cur` is free unless it still holds the identity skip.
         lds_f *dst = (!from_global && !down) ? aux : cur;
+        if (small) {
+            // few channels: a thread per output value, weights from LDS
+            const int kk = k * k;
+            for (int e = tid; e < Cout * P; e += kTT) {
+                const int co = e / P, p = e - co * P;
+                const int r = p / HW, sp = p - r * HW, py = sp / G.W, px = sp - py * G.W;
+                float v = 0.0f;
+                for (int ci = 0; ci < Cout; ++ci)
+                    v += window_sum_k(mid + ci * P + r * HW, 0, par + (co * Cout + ci) * kk, k, G.H, G.W, py, px);
+                dst[e] = v;
+            }
+        } else
         for (int co0 = 0; co0 < Cout; co0 += COB) {
             for (int pb = 0; pb < P; pb += pstride) {
                 const int slot = pwi * 64 + lane, p = pb + slot;
@@ -760,7 +845,9 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
         }
         __syncthreads();
         MZ_TT(6)
-        bn_act(dst, Cout, P, R.bn2_w, R.bn2_b, R.eps2, MZ_ACT_NONE);
+        bn_act(BnJob{dst, R.bn2_w, R.bn2_b, pg ? pg + 2 * Cout : nullptr, pg ? pg + 3 * Cout : nullptr, R.eps2,
+                     MZ_ACT_NONE},
+               BnJob{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, MZ_ACT_NONE}, Cout, P);
         __syncthreads();
         MZ_TT(7)
         // ---- skip connection + activation -> cur (input of the next block)
@@ -882,7 +969,7 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
     const long long wpc = (long long)(kkmax + 1) * COB;  // staged weight floats per input channel
     const long long buf = up4((long long)std::max(1, g->cmax) * g->P);
     const long long red = g->ks > 1 ? (long long)g->ks * 2 * COB * g->pw * 64 : 0;
-    const long long fixed = 3 * buf + red;
+    const long long fixed = 3 * buf + red + kPar;
     const long long lds_floats = (long long)(kMaxLds / sizeof(float));
     const int cl = T->n_blocks ? T->block[T->n_blocks - 1].out_channels : T->C;
     const long long fin = T->final_w ? (long long)T->C * (cl <= 3 ? 4 : cl + 1) : 0;
@@ -905,6 +992,7 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
             g->off_b = (int)buf;
             g->off_c = (int)(2 * buf);
             g->off_red = (int)(3 * buf);
+            g->off_par = (int)(3 * buf + red);
             g->off_stage = g->off_w = (int)fixed;
             g->stage_c = T->C;
             *lds_bytes = (size_t)(fixed + std::max(std::max(need, later), fin)) * sizeof(float);
@@ -926,6 +1014,7 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
     g->off_b = (int)buf;
     g->off_c = (int)(2 * buf);
     g->off_red = (int)(3 * buf);
+    g->off_par = (int)(3 * buf + red);
     g->off_stage = (int)fixed;
     g->stage_c = sc;
     g->off_w = (int)(fixed + up4((long long)sc * g->P));

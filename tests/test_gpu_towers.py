@@ -196,7 +196,12 @@ def test_lockstep_search_with_towers(ni, ti):
             np.testing.assert_allclose(reward_stream[gi], Z[k + "reward_stream"], **TOL)
             np.testing.assert_allclose(rollout[gi], Z[k + "sim_stream"], **TOL)
             assert np.array_equal(ref["visit"][gi], Z[k + "visit"])
-            np.testing.assert_allclose(ref["value_sum"][gi], Z[k + "value_sum"], rtol=1e-5, atol=1e-6)
+            # a node's value_sum adds one backed-up utility per visit, signs mixed: the terms are
+            # within 1e-5 of the reference's, the sum within visits * 1e-5 * (largest term)
+            want = Z[k + "value_sum"]
+            term = max(float(np.abs(Z[k + "sim_stream"]).max()), float(np.abs(Z[k + "reward_stream"]).max()))
+            bound = 1e-5 * np.abs(want) + 1e-5 * term * np.maximum(Z[k + "visit"], 1)
+            assert (np.abs(ref["value_sum"][gi] - want) <= bound).all()
             np.testing.assert_allclose(res.policy[gi].cpu().numpy(), Z[k + "policy"], rtol=1e-5)
     same_as_reference = sum(int(np.array_equal(ref["visit"][gi], Z[k + "visit"])) for gi in (0, 1))
     assert same_as_reference == 2, "the reference's recorded tree was not reproduced"
