@@ -294,6 +294,7 @@ struct TowerGeom {
     int vec_ok;          // rows may be read as 16-byte vectors
     int gemm1;           // the first block's convolutions run as one matrix product (see gemm_conv1)
     int y_ld;            // its result's row stride in LDS
+    int part_ld;         // row stride of its per-wave partial sums
     int off_a, off_b, off_c, off_red, off_par, off_stage, off_w;  // LDS offsets in floats
 };
 
@@ -489,16 +490,16 @@ __device__ __forceinline__ float window_sum_k(const lds_f *src, int src_tap, con
 }
 
 constexpr int kG1Cols = 32;  // columns of the first block's matrix product (two 16-wide tiles)
-constexpr int kG1Ld = 68;    // row stride of its per-wave partials: 64 positions + 4 (LDS banks)
 
 // One workgroup per group of rows (one network call of the reference).  LDS holds three
 // activation buffers of cmax x P floats (a: block input / result, b: after conv1, c: skip path
 // or conv2 output), the staging area for the first block's input and the slice partials.
-__global__ void __launch_bounds__(kTT)
-k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
-        const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
-        float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, float *__restrict__ t_out,
-        long long ld_t, int group) {
+template <int DEPTH>
+__device__ __forceinline__ void
+tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, long long ldx,
+           const int32_t *__restrict__ x_rows, const float *__restrict__ row_add, long long ld_add,
+           const int32_t *__restrict__ row_sel, float *__restrict__ y, long long ldy,
+           const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group) {
     extern __shared__ __align__(16) float smem[];
     lds_f *S = to_lds(smem);
     lds_f *cur = S + G.off_a, *mid = S + G.off_b, *aux = S + G.off_c, *red = S + G.off_red, *stage = S + G.off_stage;
@@ -656,7 +657,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
             // 4*step + q, one 16-byte load, used by the four tiles t = 0..3 whose row m is position
             // 4m + t.  The waves split the channels; their partial tiles are summed in wave order.
             const int kk = k * k, ncol = Cout * kk + (down ? Cout : 0);
-            lds_f *part = stage, *Yt = stage + kTW * kG1Cols * kG1Ld;
+            lds_f *part = stage, *Yt = stage + (kTW / 2) * kG1Cols * G.part_ld;
             const int m = lane & 15, q = lane >> 4;
             const int nsteps = (Cin + 3) >> 2;
             const float *wb[2];
@@ -685,7 +686,7 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                 f32x4 acc[4][2];
                 for (int t = 0; t < 4; ++t)
                     for (int nt = 0; nt < 2; ++nt) acc[t][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                constexpr int UN = 8;
+                constexpr int UN = DEPTH;  // k-steps whose loads are in flight together
                 for (int k0 = wave; k0 < nsteps; k0 += kTW * UN) {
                     f32x4 xv[UN], av[UN];
                     float wv[UN][2];
@@ -717,26 +718,46 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
                     }
                 }
                 MZ_TT(2)
-                // element i of tile (t, nt) in lane (n, mq) is position 16 mq + 4 i + t, column 16 nt + n
+                // element i of tile (t, nt) in lane (n, mq) is position 16 mq + 4 i + t, column 16 nt + n.
+                // The upper half of the waves parks its tiles, the lower half adds its own (wave w
+                // + wave w + kTW/2), then all threads sum the kTW/2 rows in wave order.
+                const int lim = min(64, (P - pb + 15) & ~15);  // positions of this pass that are stored
+                const int pl = G.part_ld;
+                lds_f *mine = part + (((wave & (kTW / 2 - 1)) * kG1Cols + m) * pl + 16 * q);
                 __syncthreads();  // the previous pass's partials have been summed
+                if (wave >= kTW / 2 && 16 * q < lim) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<lds_f4 *>(part + (wave * kG1Cols + nt * 16 + m) * kG1Ld + 16 * q + 4 * i) =
-                            f32x4{acc[0][nt][i], acc[1][nt][i], acc[2][nt][i], acc[3][nt][i]};
+                        for (int i = 0; i < 4; ++i)
+                            *reinterpret_cast<lds_f4 *>(mine + nt * 16 * pl + 4 * i) =
+                                f32x4{acc[0][nt][i], acc[1][nt][i], acc[2][nt][i], acc[3][nt][i]};
+                }
+                __syncthreads();
+                if (wave < kTW / 2 && 16 * q < lim) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 o = *reinterpret_cast<const lds_f4 *>(mine + nt * 16 * pl + 4 * i);
+                            *reinterpret_cast<lds_f4 *>(mine + nt * 16 * pl + 4 * i) =
+                                f32x4{acc[0][nt][i] + o.x, acc[1][nt][i] + o.y, acc[2][nt][i] + o.z, acc[3][nt][i] + o.w};
+                        }
+                }
                 __syncthreads();
                 {
                     const int col = tid >> 4, c4 = (tid & 15) << 2;  // kTT = 32 columns x 16 vectors
-                    f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
-                    for (int w = 0; w < kTW; ++w) {
-                        const f32x4 v = *reinterpret_cast<const lds_f4 *>(part + (w * kG1Cols + col) * kG1Ld + c4);
-                        sum.x += v.x;
-                        sum.y += v.y;
-                        sum.z += v.z;
-                        sum.w += v.w;
+                    if (c4 < lim) {
+                        f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int w = 0; w < kTW / 2; ++w) {
+                            const f32x4 v = *reinterpret_cast<const lds_f4 *>(part + (w * kG1Cols + col) * pl + c4);
+                            sum.x += v.x;
+                            sum.y += v.y;
+                            sum.z += v.z;
+                            sum.w += v.w;
+                        }
+                        *reinterpret_cast<lds_f4 *>(Yt + col * G.y_ld + pb + c4) = sum;
                     }
-                    *reinterpret_cast<lds_f4 *>(Yt + col * G.y_ld + pb + c4) = sum;
                 }
             }
             __syncthreads();
@@ -927,6 +948,24 @@ k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, con
     MZ_TT(9)
 }
 
+// Two builds of the tower: up to one workgroup per compute unit, each call is a chain of memory
+// round trips and the deep variant keeps more loads in flight; with more workgroups than compute
+// units the shallow one fits two workgroups per unit (128 vector registers), which overlap.
+__global__ void __launch_bounds__(kTT)
+k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
+        const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
+        float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, float *__restrict__ t_out,
+        long long ld_t, int group) {
+    tower_body<8>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
+}
+__global__ void __launch_bounds__(kTT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx,
+               const int32_t *__restrict__ x_rows, const float *__restrict__ row_add, long long ld_add,
+               const int32_t *__restrict__ row_sel, float *__restrict__ y, long long ldy,
+               const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group) {
+    tower_body<4>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
+}
+
 int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
     if (!T || T->n_blocks < 0 || T->n_blocks > MZ_MAX_BLOCKS || T->C <= 0 || T->H <= 0 || T->W <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: bad tower (n_blocks 0..%d, positive C, H, W)", MZ_MAX_BLOCKS);
@@ -968,11 +1007,25 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
     for (int b = 0; b < T->n_blocks; ++b) kkmax = std::max(kkmax, T->block[b].kernel_size * T->block[b].kernel_size);
     const long long wpc = (long long)(kkmax + 1) * COB;  // staged weight floats per input channel
     const long long buf = up4((long long)std::max(1, g->cmax) * g->P);
-    const long long red = g->ks > 1 ? (long long)g->ks * 2 * COB * g->pw * 64 : 0;
-    const long long fixed = 3 * buf + red + kPar;
     const long long lds_floats = (long long)(kMaxLds / sizeof(float));
     const int cl = T->n_blocks ? T->block[T->n_blocks - 1].out_channels : T->C;
     const long long fin = T->final_w ? (long long)T->C * (cl <= 3 ? 4 : cl + 1) : 0;
+    // the slice partials are needed by every convolution that runs on the sliced path with more than
+    // 8 input channels: any first convolution but a matrix-product one, second ones of blocks whose
+    // parameters do not fit the small-parameter area
+    auto small_block = [](const mz_resblock &R) {
+        const int kk = R.kernel_size * R.kernel_size;
+        return R.out_channels * R.out_channels * kk + 6 * R.out_channels <= kPar && R.out_channels * kk <= 128;
+    };
+    auto red_floats = [&](bool gemm_first) -> long long {
+        bool need = false;
+        for (int b = 0; b < T->n_blocks; ++b) {
+            const mz_resblock &R = T->block[b];
+            if (!(b == 0 && gemm_first) && R.in_channels > 8) need = true;
+            if (!small_block(R) && R.out_channels > 8) need = true;
+        }
+        return need && g->ks > 1 ? (long long)g->ks * 2 * COB * g->pw * 64 : 0;
+    };
     // the first block as a matrix product: its columns fit two 16-wide tiles, rows are read as
     // 16-byte vectors, and the per-wave partials plus the product fit next to the buffers
     static const bool gemm_off = [] {
@@ -982,12 +1035,15 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
     if (T->n_blocks && vec_ok && !gemm_off) {
         const mz_resblock &R = T->block[0];
         const int ncol = R.out_channels * R.kernel_size * R.kernel_size + (R.down_w ? R.out_channels : 0);
-        const long long y_ld = ((g->P + 63) & ~63) + 4;
-        const long long need = (long long)kTW * kG1Cols * kG1Ld + kG1Cols * y_ld;
+        const long long p16 = (g->P + 15) & ~15LL;
+        const long long part_ld = std::min<long long>(64, p16) + 4, y_ld = p16 + 4;
+        const long long need = (long long)(kTW / 2) * kG1Cols * part_ld + kG1Cols * y_ld;
         const long long later = (long long)g->cmax * wpc;  // staged weights of the later convolutions
+        const long long red = red_floats(true), fixed = 3 * buf + red + kPar;
         if (ncol <= kG1Cols && fixed + std::max(std::max(need, later), fin) <= lds_floats) {
             g->gemm1 = 1;
             g->y_ld = (int)y_ld;
+            g->part_ld = (int)part_ld;
             g->off_a = 0;
             g->off_b = (int)buf;
             g->off_c = (int)(2 * buf);
@@ -999,6 +1055,7 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
             return MZ_OK;
         }
     }
+    const long long red = red_floats(false), fixed = 3 * buf + red + kPar;
     // the first block's input is staged `stage_c` channels at a time next to their weights
     int sc = 0;
     for (int c = T->C; c >= 1; --c)
@@ -1122,10 +1179,20 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
     if (B % group) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: B=%d is not a multiple of group=%d", B, group);
     if (B == 0) return MZ_OK;
     g.vec_ok = vec_ok;
-    MZ_TRY(allow_lds(k_tower, lds, "k_tower"));
-    hipLaunchKernelGGL(k_tower, dim3(B / group), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x, (long long)ldx,
-                       x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows, t_out, (long long)ld_t, group);
-    return mz::check_launch("k_tower");
+    // more workgroups than compute units, and two of them fit a unit's LDS: the build that shares it
+    static const int packed_mode = [] {
+        const char *e = getenv("MZ_TOWER_PACKED");  // tuning aid: 0 never, 1 always
+        return e ? atoi(e) : -1;
+    }();
+    const bool packed = packed_mode >= 0 ? packed_mode == 1 : (B / group > 256 && 2 * (lds + 1024) <= kMaxLds);
+    auto launch = [&](auto kernel, const char *name) -> int {
+        MZ_TRY(allow_lds(kernel, lds, name));
+        hipLaunchKernelGGL(kernel, dim3(B / group), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x,
+                           (long long)ldx, x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows,
+                           t_out, (long long)ld_t, group);
+        return mz::check_launch(name);
+    };
+    return packed ? launch(k_tower_packed, "k_tower_packed") : launch(k_tower, "k_tower");
 }
 
 #ifdef MZ_TOWER_TIMELINE
