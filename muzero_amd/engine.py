@@ -235,7 +235,9 @@ class BatchedMCTS:
         self.keep_latents = keep_latents or not dt or getattr(nets, "tower_f_t", None) is None
         self.use_graph = True
         self._graph, self._graph_version = None, -1
-        self.rand_static = torch.zeros(G, **i32)
+        self.rand_static = torch.zeros((0, G), **i32)  # the recorded search's child draws [n, G]
+        self.replays = 0
+        self._warm_version = None
         self.t_pool = torch.zeros((G * self.pool.cap, dt), **f32) if dt else None
         self.tmp_t = [torch.zeros((G, dt), **f32) for _ in range(2)] if dt else None
 
@@ -314,38 +316,38 @@ class BatchedMCTS:
     def advance(self, rand_child: torch.Tensor, trace: dict | None = None) -> None:
         """One `_step` per column of rand_child i32[G, n].
 
-        With networks evaluated by many small kernels (`nets.concurrent`) a step is some 45 launches
-        and, at a few hundred trees, bound by the launch rate: the step is captured once as a HIP
-        graph (both streams included) and replayed; only the column of child draws changes between
-        replays, through a fixed buffer.  Tracing runs the launches one by one."""
+        With networks evaluated by many small kernels (`nets.concurrent`) a step is some 30 launches
+        and, at a few hundred trees, bound by the launch rate.  The first search after construction
+        (or after the weights changed) runs launch by launch; the next one records all n steps, both
+        streams included, as one HIP graph, and from then on a search copies its child draws into the
+        graph's buffer and replays it: one launch per search.  Tracing runs the launches one by one."""
         rand_t = rand_child.t().contiguous()
         n = rand_t.shape[0]
         use_graph = self.use_graph and trace is None and self.side is not None and n > 2
-        if not use_graph:
-            for s in range(n):
-                rollout = self._step(rand_t[s])
-                if trace is not None:
-                    trace.setdefault("leaf", []).append(self.leaf.clone())
-                    trace.setdefault("child", []).append(self.child.clone())
-                    trace.setdefault("rollout", []).append(rollout.clone())
-                    trace.setdefault("prior", []).append(self.prior.clone())
-            return
         version = getattr(self.nets, "version", 0)
-        first = 0
-        if self._graph is None or self._graph_version != version:
-            # the first step runs launch by launch (it also creates every scratch buffer), the
-            # second is recorded
-            self._step(rand_t[0])
-            first = 1
-            self.rand_static.copy_(rand_t[1])
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._step(self.rand_static)
-            self._graph, self._graph_version = graph, version
-        for s in range(first, n):
-            self.rand_static.copy_(rand_t[s])
+        if use_graph and self._warm_version == version:
+            if self._graph is None or self._graph_version != version or self.rand_static.shape[0] != n:
+                # recording launches nothing; every scratch buffer exists since the earlier search
+                self._graph = None
+                self.rand_static = torch.zeros_like(rand_t)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for s in range(n):
+                        self._step(self.rand_static[s])
+                self._graph, self._graph_version = graph, version
+            self.rand_static.copy_(rand_t)
             self._graph.replay()
+            self.replays += 1
+            return
+        for s in range(n):
+            rollout = self._step(rand_t[s])
+            if trace is not None:
+                trace.setdefault("leaf", []).append(self.leaf.clone())
+                trace.setdefault("child", []).append(self.child.clone())
+                trace.setdefault("rollout", []).append(rollout.clone())
+                trace.setdefault("prior", []).append(self.prior.clone())
+        self._warm_version = version
 
     def finish(self) -> SearchResult:
         return SearchResult(*self.pool.result())

@@ -440,9 +440,9 @@ def test_shipped_shape_matches_torch():
 
 
 def test_graph_replay_equals_launch_by_launch():
-    """The captured simulation step (HIP graph, two streams) leaves the same pool, bit for bit, as
-    launching its kernels one by one -- also on a second search that reuses the recorded graph, and
-    after a weight refresh (which re-records it)."""
+    """The recorded search (one HIP graph of all simulation steps, two streams) leaves the same
+    pool, bit for bit, as launching its kernels one by one: the first search (run launch by launch),
+    the next one (recorded, then replayed), and the same pair after a weight refresh."""
     from muzero_amd.engine import BatchedMCTS
     from muzero_amd.towers import TowerNetworks
     g, f, A, shape = load_tower_nets(0)
@@ -462,7 +462,7 @@ def test_graph_replay_equals_launch_by_launch():
     graphed = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25)
     lean = BatchedMCTS(nets, G, S, 2, discount=0.998, noise_frac=0.25, keep_latents=False)  # children kept as bottleneck values only
     assert not lean.keep_latents
-    for round_ in range(3):
+    for round_ in range(4):
         if round_ == 2:
             with torch.no_grad():
                 g.fc_merge.bias.add_(0.01)
@@ -474,7 +474,7 @@ def test_graph_replay_equals_launch_by_launch():
             assert torch.equal(getattr(eager.pool, name), getattr(lean.pool, name)), (round_, name, "lean")
         assert torch.equal(a.policy, c.policy) and torch.equal(eager.t_pool, lean.t_pool)
         assert float(lean.pool.latent[:, 1:].abs().max()) == 0.0
-        assert graphed._graph is not None
+        assert graphed.replays == (0, 1, 1, 2)[round_] and (graphed._graph is not None) == (round_ > 0)
         for name in ("visit", "value_sum", "prior", "reward", "first_child", "latent"):
             assert torch.equal(getattr(eager.pool, name), getattr(graphed.pool, name)), (round_, name)
         assert torch.equal(a.policy, b.policy) and torch.equal(a.value, b.value) and torch.equal(a.visits, b.visits)

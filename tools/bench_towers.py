@@ -51,7 +51,7 @@ def main() -> None:
     ap.add_argument("--games", type=int, default=256)
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--actions", type=int, default=5)
     ap.add_argument("--latent", type=int, nargs=3, default=[256, 6, 6])
     args = ap.parse_args()
@@ -70,9 +70,13 @@ def main() -> None:
     eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((G,)).float().cuda()
     rand = torch.randint(0, A, (G, S + 1), device="cuda", generator=gen, dtype=torch.int32)
     to_play = torch.zeros(G, dtype=torch.int8, device="cuda")
+    warm_s = []  # the first search runs launch by launch, the second records the graph
     for _ in range(args.warmup):
+        torch.cuda.synchronize()
+        t0 = time.time()
         res = mcts.run(lat, to_play, eta, rand)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        warm_s.append(time.time() - t0)
     t0 = time.time()
     for _ in range(args.steps):
         res = mcts.run(lat, to_play, eta, rand)
@@ -129,7 +133,7 @@ def main() -> None:
                      "achieved": merge_flop / merge_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": merge_flop / merge_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": merge_ms * 1e3,
                      "flop_per_launch": merge_flop, "traffic": pmc_traffic() if (G, D) == (256, 9216) else None},
-        "build_s": t_build,
+        "build_s": t_build, "warmup_search_s": warm_s,
     }))
 
 
