@@ -349,6 +349,7 @@ def _random_tower_nets(shape, A, g_blocks, f_blocks, act, seed):
     ((40, 5, 5), 3, [(40, 3)], [(12, 3), (40, 3), (7, 3), (40, 3)], "tanh"),  # 40 channels: 10 output-channel passes; 4 blocks; tanh
     ((3, 7, 9), 4, [(9, 5), (3, 3)], [(3, 3)], "sigmoid"),            # odd H x W (no 16-byte rows), ends on C channels without res_final
     ((130, 6, 6), 2, [(3, 3)], [(3, 3)], "relu"),                     # the shipped form with a channel count that is no multiple of 4
+    ((8, 4, 4), 6, [(1, 5)], [(2, 3), (8, 1)], "relu"),               # matrix-product first block with k = 5 (26 columns), 96 positions per expansion call; a later k = 1 block; no res_final in f
 ])
 def test_tower_kernel_general_shapes_match_torch(shape, A, g_blocks, f_blocks, act):
     """Towers the golden file does not hold (kernel sizes 1 and 5, other activations, many positions
@@ -388,6 +389,41 @@ def test_tower_kernel_general_shapes_match_torch(shape, A, g_blocks, f_blocks, a
     close(rew, torch.cat([w[1] for w in want_g1])[:, 0])
     close(nxtA, torch.cat([w[0] for w in want_gA]))
     close(rewA, torch.stack([w[1][:, 0] for w in want_gA]))
+    close(pol, torch.cat([w[0] for w in want_f]))
+    close(val, torch.cat([w[1] for w in want_f])[:, 0])
+
+
+def test_more_groups_than_compute_units():
+    """300 calls of batch size 1 in one launch (the build of the tower kernel that shares a compute
+    unit between two workgroups) against the torch modules evaluated call by call."""
+    from muzero_amd.towers import TowerNetworks
+    shape, A = (16, 4, 4), 3
+    g, f = _random_tower_nets(shape, A, [(3, 3)], [(3, 3)], "relu", seed=11)
+    D = int(np.prod(shape))
+    nets = TowerNetworks(g, f)
+    B = 300
+    torch.manual_seed(4)
+    lat = torch.randn(B, *shape)
+    act_t = torch.randint(0, A, (B,))
+    with torch.no_grad():
+        want_g = [g(lat[i:i + 1], act_t[i:i + 1]) for i in range(B)]
+        want_f = [f(lat[i:i + 1]) for i in range(B)]
+    x = lat.reshape(B, D).cuda().contiguous()
+    nxt = torch.zeros(B, D, device="cuda")
+    rew = torch.zeros(B, device="cuda")
+    nets.dynamics(x, B, action=act_t.to(torch.int32).cuda(), next_latent=nxt, reward=rew)
+    pol = torch.zeros(B, A, device="cuda")
+    val = torch.zeros(B, device="cuda")
+    nets.prediction(x, B, policy=pol, value=val)
+    torch.cuda.synchronize()
+
+    def close(got, want):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy().reshape(want.shape), want, rtol=1e-5,
+                                   atol=1e-5 * float(np.abs(want).max()))
+
+    close(nxt, torch.cat([w[0] for w in want_g]))
+    close(rew, torch.cat([w[1] for w in want_g])[:, 0])
     close(pol, torch.cat([w[0] for w in want_f]))
     close(val, torch.cat([w[1] for w in want_f])[:, 0])
 
