@@ -42,6 +42,9 @@ class DeviceEpisodeStore:
                          action=buf(capacity + 1, dtype=torch.int64))
         self.done_len = torch.zeros(capacity + 1, dtype=torch.int64, device=dev)
         self._n_finished = torch.zeros((), dtype=torch.int64, device=dev)  # episodes ever finished
+        # episode priorities of the prioritised replay (src/replay_buffer.py:39-44,121-130)
+        self.priority = torch.zeros(capacity + 1, dtype=torch.float64, device=dev)
+        self.max_priority = torch.ones((), dtype=torch.float64, device=dev)
 
     def record(self, obs, policy, value, action, reward, ended) -> None:
         """One lock-step move of all games (the tuple SelfPlayEngine.move returns).  Games whose
@@ -62,6 +65,7 @@ class DeviceEpisodeStore:
             self.done[k].index_copy_(0, slot, self.cur[k])
         self.done_len.index_copy_(0, slot, new_len)
         self.done_len[self.cap] = 0
+        self.priority.index_copy_(0, slot, self.max_priority.expand(self.G))  # new episodes: the largest priority so far
         self.cur_len = torch.where(fin, torch.zeros_like(new_len), new_len)
         self._n_finished = self._n_finished + fin.sum()
 
@@ -117,6 +121,66 @@ class DeviceEpisodeStore:
         u = torch.rand(batch_size, device=self.device, generator=generator)
         k = lookback + torch.minimum((u * span).long(), span - 1)
         return self.cut_windows(slots, k, lookback, roll_ahead, history_length, discount, z_targets), slots, k
+
+    def sampling_probabilities(self, alpha: float) -> torch.Tensor:
+        """P(i) = p_i^alpha / sum_j p_j^alpha over the stored episodes, uniform if the sum
+        vanishes (src/replay_buffer.py:88-96).  f64[size]."""
+        n = self.size
+        scaled = self.priority[:n] ** alpha
+        total = scaled.sum()
+        uniform = torch.full_like(scaled, 1.0 / max(n, 1))
+        return torch.where(total < 1e-8, uniform, scaled / total)
+
+    def sample_prioritized(self, batch_size: int, lookback: int, roll_ahead: int, history_length: int,
+                           discount: float, z_targets, alpha: float = 0.6, beta: float = 1.0, generator=None):
+        """ReplayBuffer.sample_batch + the learner's window cut, on the device
+        (src/replay_buffer.py:72-119, src/training.py:115-142): min(batch_size, n) episodes drawn
+        with replacement with P(i) ~ priority^alpha, importance weights (n P(i))^-beta divided
+        by their maximum over the draw, episodes too short for a window dropped afterwards
+        (src/training.py:210-221), window start uniform over the admissible ones.
+        The batch keeps its shape: a dropped draw stays in it as a window of the longest stored
+        episode with importance weight 0 (no contribution to the weighted loss, its gradient or
+        the weight total) and slot = capacity (the scratch row, ignored by update_priorities), so
+        the learner sees `min(batch_size, n)` windows every step instead of a new shape per step.
+
+        Returns (WindowBatch, slots, k); `slots` are what update_priorities takes.  Each kept
+        window carries the weight and the slot of ITS episode (the reference indexes both by the
+        position in the filtered list, src/training.py:133,164, which pairs a window with the
+        weight and index of another draw once an episode has been dropped)."""
+        n = self.size
+        if n == 0:
+            raise ValueError("the store holds no finished episode")
+        need = lookback + roll_ahead + 1
+        longest = torch.argmax(self.done_len[:n])
+        if int(self.done_len[longest]) < need:
+            raise ValueError("no stored episode is long enough for a training window")
+        probs = self.sampling_probabilities(alpha)
+        draw = torch.multinomial(probs, min(batch_size, n), replacement=True, generator=generator)
+        weights = (n * probs[draw]) ** (-beta)
+        weights = weights / weights.max()
+        keep = self.done_len[draw] >= need
+        cut_from = torch.where(keep, draw, longest)
+        span = self.done_len[cut_from] - roll_ahead - lookback
+        u = torch.rand(cut_from.numel(), device=self.device, generator=generator)
+        k = lookback + torch.minimum((u * span).long(), span - 1)
+        batch = self.cut_windows(cut_from, k, lookback, roll_ahead, history_length, discount, z_targets,
+                                 is_weights=torch.where(keep, weights, torch.zeros_like(weights)).to(torch.float32))
+        return batch, torch.where(keep, draw, torch.full_like(draw, self.cap)), k
+
+    def update_priorities(self, slots: torch.Tensor, errors: torch.Tensor) -> None:
+        """priority[slot] = |error| + 1e-6, the running maximum follows
+        (src/replay_buffer.py:121-130).  When a slot occurs more than once the last occurrence
+        wins, as in the reference's loop; entries with slot = capacity are ignored."""
+        slots = slots.to(self.device)
+        pri = errors.to(device=self.device, dtype=torch.float64).abs() + 1e-6
+        pos = torch.arange(slots.numel(), device=self.device)
+        last = torch.full((self.cap + 1,), -1, dtype=torch.int64, device=self.device)
+        last.scatter_reduce_(0, slots, pos, reduce="amax")
+        winner = last[slots] == pos
+        self.priority.index_copy_(0, slots[winner], pri[winner])
+        self.priority[self.cap] = 0.0
+        real = slots < self.cap
+        self.max_priority = torch.maximum(self.max_priority, torch.where(real, pri, torch.zeros_like(pri)).max())
 
     def to_episodes(self):
         """The stored episodes as the reference's Episode/Chunk lists (states on the CPU)."""

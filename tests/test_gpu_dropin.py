@@ -260,6 +260,18 @@ def test_actor_store_learner_loop_on_device():
     with torch.no_grad():
         want = torch.softmax(f(lat.reshape(G, 4, 6, 7))[0], dim=1)
     torch.testing.assert_close(pol_new, want, rtol=1e-5, atol=2e-6)
+    # prioritised replay on the device: the learner's per-window |loss| becomes the episodes' priority
+    pbatch, pslots, _ = store.sample_prioritized(64, 4, 5, h.history_length, 0.998, z_targets_device, alpha=0.6,
+                                                 beta=0.4, generator=gen)
+    _, per_window, mine = dp.step(pbatch)
+    store.update_priorities(pslots[mine.cuda()], per_window)
+    touched = torch.zeros(store.cap + 1, dtype=torch.bool, device="cuda")
+    touched[pslots] = True
+    assert bool((store.priority[touched] != 1.0).all()) and bool((store.priority[: store.size][~touched[: store.size]] == 1.0).all())
+    real = (pslots[mine.cuda()] < store.cap).cpu()
+    assert float(store.max_priority) == max(1.0, float(per_window[real].max()) + 1e-6)
+    assert float(pbatch.is_weights.max()) == 1.0 and len(pbatch) == 64
+    assert bool(((pbatch.is_weights > 0).cpu() == (pslots < store.cap).cpu()).all())
 
 
 def test_validation_rollout_matches_reference():

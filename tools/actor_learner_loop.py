@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--moves-per-iter", type=int, default=42)
     ap.add_argument("--steps-per-iter", type=int, default=16)
     ap.add_argument("--batch", type=int, default=256, help="windows per rank and learner step")
+    ap.add_argument("--prioritized", action="store_true",
+                    help="episodes drawn by priority (alpha 0.6, beta 1.0, src/replay_buffer.py:11-39 defaults), "
+                         "priorities updated from the per-window loss; default: uniform")
     args = ap.parse_args()
 
     import bench
@@ -80,9 +83,16 @@ def main():
         t0 = time.perf_counter()
         last = float("nan")
         for _ in range(args.steps_per_iter):
-            batch, _, _ = store.sample_windows(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
-                                               tcfg.discount_factor, z_targets_device, generator=gen)
-            last, _ = learner.step_local(batch)
+            if args.prioritized:
+                batch, slots, _ = store.sample_prioritized(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
+                                                           tcfg.discount_factor, z_targets_device, alpha=0.6, beta=1.0,
+                                                           generator=gen)
+                last, errors = learner.step_local(batch)
+                store.update_priorities(slots, errors)
+            else:
+                batch, _, _ = store.sample_windows(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
+                                                   tcfg.discount_factor, z_targets_device, generator=gen)
+                last, _ = learner.step_local(batch)
             steps += 1
         eng.nets.refresh()  # the actors search with the new weights from the next move on
         sharding.fence(dist)
@@ -92,7 +102,7 @@ def main():
         print(json.dumps({
             "n_gpus": shard.world, "games_per_gpu": args.games, "iters": args.iters,
             "selfplay_env_steps_per_sec": shard.world * args.games * moves / t_play,
-            "learner_steps_per_sec": steps / t_learn, "windows_per_step": shard.world * args.batch,
+            "learner_steps_per_sec": steps / t_learn, "windows_per_step": shard.world * args.batch, "prioritized": args.prioritized,
             "episodes_stored_rank0": store.n_finished, "loss_per_iter": losses,
             "seconds": {"selfplay": t_play, "learner": t_learn}}))
     if dist is not None:
