@@ -97,6 +97,21 @@ def _unroll(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, cp
     return (batch.is_weights * per_window).sum(), per_window, (lp.sum(), lv.sum(), lr.sum())
 
 
+def tune_small_gemms(results_file: str | None = None, max_ms: int = 30, max_iterations: int = 20) -> None:
+    """Lets torch time the rocBLAS / hipBLASLt solutions for every matrix product it meets and keep
+    the fastest (torch.cuda.tunable).  The libraries' default choice for the learner's products on
+    the small networks (a few hundred rows, 128-336 wide) is one 256 x 256 tile, i.e. ONE workgroup
+    per product, 30-70 us each; the tuned choices take 10-16 us.  The first step with a new shape
+    pays for the timing (seconds); `results_file` keeps the choices between runs (they are tied to
+    the library versions named in the file and ignored otherwise)."""
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.set_max_tuning_duration(max_ms)
+    tunable.set_max_tuning_iterations(max_iterations)
+    if results_file is not None:
+        tunable.set_filename(results_file)
+
+
 class DataParallelLearner:
     """One optimizer step over a batch of windows split across ranks.
 
@@ -146,6 +161,99 @@ class DataParallelLearner:
             off += n
         self.optimizer.step()
         return float(flat[-1] / norm), per_window.detach().abs().cpu()
+
+    # ------------------------------------------------------------------ recorded step
+    def step_local_recorded(self, local: WindowBatch):
+        """step_local replayed from HIP graphs: the unroll, its backward pass and the flattening
+        of the gradient are one recorded graph, the division by the weight total and the
+        optimizer step a second one, the all-reduce (world > 1) runs between the two.  On the
+        small networks a step is a few hundred launches of microsecond kernels, so replaying it
+        costs a fraction of issuing it.
+
+        Needs a fixed batch shape (DeviceEpisodeStore's samplers give one) and an optimizer whose
+        step can be recorded (torch.optim.Adam/AdamW(..., capturable=True), plain SGD; a learning
+        rate that changes must be a tensor).  The first call records (after one trial step whose
+        effect on the weights and the optimizer state is undone).  Returns DEVICE tensors
+        (normalised loss over all ranks, per-window |loss| of the local windows): nothing here
+        waits for the GPU."""
+        dev = self.params[0].device
+        fields = ("history", "actions", "policies", "z", "rewards", "is_weights")
+        shapes = tuple(tuple(getattr(local, f).shape) for f in fields)
+        if getattr(self, "_rec_shapes", None) != shapes:
+            self._record(local.to(dev), shapes)
+        for f in fields:
+            getattr(self._rec_batch, f).copy_(getattr(local, f), non_blocking=True)
+        self._rec_backward.replay()
+        if self.world > 1:
+            self.dist.all_reduce(self._rec_flat, op=self.dist.ReduceOp.SUM)
+        self._rec_update.replay()
+        return self._rec_loss, self._rec_per_window
+
+    def _backward_into_flat(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        wsum, per_window, _ = batched_unroll_loss(*self.nets, self._rec_batch, self.roll_ahead, self.coeff)
+        wsum.backward()
+        n = self._rec_flat.numel() - 2
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self._rec_flat[:n])
+        self._rec_flat[n] = self._rec_batch.is_weights.sum()
+        self._rec_flat[n + 1] = wsum.detach()
+        self._rec_per_window.copy_(per_window.detach().abs())
+
+    def _update_from_flat(self):
+        flat = self._rec_flat
+        norm = flat[-2]
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad.copy_((flat[off:off + n] / norm).view_as(p))
+            off += n
+        self.optimizer.step()
+        self._rec_loss.copy_(flat[-1] / norm)
+
+    def _record(self, local: WindowBatch, shapes):
+        import copy
+        dev = self.params[0].device
+        self._rec_batch = WindowBatch(*(t.clone() for t in (local.history, local.actions, local.policies, local.z,
+                                                            local.rewards, local.is_weights)))
+        n = sum(p.numel() for p in self.params)
+        self._rec_flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self._rec_per_window = torch.zeros(len(local), dtype=torch.float32, device=dev)
+        self._rec_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        # one trial step on a side stream (creates the optimizer state and every workspace), then
+        # the weights and the optimizer state go back to what they were
+        weights = [p.detach().clone() for p in self.params]
+        had_state = len(self.optimizer.state) > 0
+        saved = copy.deepcopy(self.optimizer.state_dict()) if had_state else None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._backward_into_flat()
+            self._update_from_flat()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():
+            for p, w in zip(self.params, weights):
+                p.copy_(w)
+            if had_state:
+                fresh = self.optimizer.state_dict()["state"]
+                for key, st in saved["state"].items():
+                    for name, v in st.items():
+                        if torch.is_tensor(v):
+                            fresh[key][name].copy_(v)
+            else:
+                for st in self.optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+        torch.cuda.synchronize(dev)
+        self._rec_backward, self._rec_update = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._rec_backward):
+            self._backward_into_flat()
+        with torch.cuda.graph(self._rec_update, pool=self._rec_backward.pool()):
+            self._update_from_flat()
+        self._rec_shapes = shapes
 
     def broadcast_weights(self, src: int = 0):
         """Learner -> actors: one flat broadcast; actors re-pack their MFMA weight blob afterwards

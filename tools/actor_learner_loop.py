@@ -27,6 +27,11 @@ def main():
     ap.add_argument("--moves-per-iter", type=int, default=42)
     ap.add_argument("--steps-per-iter", type=int, default=16)
     ap.add_argument("--batch", type=int, default=256, help="windows per rank and learner step")
+    ap.add_argument("--recorded", action="store_true",
+                    help="learner steps replayed from HIP graphs (DataParallelLearner.step_local_recorded)")
+    ap.add_argument("--tune-gemms", action="store_true",
+                    help="torch times the BLAS solutions for the learner's matrix products once (untimed warm-up) "
+                         "and keeps the fastest (muzero_amd.learner.tune_small_gemms)")
     ap.add_argument("--prioritized", action="store_true",
                     help="episodes drawn by priority (alpha 0.6, beta 1.0, src/replay_buffer.py:11-39 defaults), "
                          "priorities updated from the per-window loss; default: uniform")
@@ -35,7 +40,7 @@ def main():
     import bench
     from muzero_amd import sharding
     from muzero_amd.episode_store import DeviceEpisodeStore
-    from muzero_amd.learner import DataParallelLearner
+    from muzero_amd.learner import DataParallelLearner, tune_small_gemms
     from muzero_amd.selfplay import SelfPlayEngine
     from muzero_amd.training import z_targets_device
 
@@ -47,26 +52,42 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.tune_gemms:
+        tune_small_gemms()
     cfg, h, g, f = bench.build_networks()  # identical seed-0 weights on every rank
     h, g, f = h.to(dev), g.to(dev), f.to(dev)
     tcfg, gcfg = cfg.training, cfg.training_data_generator
     eng = SelfPlayEngine(h, g, f, args.games, gcfg, device=dev, seed=shard.rank, device_rng=True)
     store = DeviceEpisodeStore(args.games, gcfg.max_steps_per_episode, (2, 6, 7), 7, capacity=4 * args.games, device=dev)
     params = [p for n in (h, g, f) for p in n.parameters()]
-    opt = torch.optim.Adam(params, lr=tcfg.learning_rate, betas=tuple(tcfg.betas), weight_decay=tcfg.weight_decay)
+    opt = torch.optim.Adam(params, lr=tcfg.learning_rate, betas=tuple(tcfg.betas), weight_decay=tcfg.weight_decay,
+                           capturable=args.recorded)
     learner = DataParallelLearner(h, g, f, opt, tcfg.roll_ahead,
                                   (tcfg.policy_coefficient, tcfg.value_coefficient, tcfg.reward_coefficient), dist=dist)
     gen = torch.Generator(device=dev).manual_seed(1000 + shard.rank)
+    learner_step = learner.step_local_recorded if args.recorded else learner.step_local
 
     # untimed warm-up: first uses of the torch operators load their code objects
     for _ in range(3):
         store.record(*eng.move())
     for _ in range(gcfg.max_steps_per_episode):
         store.record(*eng.move())
-    for _ in range(2):  # and of autograd / the optimizer
-        batch, _, _ = store.sample_windows(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
-                                           tcfg.discount_factor, z_targets_device, generator=gen)
-        learner.step_local(batch)
+
+    def one_step():
+        if args.prioritized:
+            batch, slots, _ = store.sample_prioritized(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
+                                                       tcfg.discount_factor, z_targets_device, alpha=0.6, beta=1.0,
+                                                       generator=gen)
+            loss, errors = learner_step(batch)
+            store.update_priorities(slots, errors)
+        else:
+            batch, _, _ = store.sample_windows(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
+                                               tcfg.discount_factor, z_targets_device, generator=gen)
+            loss, _ = learner_step(batch)
+        return loss
+
+    for _ in range(3):  # and of the sampler / autograd / the optimizer
+        one_step()
     eng.nets.refresh()
 
     t_play = t_learn = 0.0
@@ -83,26 +104,17 @@ def main():
         t0 = time.perf_counter()
         last = float("nan")
         for _ in range(args.steps_per_iter):
-            if args.prioritized:
-                batch, slots, _ = store.sample_prioritized(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
-                                                           tcfg.discount_factor, z_targets_device, alpha=0.6, beta=1.0,
-                                                           generator=gen)
-                last, errors = learner.step_local(batch)
-                store.update_priorities(slots, errors)
-            else:
-                batch, _, _ = store.sample_windows(args.batch, tcfg.look_back, tcfg.roll_ahead, h.history_length,
-                                                   tcfg.discount_factor, z_targets_device, generator=gen)
-                last, _ = learner.step_local(batch)
+            last = one_step()
             steps += 1
         eng.nets.refresh()  # the actors search with the new weights from the next move on
         sharding.fence(dist)
         t_learn += sharding.max_over_ranks(time.perf_counter() - t0, dist, dev)
-        losses.append(last)
+        losses.append(float(last))
     if shard.rank == 0:
         print(json.dumps({
             "n_gpus": shard.world, "games_per_gpu": args.games, "iters": args.iters,
             "selfplay_env_steps_per_sec": shard.world * args.games * moves / t_play,
-            "learner_steps_per_sec": steps / t_learn, "windows_per_step": shard.world * args.batch, "prioritized": args.prioritized,
+            "learner_steps_per_sec": steps / t_learn, "windows_per_step": shard.world * args.batch, "prioritized": args.prioritized, "recorded": args.recorded, "tuned_gemms": args.tune_gemms,
             "episodes_stored_rank0": store.n_finished, "loss_per_iter": losses,
             "seconds": {"selfplay": t_play, "learner": t_learn}}))
     if dist is not None:
