@@ -287,7 +287,8 @@ constexpr int kTT = 512;       // threads of the tower kernel
 constexpr int kTW = kTT / 64;  // its waves
 
 struct TowerGeom {
-    int C, H, W, HW, P;  // P = group * HW positions normalised together
+    int C, H, W, HW, P;  // P = positions held by a workgroup (rows per workgroup * HW)
+    int group0, seg;     // rows per reference call, seg = group0 * HW positions normalised together
     int cmax;            // widest block output
     int stage_c;         // input channels of the first block staged per pass
     int pw, ks;          // waves across positions / slices of the input channels (pw * ks = kTW)
@@ -333,19 +334,21 @@ struct BnJob {
     float eps;
     int act;
 };
-__device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P) {
+__device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P, int seg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int jobs = j1.buf ? 2 * C : C;
+    const int nseg = P / seg, per_buf = C * nseg;  // a workgroup may hold several calls: one segment each
+    const int jobs = j1.buf ? 2 * per_buf : per_buf;
     for (int job = wave; job < jobs; job += kTW) {
-        const bool second = job >= C;
+        const bool second = job >= per_buf;
         const BnJob &J = second ? j1 : j0;
-        const int c = second ? job - C : job;
-        lds_f *v = J.buf + c * P;
+        const int jj = second ? job - per_buf : job;
+        const int c = jj / nseg, sg = jj - c * nseg;
+        lds_f *v = J.buf + c * P + sg * seg;
         // one sweep: sums of (x - pivot) and (x - pivot)^2, the pivot (the channel's first value)
         // keeping the squares small; the two wave reductions overlap
         const double pivot = (double)v[0];
         double s = 0.0, q = 0.0;
-        for (int p = lane; p < P; p += 64) {
+        for (int p = lane; p < seg; p += 64) {
             const double d = (double)v[p] - pivot;
             s += d;
             q += d * d;
@@ -354,14 +357,14 @@ __device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P) {
             s += __shfl_xor(s, o, 64);
             q += __shfl_xor(q, o, 64);
         }
-        const double ds = s / P, mean = pivot + ds;
-        const double var = fmax(q / P - ds * ds, 0.0);
+        const double ds = s / seg, mean = pivot + ds;
+        const double var = fmax(q / seg - ds * ds, 0.0);
         const double invstd = 1.0 / sqrt(var + (double)J.eps);
         const double ga = J.lg ? (double)J.lg[c] : (double)as_constant(J.gamma)[c];
         const double be = J.lb ? (double)J.lb[c] : (double)as_constant(J.beta)[c];
         const float scale = (float)(ga * invstd);
         const float shift = (float)(be - mean * ga * invstd);
-        for (int p = lane; p < P; p += 64) v[p] = activate(v[p] * scale + shift, J.act);
+        for (int p = lane; p < seg; p += 64) v[p] = activate(v[p] * scale + shift, J.act);
     }
 }
 
@@ -518,7 +521,7 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
     };
     auto add_row = [&](int r) -> const float * {
         if (row_add == nullptr) return nullptr;
-        const int sel = row_sel ? row_sel[r0 + r] : r;
+        const int sel = row_sel ? row_sel[r0 + r] : r % G.group0;
         return row_add + (long long)sel * ld_add;
     };
     // tower input (merge split applied) for channels [cb, cb+cn) -> dst[c * P + p].  A row's
@@ -824,7 +827,7 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
         MZ_TT(4)
         bn_act(BnJob{mid, R.bn1_w, R.bn1_b, pg, pg ? pg + Cout : nullptr, R.eps1, R.activation},
                BnJob{down ? aux : nullptr, R.dbn_w, R.dbn_b, pg ? pg + 4 * Cout : nullptr,
-                     pg ? pg + 5 * Cout : nullptr, R.epsd, MZ_ACT_NONE}, Cout, P);
+                     pg ? pg + 5 * Cout : nullptr, R.epsd, MZ_ACT_NONE}, Cout, P, G.seg);
         __syncthreads();
         MZ_TT(5)
         // ---- conv2: mid -> dst.  `cur` is free unless it still holds the identity skip.
@@ -868,7 +871,7 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
         MZ_TT(6)
         bn_act(BnJob{dst, R.bn2_w, R.bn2_b, pg ? pg + 2 * Cout : nullptr, pg ? pg + 3 * Cout : nullptr, R.eps2,
                      MZ_ACT_NONE},
-               BnJob{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, MZ_ACT_NONE}, Cout, P);
+               BnJob{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, MZ_ACT_NONE}, Cout, P, G.seg);
         __syncthreads();
         MZ_TT(7)
         // ---- skip connection + activation -> cur (input of the next block)
@@ -966,7 +969,7 @@ k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long l
     tower_body<4>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
 }
 
-int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
+int tower_geometry(const mz_tower *T, int group, int ng, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
     if (!T || T->n_blocks < 0 || T->n_blocks > MZ_MAX_BLOCKS || T->C <= 0 || T->H <= 0 || T->W <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: bad tower (n_blocks 0..%d, positive C, H, W)", MZ_MAX_BLOCKS);
     if (group <= 0) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: group must be positive");
@@ -975,8 +978,10 @@ int tower_geometry(const mz_tower *T, int group, bool vec_ok, TowerGeom *g, size
     g->H = T->H;
     g->W = T->W;
     g->HW = T->H * T->W;
-    g->P = group * g->HW;
-    if (T->n_blocks && g->P < 2)
+    g->group0 = group;
+    g->seg = group * g->HW;
+    g->P = ng * g->seg;  // ng reference calls per workgroup
+    if (T->n_blocks && g->seg < 2)
         // torch.nn.BatchNorm2d: "Expected more than 1 value per channel when training"
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: batch statistics need more than 1 value per channel");
     int cin = T->C;
@@ -1167,7 +1172,24 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec_ok = h_tower && h_tower->H > 0 && h_tower->W > 0 && (h_tower->H * h_tower->W) % 4 == 0 &&
                         ldx % 4 == 0 && aligned(x) && (!row_add || (ld_add % 4 == 0 && aligned(row_add)));
-    MZ_TRY(tower_geometry(h_tower, group, vec_ok, &g, &lds));
+    // With several groups per compute unit a workgroup takes up to four reference calls at once
+    // (each keeps its own batch statistics): the chain of round trips and barriers is paid once for
+    // them.  Kept to 192 positions per workgroup and to at least two workgroups per compute unit.
+    static const int ng_cap = [] {
+        const char *e = getenv("MZ_TOWER_CALLS_PER_WG");  // tuning aid
+        return e ? atoi(e) : 4;
+    }();
+    int ng = 1;
+    if (h_tower && group > 0 && B > 0 && B % group == 0 && h_tower->H > 0 && h_tower->W > 0) {
+        const int groups = B / group, seg = group * h_tower->H * h_tower->W;
+        for (int c = std::min(ng_cap, 4); c >= 2; --c)
+            if (groups % c == 0 && groups / c >= 512 && c * seg <= 192) {
+                ng = c;
+                break;
+            }
+    }
+    if (ng > 1 && tower_geometry(h_tower, group, ng, vec_ok, &g, &lds) != MZ_OK) ng = 1;
+    if (ng == 1) MZ_TRY(tower_geometry(h_tower, group, 1, vec_ok, &g, &lds));
     const int D = g.C * g.HW;
     if (!x || (!y && !t_out) || B < 0 || ldx < D || (y && ldy < D) || (row_add && ld_add < D))
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: NULL argument, negative B or a row stride below C*H*W=%d", D);
@@ -1184,12 +1206,13 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
         const char *e = getenv("MZ_TOWER_PACKED");  // tuning aid: 0 never, 1 always
         return e ? atoi(e) : -1;
     }();
-    const bool packed = packed_mode >= 0 ? packed_mode == 1 : (B / group > 256 && 2 * (lds + 1024) <= kMaxLds);
+    const int rows_per_wg = ng * group, wgs = B / rows_per_wg;
+    const bool packed = packed_mode >= 0 ? packed_mode == 1 : (wgs > 256 && 2 * (lds + 1024) <= kMaxLds);
     auto launch = [&](auto kernel, const char *name) -> int {
         MZ_TRY(allow_lds(kernel, lds, name));
-        hipLaunchKernelGGL(kernel, dim3(B / group), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x,
+        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x,
                            (long long)ldx, x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows,
-                           t_out, (long long)ld_t, group);
+                           t_out, (long long)ld_t, rows_per_wg);
         return mz::check_launch(name);
     };
     return packed ? launch(k_tower_packed, "k_tower_packed") : launch(k_tower, "k_tower");

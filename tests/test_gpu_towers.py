@@ -394,24 +394,30 @@ def test_tower_kernel_general_shapes_match_torch(shape, A, g_blocks, f_blocks, a
 
 
 def test_more_groups_than_compute_units():
-    """300 calls of batch size 1 in one launch (the build of the tower kernel that shares a compute
-    unit between two workgroups) against the torch modules evaluated call by call."""
+    """2048 reference calls in one launch -- batch size 1 (g step, f) and batch size A (expansion):
+    the build of the tower kernel that shares a compute unit between two workgroups, each workgroup
+    taking four calls with their own batch statistics -- against the torch modules call by call."""
     from muzero_amd.towers import TowerNetworks
     shape, A = (16, 4, 4), 3
     g, f = _random_tower_nets(shape, A, [(3, 3)], [(3, 3)], "relu", seed=11)
     D = int(np.prod(shape))
     nets = TowerNetworks(g, f)
-    B = 300
+    B = 2048
     torch.manual_seed(4)
     lat = torch.randn(B, *shape)
     act_t = torch.randint(0, A, (B,))
     with torch.no_grad():
         want_g = [g(lat[i:i + 1], act_t[i:i + 1]) for i in range(B)]
+        want_gA = [g(lat[i:i + 1].repeat(A, 1, 1, 1), torch.arange(A)) for i in range(B)]
         want_f = [f(lat[i:i + 1]) for i in range(B)]
     x = lat.reshape(B, D).cuda().contiguous()
     nxt = torch.zeros(B, D, device="cuda")
     rew = torch.zeros(B, device="cuda")
     nets.dynamics(x, B, action=act_t.to(torch.int32).cuda(), next_latent=nxt, reward=rew)
+    nxtA = torch.zeros(B * A, D, device="cuda")
+    rewA = torch.zeros(B, A, device="cuda")
+    nets.dynamics(x, B * A, rows=torch.arange(B, dtype=torch.int32, device="cuda").repeat_interleave(A), action=None,
+                  next_latent=nxtA, reward=rewA)
     pol = torch.zeros(B, A, device="cuda")
     val = torch.zeros(B, device="cuda")
     nets.prediction(x, B, policy=pol, value=val)
@@ -424,6 +430,8 @@ def test_more_groups_than_compute_units():
 
     close(nxt, torch.cat([w[0] for w in want_g]))
     close(rew, torch.cat([w[1] for w in want_g])[:, 0])
+    close(nxtA, torch.cat([w[0] for w in want_gA]))
+    close(rewA, torch.stack([w[1][:, 0] for w in want_gA]))
     close(pol, torch.cat([w[0] for w in want_f]))
     close(val, torch.cat([w[1] for w in want_f])[:, 0])
 
