@@ -46,6 +46,34 @@ def build_nets(shape, A):
     return g, f
 
 
+def cpu_network_time(g, f, shape, A, budget_s, threads):
+    """The torch modules on the host, called as the reference calls them per simulation
+    (src/search/expansion.py:25-30, src/search/simulation.py:31-44: 3 f calls at batch size 1, one g
+    call at batch size 1 and one at batch size A).  Tree bookkeeping is not included (microseconds
+    against the 18432 x 9216 fc_merge product of every g call)."""
+    import copy
+    g, f = copy.deepcopy(g).cpu(), copy.deepcopy(f).cpu()
+    torch.set_num_threads(threads)
+    lat1, latA = torch.randn(1, *shape), torch.randn(A, *shape)
+    a1, aA = torch.zeros(1, dtype=torch.long), torch.arange(A)
+    per_sim = []
+    with torch.no_grad():
+        f(lat1), g(lat1, a1)  # first-use costs
+        t_end = time.perf_counter() + budget_s
+        while time.perf_counter() < t_end or not per_sim:
+            t0 = time.perf_counter()
+            f(lat1)
+            g(latA, aA)
+            f(lat1)
+            g(lat1, a1)
+            f(lat1)
+            per_sim.append(time.perf_counter() - t0)
+    mean = sum(per_sim) / len(per_sim)
+    return {"value": 1.0 / mean, "unit": "sims/s", "cores": threads, "kind": "port",
+            "sample": f"network calls of {len(per_sim)} simulations (3 f at batch 1, g at batch 1 and {A}) on the "
+                      f"torch modules, {threads} host threads, {sum(per_sim):.1f}s"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=256)
@@ -54,6 +82,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--actions", type=int, default=5)
     ap.add_argument("--latent", type=int, nargs=3, default=[256, 6, 6])
+    ap.add_argument("--cpu-seconds", type=float, default=0.0, help="time the torch modules on the host for this long")
     args = ap.parse_args()
     from muzero_amd.engine import BatchedMCTS
     from muzero_amd.towers import TowerNetworks
@@ -61,6 +90,10 @@ def main() -> None:
     D = shape[0] * shape[1] * shape[2]
     t0 = time.time()
     g, f = build_nets(shape, A)
+    cpu = None
+    if args.cpu_seconds > 0:
+        cpu = cpu_network_time(g, f, shape, A, args.cpu_seconds, min(16, os.cpu_count() or 1))
+        t0 = time.time()
     nets = TowerNetworks(g, f)
     torch.cuda.synchronize()
     t_build = time.time() - t0
@@ -133,7 +166,7 @@ def main() -> None:
                      "achieved": merge_flop / merge_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": merge_flop / merge_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": merge_ms * 1e3,
                      "flop_per_launch": merge_flop, "traffic": pmc_traffic() if (G, D) == (256, 9216) else None},
-        "build_s": t_build, "warmup_search_s": warm_s,
+        "build_s": t_build, "warmup_search_s": warm_s, "cpu_baseline": cpu,
     }))
 
 
