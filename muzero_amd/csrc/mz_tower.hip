@@ -318,11 +318,6 @@ __device__ unsigned long long g_tower_stamps[16];
 typedef __attribute__((address_space(4))) const float cst_f;
 __device__ __forceinline__ cst_f *as_constant(const float *p) { return (cst_f *)p; }
 
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // In-place BatchNorm2d with the statistics of the P values of each channel (mean and biased
 // variance, accumulated in double as torch's CPU kernels do), then the activation.  One wave per
 // channel; a second buffer (the skip path), if given, is normalised by other waves at the same
