@@ -33,6 +33,16 @@ def pmc_traffic():
         return None
 
 
+def pmc_tower_traffic(G):
+    """HBM bytes per launch of the tower kernel's rollout-step call from the committed counter passes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_i_tower_pmc_traffic.json")) as fh:
+            d = json.load(fh)
+        return d["hbm_bytes_per_launch"] if d.get("groups") == G else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_nets(shape, A):
     from muzero_amd.config import DenseLayerConfig, DynamicsNetworkConfig, PredictionNetworkConfig, ResBlockConfig
     from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork
@@ -149,6 +159,29 @@ def main() -> None:
                                         next_latent=nxt, reward=rew))
     g1_ms = timed(lambda: nets.dynamics(mcts.pool.latent, G, rows=rows, action=arg.zero_(), next_latent=nxt[:G],
                                         reward=val))
+    # the tower kernel of the search form alone: g's rollout-step call (one reference call per tree; reads
+    # fc_merge's latent half, D floats per tree, adds the action's table row, which stays in L2, and
+    # writes the block output) and the expansion call (A children per tree; same input read once per tree)
+    tower_roofline = None
+    if nets.tower_f_t is not None:
+        dt_ = nets.bottleneck_g
+        base = torch.randn(G, D, device="cuda")
+        t_out = torch.empty(G * A, dt_, device="cuda")
+        sel = torch.zeros(G, dtype=torch.int32, device="cuda")
+        gidx = (torch.arange(G * A, dtype=torch.int32, device="cuda") // A).contiguous()
+        step_ms = timed(lambda: nets._tower_call(nets.tower_g, base, D, None, nets.table_t, sel, None, 0, None, G, 1,
+                                                 t_out=t_out))
+        exp_ms = timed(lambda: nets._tower_call(nets.tower_g, base, D, gidx, nets.table_t, None, None, 0, None, G * A,
+                                                A, t_out=t_out))
+        step_bytes = 4.0 * G * (D + dt_)
+        exp_bytes = 4.0 * G * (D + A * dt_)
+        tower_roofline = {"bound": "hbm", "kernel": "k_tower / k_tower_packed [g rollout step, search form]",
+                          "achieved": step_bytes / step_ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                          "frac": step_bytes / step_ms / 1e6 / 8000.0, "avg_launch_us": step_ms * 1e3,
+                          "bytes_per_launch": step_bytes,
+                          "expansion_call": {"avg_launch_us": exp_ms * 1e3, "bytes_per_launch": exp_bytes,
+                                             "achieved": exp_bytes / exp_ms / 1e6},
+                          "traffic": pmc_tower_traffic(G)}
     # reference arithmetic per simulation: 3 f calls and A+1 g calls, each g with the full 2D x D fc_merge
     F_heads = 2.0 * (D * 256 + 256 * 128 + 128 + D * 256 + 256 * 256 + 256 * A)
     F_tower = 2.0 * 36 * (shape[0] * 9 * 3 + 3 * 9 * 3 + shape[0] * 3 + 3 * shape[0])
@@ -166,6 +199,7 @@ def main() -> None:
                      "achieved": merge_flop / merge_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": merge_flop / merge_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": merge_ms * 1e3,
                      "flop_per_launch": merge_flop, "traffic": pmc_traffic() if (G, D) == (256, 9216) else None},
+        "roofline_tower": tower_roofline,
         "build_s": t_build, "warmup_search_s": warm_s, "cpu_baseline": cpu,
     }))
 
