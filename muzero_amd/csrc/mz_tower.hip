@@ -961,7 +961,7 @@ k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long l
                const int32_t *__restrict__ x_rows, const float *__restrict__ row_add, long long ld_add,
                const int32_t *__restrict__ row_sel, float *__restrict__ y, long long ldy,
                const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group) {
-    tower_body<4>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
+    tower_body<2>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
 }
 
 int tower_geometry(const mz_tower *T, int group, int ng, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
