@@ -653,7 +653,7 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
             // input goes from global memory straight into the matrix instruction's operand (no
             // staging): lane (m, q) of v_mfma_f32_16x16x4 supplies positions 4m..4m+3 of channel
             // 4*step + q, one 16-byte load, used by the four tiles t = 0..3 whose row m is position
-            // 4m + t.  The waves split the channels; their partial tiles are summed in wave order.
+            // 4m + t.  The waves split the channels; their partial tiles are summed in a fixed order.
             const int kk = k * k, ncol = Cout * kk + (down ? Cout : 0);
             lds_f *part = stage, *Yt = stage + (kTW / 2) * kG1Cols * G.part_ld;
             const int m = lane & 15, q = lane >> 4;
@@ -673,8 +673,15 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
                     wstr[nt] = 1;
                 }
             }
-            for (int pb = 0; pb < P; pb += 64) {
+            // Passes of 64 positions.  A call with several passes (the expansion's A children, or
+            // several calls per workgroup) gives them to CS wave sets working side by side, each
+            // set splitting the channels KS = kTW / CS ways: one round of barriers for CS passes.
+            const int npass = (P + 63) >> 6;
+            const int CS = npass >= 3 ? 4 : npass, KS = kTW / CS;
+            const int cs = wave % CS, ks = wave / CS;
+            for (int pb0 = 0; pb0 < P; pb0 += 64 * CS) {
                 MZ_TT(1)
+                const int pb = pb0 + 64 * cs;
                 const int p4 = pb + 4 * m;
                 const bool live = p4 < P;  // P % 4 == 0: the four positions are live together
                 const int r = live ? p4 / HW : 0, sp = live ? p4 - r * HW : 0;
@@ -685,12 +692,13 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
                 for (int t = 0; t < 4; ++t)
                     for (int nt = 0; nt < 2; ++nt) acc[t][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 constexpr int UN = DEPTH;  // k-steps whose loads are in flight together
-                for (int k0 = wave; k0 < nsteps; k0 += kTW * UN) {
+                if (pb < P)
+                for (int k0 = ks; k0 < nsteps; k0 += KS * UN) {
                     f32x4 xv[UN], av[UN];
                     float wv[UN][2];
 #pragma unroll
                     for (int u = 0; u < UN; ++u) {
-                        const int ci = 4 * (k0 + u * kTW) + q;
+                        const int ci = 4 * (k0 + u * KS) + q;
                         const bool ok = ci < Cin;
                         xv[u] = av[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         if (ok && xr) xv[u] = *reinterpret_cast<const f32x4 *>(xr + (long long)ci * HW);
@@ -717,13 +725,13 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
                 }
                 MZ_TT(2)
                 // element i of tile (t, nt) in lane (n, mq) is position 16 mq + 4 i + t, column 16 nt + n.
-                // The upper half of the waves parks its tiles, the lower half adds its own (wave w
-                // + wave w + kTW/2), then all threads sum the kTW/2 rows in wave order.
-                const int lim = min(64, (P - pb + 15) & ~15);  // positions of this pass that are stored
+                // The upper half of a set's channel slices parks its tiles, the lower half adds its own
+                // (slice j + slice j + KS/2), then all threads sum the KS/2 rows of each pass in order.
+                const int lim = pb < P ? min(64, (P - pb + 15) & ~15) : 0;  // positions of this pass that are stored
                 const int pl = G.part_ld;
-                lds_f *mine = part + (((wave & (kTW / 2 - 1)) * kG1Cols + m) * pl + 16 * q);
-                __syncthreads();  // the previous pass's partials have been summed
-                if (wave >= kTW / 2 && 16 * q < lim) {
+                lds_f *mine = part + ((((ks % (KS / 2)) * CS + cs) * kG1Cols + m) * pl + 16 * q);
+                __syncthreads();  // the previous round's partials have been summed
+                if (ks >= KS / 2 && 16 * q < lim) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -732,7 +740,7 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
                                 f32x4{acc[0][nt][i], acc[1][nt][i], acc[2][nt][i], acc[3][nt][i]};
                 }
                 __syncthreads();
-                if (wave < kTW / 2 && 16 * q < lim) {
+                if (ks < KS / 2 && 16 * q < lim) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -743,18 +751,19 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
                         }
                 }
                 __syncthreads();
-                {
-                    const int col = tid >> 4, c4 = (tid & 15) << 2;  // kTT = 32 columns x 16 vectors
-                    if (c4 < lim) {
+                for (int v = tid; v < CS * kG1Cols * 16; v += kTT) {  // per pass: 32 columns x 16 vectors
+                    const int c = v / (kG1Cols * 16), col = (v >> 4) & (kG1Cols - 1), c4 = (v & 15) << 2;
+                    const int pbc = pb0 + 64 * c;
+                    if (pbc < P && c4 < min(64, (P - pbc + 15) & ~15)) {
                         f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
-                        for (int w = 0; w < kTW / 2; ++w) {
-                            const f32x4 v = *reinterpret_cast<const lds_f4 *>(part + (w * kG1Cols + col) * pl + c4);
-                            sum.x += v.x;
-                            sum.y += v.y;
-                            sum.z += v.z;
-                            sum.w += v.w;
+                        for (int j = 0; j < KS / 2; ++j) {
+                            const f32x4 w4 = *reinterpret_cast<const lds_f4 *>(part + ((j * CS + c) * kG1Cols + col) * pl + c4);
+                            sum.x += w4.x;
+                            sum.y += w4.y;
+                            sum.z += w4.z;
+                            sum.w += w4.w;
                         }
-                        *reinterpret_cast<lds_f4 *>(Yt + col * G.y_ld + pb + c4) = sum;
+                        *reinterpret_cast<lds_f4 *>(Yt + col * G.y_ld + pbc + c4) = sum;
                     }
                 }
             }
