@@ -349,6 +349,7 @@ def _random_tower_nets(shape, A, g_blocks, f_blocks, act, seed):
     ((40, 5, 5), 3, [(40, 3)], [(12, 3), (40, 3), (7, 3), (40, 3)], "tanh"),  # 40 channels: 10 output-channel passes; 4 blocks; tanh
     ((3, 7, 9), 4, [(9, 5), (3, 3)], [(3, 3)], "sigmoid"),            # odd H x W (no 16-byte rows), ends on C channels without res_final
     ((130, 6, 6), 2, [(3, 3)], [(3, 3)], "relu"),                     # the shipped form with a channel count that is no multiple of 4
+    ((32, 6, 6), 10, [(3, 3)], [(3, 3)], "relu"),                     # 360 positions per expansion call: six 64-position passes, two rounds of wave sets
     ((8, 4, 4), 6, [(1, 5)], [(2, 3), (8, 1)], "relu"),               # matrix-product first block with k = 5 (26 columns), 96 positions per expansion call; a later k = 1 block; no res_final in f
 ])
 def test_tower_kernel_general_shapes_match_torch(shape, A, g_blocks, f_blocks, act):
