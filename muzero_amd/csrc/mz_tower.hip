@@ -5,9 +5,12 @@
 //   * the ResBlock tower with the batch statistics of one network call per group of rows;
 //   * policy post-processing.
 // The convolutions of the shipped g/f towers are skinny (256 -> 3 -> 3 -> 256 channels on a
-// 6 x 6 latent): a 16-wide matrix tile would idle on 13 of 16 columns, so they run on the
-// 4 x 4 x 1 matrix instruction (16 independent 4-position x 4-channel blocks per wave); the
-// 16 x 16 tiles take fc_merge and the heads.
+// 6 x 6 latent).  The first one (and the 1 x 1 skip convolution beside it) is one matrix product
+// over (output channel, tap) columns -- 27 + 3 of 32 columns of two 16 x 16 x 4 tiles -- whose
+// shifted rows are then summed; the 3 -> 3 convolution after it is a thread per output value.
+// Blocks with more output channels, or whose (channel, tap) columns exceed 32, run on the
+// 4 x 4 x 1 matrix instruction (16 independent 4-position x 4-channel blocks per wave), where a
+// 16-wide tile would idle on most of its columns.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
