@@ -94,6 +94,20 @@ int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float 
                           const float *reward, const float *next_latent,
                           const int32_t *rand_child, int32_t *out_child, void *stream);
 
+/* mz_tree_select / mz_tree_expand_commit that also return pool ROW indices (tree * cap + node),
+ * the form the network entry points gather and scatter latents by: out_row i32[G] = row of the
+ * selected leaf, out_child_rows i32[G][A] = rows its A children would get (n_nodes .. n_nodes+A-1),
+ * out_child_row i32[G] = row of the drawn child (tree * cap - 1 where out_child = -1).  Any of the
+ * three may be NULL.  Same reference lines as the two calls above; the lock-step search uses
+ * these to save the index arithmetic launches between selection and the network calls. */
+int mz_tree_select_rows(const mz_pool *pool, const double *sqrt_tab, const double *log_tab,
+                        int32_t tab_len, int32_t flags, int32_t *out_leaf, int32_t *out_depth,
+                        int32_t *out_row, int32_t *out_child_rows, void *stream);
+int mz_tree_expand_commit_rows(const mz_pool *pool, const int32_t *leaf, const float *prior,
+                               const float *reward, const float *next_latent,
+                               const int32_t *rand_child, int32_t *out_child,
+                               int32_t *out_child_row, void *stream);
+
 /* Root prior perturbation: src/search/mcts.py:91-94 (in float32:
  * P <- P + ((1-eps)*P + eps*eta), i.e. (2-eps)*P + eps*eta).  eta f32[G][A]. */
 int mz_tree_root_noise(const mz_pool *pool, const float *eta, double noise_frac, void *stream);

@@ -9,6 +9,7 @@
 // This file is compiled with -ffp-contract=off: every score and return is a chain of
 // individually rounded IEEE operations in the reference's order and precision, never an
 // FMA, so that argmax decisions and float64 value sums are bit-identical to CPython's.
+#include <cstdint>
 #include <algorithm>
 #include <type_traits>
 
@@ -68,7 +69,8 @@ __global__ void k_gather_latent(mz_pool p, const int32_t *__restrict__ idx, floa
 // and are scored in float32 (the state MCTS.run leaves them in, src/search/mcts.py:94).
 template <int LPT>
 __global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const double *__restrict__ log_tab,
-                         int tab_len, int flags, int32_t *__restrict__ out_leaf, int32_t *__restrict__ out_depth) {
+                         int tab_len, int flags, int32_t *__restrict__ out_leaf, int32_t *__restrict__ out_depth,
+                         int32_t *__restrict__ out_row, int32_t *__restrict__ out_child_rows) {
     extern __shared__ double s_tab[];  // [tab_len] sqrt, then [tab_len] log term
     for (int i = threadIdx.x; i < tab_len; i += blockDim.x) {
         s_tab[i] = sqrt_tab[i];
@@ -84,14 +86,17 @@ __global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const d
     if (a == 0) {
         out_leaf[g] = leaf;
         if (out_depth) out_depth[g] = depth;
+        if (out_row) out_row[g] = g * p.cap + leaf;
     }
+    // pool rows an expansion of this leaf would give its children
+    if (out_child_rows && a < p.A) out_child_rows[g * p.A + a] = g * p.cap + p.n_nodes[g] + a;
 }
 
 // src/search/expansion.py:30-35 + src/search/nodes.py:24-30.
 template <int LPT>
 __global__ void k_expand_commit(mz_pool p, const int32_t *__restrict__ leaf, const float *__restrict__ prior,
                                 const float *__restrict__ reward, const int32_t *__restrict__ rand_child,
-                                int32_t *__restrict__ out_child) {
+                                int32_t *__restrict__ out_child, int32_t *__restrict__ out_child_row) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / LPT;
     const int a = t % LPT;
@@ -113,6 +118,7 @@ __global__ void k_expand_commit(mz_pool p, const int32_t *__restrict__ leaf, con
         } else {
             out_child[g] = -1;
         }
+        if (out_child_row) out_child_row[g] = g * p.cap + out_child[g];
     }
 }
 
@@ -191,27 +197,38 @@ int mz_tree_init(const mz_pool *pool, const int8_t *root_to_play, const float *r
     return MZ_OK;
 }
 
-int mz_tree_select(const mz_pool *pool, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
-                   int32_t flags, int32_t *out_leaf, int32_t *out_depth, void *stream) {
+int mz_tree_select_rows(const mz_pool *pool, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
+                        int32_t flags, int32_t *out_leaf, int32_t *out_depth, int32_t *out_row,
+                        int32_t *out_child_rows, void *stream) {
     MZ_TRY(mz::check_pool(pool, false));
     if (!sqrt_tab || !log_tab || tab_len <= 0 || !out_leaf)
         return mz::fail(MZ_ERR_ARG, "mz_tree_select: NULL table/output or tab_len <= 0");
+    if ((long long)pool->G * pool->cap > INT32_MAX)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_select: G * cap exceeds the 32-bit row index");
     size_t lds = sizeof(double) * 2 * (size_t)tab_len;
     if (lds > 64 * 1024) return mz::fail(MZ_ERR_ARG, "mz_tree_select: tab_len %d exceeds the 4096-entry LDS table", tab_len);
     hipStream_t st = (hipStream_t)stream;
     return dispatch_lpt(pool->A, [&](auto lpt) {
         constexpr int LPT = decltype(lpt)::value;
         hipLaunchKernelGGL(k_select<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), lds, st,
-                           *pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth);
+                           *pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth, out_row, out_child_rows);
         return mz::check_launch("k_select");
     });
 }
 
-int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float *prior, const float *reward,
-                          const float *next_latent, const int32_t *rand_child, int32_t *out_child, void *stream) {
+int mz_tree_select(const mz_pool *pool, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
+                   int32_t flags, int32_t *out_leaf, int32_t *out_depth, void *stream) {
+    return mz_tree_select_rows(pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth, nullptr, nullptr, stream);
+}
+
+int mz_tree_expand_commit_rows(const mz_pool *pool, const int32_t *leaf, const float *prior, const float *reward,
+                               const float *next_latent, const int32_t *rand_child, int32_t *out_child,
+                               int32_t *out_child_row, void *stream) {
     MZ_TRY(mz::check_pool(pool, next_latent != nullptr));
     if (!leaf || !prior || !reward || !rand_child || !out_child)
         return mz::fail(MZ_ERR_ARG, "mz_tree_expand_commit: NULL argument");
+    if ((long long)pool->G * pool->cap > INT32_MAX)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_expand_commit: G * cap exceeds the 32-bit row index");
     hipStream_t st = (hipStream_t)stream;
     if (next_latent) {
         long long total = (long long)pool->G * pool->A * pool->D;
@@ -222,9 +239,14 @@ int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float 
     return dispatch_lpt(pool->A, [&](auto lpt) {
         constexpr int LPT = decltype(lpt)::value;
         hipLaunchKernelGGL(k_expand_commit<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), 0,
-                           st, *pool, leaf, prior, reward, rand_child, out_child);
+                           st, *pool, leaf, prior, reward, rand_child, out_child, out_child_row);
         return mz::check_launch("k_expand_commit");
     });
+}
+
+int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float *prior, const float *reward,
+                          const float *next_latent, const int32_t *rand_child, int32_t *out_child, void *stream) {
+    return mz_tree_expand_commit_rows(pool, leaf, prior, reward, next_latent, rand_child, out_child, nullptr, stream);
 }
 
 int mz_tree_root_noise(const mz_pool *pool, const float *eta, double noise_frac, void *stream) {

@@ -67,21 +67,29 @@ class TreePool:
         _hip.check(_hip.lib().mz_tree_init(C.byref(self.c), ptr(root_to_play), ptr(root_latent), _stream()),
                    "mz_tree_init")
 
-    def select(self, out_leaf: torch.Tensor, out_depth: torch.Tensor | None = None, root_f32: bool = True) -> None:
+    def select(self, out_leaf: torch.Tensor, out_depth: torch.Tensor | None = None, root_f32: bool = True,
+               out_row: torch.Tensor | None = None, out_child_rows: torch.Tensor | None = None) -> None:
+        """out_row i32[G] / out_child_rows i32[G, A] (optional): pool rows (tree * cap + node) of the
+        leaf and of the children an expansion would give it."""
         assert out_leaf.dtype == torch.int32 and out_leaf.numel() == self.G
-        _hip.check(_hip.lib().mz_tree_select(C.byref(self.c), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
-                                             _hip.SELECT_ROOT_F32 if root_f32 else 0, ptr(out_leaf),
-                                             ptr(out_depth), _stream()), "mz_tree_select")
+        for t, n in ((out_row, self.G), (out_child_rows, self.G * self.A)):
+            assert t is None or (t.dtype == torch.int32 and t.numel() == n and t.is_contiguous())
+        _hip.check(_hip.lib().mz_tree_select_rows(C.byref(self.c), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
+                                                  _hip.SELECT_ROOT_F32 if root_f32 else 0, ptr(out_leaf),
+                                                  ptr(out_depth), ptr(out_row), ptr(out_child_rows), _stream()),
+                   "mz_tree_select")
 
-    def expand_commit(self, leaf, prior, reward, rand_child, out_child, next_latent=None) -> None:
+    def expand_commit(self, leaf, prior, reward, rand_child, out_child, next_latent=None, out_child_row=None) -> None:
         assert prior.dtype == torch.float32 and prior.numel() == self.G * self.A and prior.is_contiguous()
         assert reward.dtype == torch.float32 and reward.numel() == self.G * self.A and reward.is_contiguous()
         assert rand_child.dtype == torch.int32 and rand_child.numel() == self.G and rand_child.is_contiguous()
         assert leaf.dtype == torch.int32 and out_child.dtype == torch.int32
+        assert out_child_row is None or (out_child_row.dtype == torch.int32 and out_child_row.numel() == self.G)
         if next_latent is not None:
             assert next_latent.dtype == torch.float32 and next_latent.numel() == self.G * self.A * self.D
-        _hip.check(_hip.lib().mz_tree_expand_commit(C.byref(self.c), ptr(leaf), ptr(prior), ptr(reward),
-                                                    ptr(next_latent), ptr(rand_child), ptr(out_child), _stream()),
+        _hip.check(_hip.lib().mz_tree_expand_commit_rows(C.byref(self.c), ptr(leaf), ptr(prior), ptr(reward),
+                                                         ptr(next_latent), ptr(rand_child), ptr(out_child),
+                                                         ptr(out_child_row), _stream()),
                    "mz_tree_expand_commit")
 
     def root_noise(self, eta: torch.Tensor, noise_frac: float) -> None:
@@ -245,8 +253,10 @@ class BatchedMCTS:
         """expand_node (src/search/expansion.py:9-35) for one node per tree (`root`: the nodes are
         the roots, whose latents come from h and have no stored bottleneck values)."""
         pool, nets, G, A = self.pool, self.nets, self.G, self.A
-        rows = torch.add(self.tree_base, node, out=self.rows_buf[0])
-        next_rows = torch.add(self.child_slots, pool.n_nodes[:, None], out=self.next_rows_buf).view(-1)
+        if root:  # no selection came before: the index vectors are formed here
+            torch.add(self.tree_base, node, out=self.rows_buf[0])
+            torch.add(self.child_slots, pool.n_nodes[:, None], out=self.next_rows_buf)
+        rows, next_rows = self.rows_buf[0], self.next_rows_buf.view(-1)  # else: written by pool.select
         rows_rep = rows if getattr(nets, "strided_outputs", False) else rows.repeat_interleave(A)  # per group is enough there
         main = torch.cuda.current_stream()
         f_extra = {"t_in": (self.t_pool, rows)} if self.t_pool is not None and not root else {}
@@ -263,13 +273,13 @@ class BatchedMCTS:
                       reward=self.reward, **extra)
         if self.side is not None:
             main.wait_stream(self.side)
-        pool.expand_commit(node, self.prior, self.reward, rand_child, out_child)
+        pool.expand_commit(node, self.prior, self.reward, rand_child, out_child, out_child_row=self.rows_buf[1])
 
     def _simulate(self, child: torch.Tensor) -> torch.Tensor:
         """MuZeroSimulation (src/search/simulation.py:23-45) from one node per tree;
         returns rollout f32[G, depth+1]."""
         pool, nets, G = self.pool, self.nets, self.G
-        cur, rows = pool.latent, torch.add(self.tree_base, child, out=self.rows_buf[1])
+        cur, rows = pool.latent, self.rows_buf[1]  # rows of `child`, written by pool.expand_commit
         strided = getattr(nets, "strided_outputs", False)  # heads write into the columns of self.rollout directly
         out_col = (lambda d: self.rollout[:, d]) if strided else (lambda d: self.rollout_t[d])
         main = torch.cuda.current_stream()
@@ -307,7 +317,7 @@ class BatchedMCTS:
 
     def _step(self, rand_column: torch.Tensor) -> torch.Tensor:
         """One `_step` (src/search/mcts.py:76-83) for every tree; returns the rollouts."""
-        self.pool.select(self.leaf)
+        self.pool.select(self.leaf, out_row=self.rows_buf[0], out_child_rows=self.next_rows_buf)
         self._expand(self.leaf, rand_column, self.child)
         rollout = self._simulate(self.child)
         self.pool.backup(self.child, self.leaf, rollout, self.discount)

@@ -134,3 +134,34 @@ def test_full_pool_and_table_overflow_are_reported():
     pool.visit[0, 0] = pool.tab_len + 5  # outside the PUCT tables
     pool.select(leaf)
     assert leaf[0].item() == -1 and leaf[1].item() >= 0
+
+
+@pytest.mark.parametrize("A,S,G", [(7, 12, 300), (18, 6, 70), (40, 4, 65)])
+def test_row_index_outputs(A, S, G):
+    """mz_tree_select_rows / mz_tree_expand_commit_rows: the same leaves and children as the plain
+    calls, plus pool rows tree * cap + node for the leaf, its future children and the drawn child."""
+    from muzero_amd.engine import TreePool
+    st = random_streams(G, A, S, 1, seed=A)
+    d = streams_to_device(st)
+    a, b = TreePool(G, A, S, D=1, with_latent=False), TreePool(G, A, S, D=1, with_latent=False)
+    i32 = dict(dtype=torch.int32, device="cuda")
+    leaf_a, leaf_b, child_a, child_b = (torch.zeros(G, **i32) for _ in range(4))
+    row, child_row, kids = torch.zeros(G, **i32), torch.zeros(G, **i32), torch.zeros((G, A), **i32)
+    base = torch.arange(G, **i32) * a.cap
+    for p in (a, b):
+        p.init(d["to_play"])
+    a.expand_commit(leaf_a, d["prior"][0], d["reward"][0], d["rand"][0], child_a)
+    b.expand_commit(leaf_b, d["prior"][0], d["reward"][0], d["rand"][0], child_b, out_child_row=child_row)
+    assert torch.equal(child_a, child_b) and torch.equal(child_row, base + child_b)
+    for s in range(S):
+        a.select(leaf_a)
+        n_before = b.n_nodes.clone()
+        b.select(leaf_b, out_row=row, out_child_rows=kids)
+        assert torch.equal(leaf_a, leaf_b) and torch.equal(row, base + leaf_b)
+        assert torch.equal(kids, (base + n_before)[:, None] + torch.arange(A, **i32)[None, :])
+        a.expand_commit(leaf_a, d["prior"][s + 1], d["reward"][s + 1], d["rand"][s + 1], child_a)
+        b.expand_commit(leaf_b, d["prior"][s + 1], d["reward"][s + 1], d["rand"][s + 1], child_b, out_child_row=child_row)
+        assert torch.equal(child_a, child_b) and torch.equal(child_row, base + child_b)
+        a.backup(child_a, leaf_a, d["sim"][s], 0.997)
+        b.backup(child_b, leaf_b, d["sim"][s], 0.997)
+    assert torch.equal(a.visit, b.visit) and torch.equal(a.value_sum, b.value_sum)
