@@ -958,15 +958,16 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
     MZ_TT(9)
 }
 
-// Two builds of the tower: up to one workgroup per compute unit, each call is a chain of memory
-// round trips and the deep variant keeps more loads in flight; with more workgroups than compute
-// units the shallow one fits two workgroups per unit (128 vector registers), which overlap.
+// Two builds of the tower.  Up to one workgroup per compute unit each call is a chain of memory
+// round trips: 4 k-steps of loads in flight per wave (8 were no faster, 2 slower).  With more
+// workgroups than compute units the second build is held to 128 vector registers so that two
+// workgroups share a unit and hide each other's round trips; there 2 k-steps in flight are best.
 __global__ void __launch_bounds__(kTT)
 k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
         const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
         float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, float *__restrict__ t_out,
         long long ld_t, int group) {
-    tower_body<8>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
+    tower_body<4>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
 }
 __global__ void __launch_bounds__(kTT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx,
