@@ -321,6 +321,27 @@ __device__ unsigned long long g_tower_stamps[16];
 typedef __attribute__((address_space(4))) const float cst_f;
 __device__ __forceinline__ cst_f *as_constant(const float *p) { return (cst_f *)p; }
 
+// Sum of a double over the wave, the same value in every lane: an inclusive scan inside each row
+// of 16 lanes on the DPP path (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0),
+// then the four row totals added in order.  No LDS traffic, unlike a shuffle tree.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v = dpp_add<0x111>(v);
+    v = dpp_add<0x112>(v);
+    v = dpp_add<0x114>(v);
+    v = dpp_add<0x118>(v);
+    auto row_total = [&](int lane) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                                __builtin_amdgcn_readlane(__double2loint(v), lane));
+    };
+    return ((row_total(15) + row_total(31)) + row_total(47)) + row_total(63);
+}
+
 // In-place BatchNorm2d with the statistics of the P values of each channel (mean and biased
 // variance, accumulated in double as torch's CPU kernels do), then the activation.  One wave per
 // channel; a second buffer (the skip path), if given, is normalised by other waves at the same
@@ -343,7 +364,7 @@ __device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P, int seg) 
         const int c = jj / nseg, sg = jj - c * nseg;
         lds_f *v = J.buf + c * P + sg * seg;
         // one sweep: sums of (x - pivot) and (x - pivot)^2, the pivot (the channel's first value)
-        // keeping the squares small; the two wave reductions overlap
+        // keeping the squares small
         const double pivot = (double)v[0];
         double s = 0.0, q = 0.0;
         for (int p = lane; p < seg; p += 64) {
@@ -351,10 +372,8 @@ __device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P, int seg) 
             s += d;
             q += d * d;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            q += __shfl_xor(q, o, 64);
-        }
+        s = wave_total(s);
+        q = wave_total(q);
         const double ds = s / seg, mean = pivot + ds;
         const double var = fmax(q / seg - ds * ds, 0.0);
         const double invstd = 1.0 / sqrt(var + (double)J.eps);
