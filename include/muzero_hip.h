@@ -171,6 +171,15 @@ int mz_mlp_pack(const mz_mlp *h_mlp, const mz_packed_mlp *h_plan, float *blob, v
 int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,
                    const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream);
 
+/* mz_mlp_forward for a policy head, with the post-processing of the search in the same launch:
+ * argmax i32[B] (may be NULL) = first maximum of each output row (the action MuZeroSimulation
+ * takes, src/search/simulation.py:35), then softmax_times further softmax passes over the row
+ * (expand_node's extra softmax, src/search/expansion.py:30) before y is stored.  y may be NULL when
+ * only the argmax is wanted.  Same arithmetic as mz_mlp_forward followed by mz_policy_post. */
+int mz_mlp_forward_post(const mz_packed_mlp *plan, const float *blob, const float *x, int64_t ldx,
+                        const int32_t *x_rows, float *y, int64_t ldy, int32_t B,
+                        int32_t softmax_times, int32_t *argmax, void *stream);
+
 /* g: DynamicsNetwork.forward for MLP-only configs, src/neural_networks/neural_network.py:152-188
  *    next = relu(fc_merge([latent ; action_embedding[action]])), reward = reward_mlp(next).
  * f: PredictionNetwork.forward, :234-262: value = value_mlp(latent), policy = policy_mlp(latent)

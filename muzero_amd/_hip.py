@@ -111,6 +111,8 @@ _SIGS = {
     "mz_mlp_plan": (C.c_int64, [C.POINTER(Mlp), C.c_int64, C.POINTER(PackedMlp)]),
     "mz_mlp_pack": (C.c_int, [C.POINTER(Mlp), C.POINTER(PackedMlp), _P, _P]),
     "mz_mlp_forward": (C.c_int, [C.POINTER(PackedMlp), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P]),
+    "mz_mlp_forward_post": (C.c_int, [C.POINTER(PackedMlp), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, C.c_int32,
+                                      _P, _P]),
     "mz_nets_plan": (C.c_int, [C.POINTER(DynamicsNet), C.POINTER(PredictionNet), C.POINTER(PackedNets)]),
     "mz_nets_pack": (C.c_int, [C.POINTER(DynamicsNet), C.POINTER(PredictionNet), C.POINTER(PackedNets), _P, _P]),
     "mz_dynamics_forward": (C.c_int, [C.POINTER(PackedNets), _P, _P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P,

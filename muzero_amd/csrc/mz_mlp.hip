@@ -47,7 +47,8 @@ __global__ void k_action_table(const float *__restrict__ emb, const float *__res
 template <int MT>
 __global__ void __launch_bounds__(kThreads)
 k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__restrict__ x, long long ldx,
-              const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B) {
+              const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B, int softmax_times,
+              int32_t *__restrict__ argmax) {
     extern __shared__ __align__(16) float smem[];
     constexpr int TM = 16 * MT;
     const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
@@ -59,8 +60,22 @@ k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__re
         return src < 0 ? nullptr : x + src * ldx;
     });
     int ld_out;
-    const lds_f *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    lds_f *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
+    // policy heads: the first maximum of each row, then `softmax_times` more softmax passes
+    // (src/search/simulation.py:35, src/search/expansion.py:30) before the store
+    if (argmax && (int)threadIdx.x < rows) {
+        const lds_f *p = out + threadIdx.x * ld_out;
+        int best = 0;
+        for (int i = 1; i < N; ++i)
+            if (p[i] > p[best]) best = i;
+        argmax[row0 + threadIdx.x] = best;
+    }
+    if (y == nullptr) return;
+    if (softmax_times > 0) {
+        __syncthreads();
+        softmax_rows(out, ld_out, TM, N, softmax_times);
+    }
     for (int i = threadIdx.x; i < rows * N; i += kThreads) {
         const int r = i / N, c = i - r * N;
         y[(long long)(row0 + r) * ldy + c] = out[r * ld_out + c];
@@ -245,10 +260,13 @@ int mz_mlp_pack(const mz_mlp *h_mlp, const mz_packed_mlp *h_plan, float *blob, v
     return MZ_OK;
 }
 
-int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,
-                   const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream) {
-    if (!h_plan || !blob || !x || !y || B < 0 || ldx < h_plan->in_features || ldy < h_plan->out_features)
-        return mz::fail(MZ_ERR_ARG, "mz_mlp_forward: NULL argument, negative B or row stride below the row width");
+int mz_mlp_forward_post(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,
+                        const int32_t *x_rows, float *y, int64_t ldy, int32_t B, int32_t softmax_times,
+                        int32_t *argmax, void *stream) {
+    if (!h_plan || !blob || !x || (!y && !argmax) || B < 0 || ldx < h_plan->in_features ||
+        (y && ldy < h_plan->out_features) || softmax_times < 0)
+        return mz::fail(MZ_ERR_ARG, "mz_mlp_forward: NULL argument, negative B or softmax_times, or row stride below "
+                        "the row width");
     if (B == 0) return MZ_OK;
     hipStream_t st = (hipStream_t)stream;
     size_t per_row = (size_t)lds_stride(h_plan->in_features) + 2 * (size_t)lds_stride(h_plan->max_width);
@@ -257,15 +275,21 @@ int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *
         [&](size_t lds) {
             MZ_TRY(allow_lds(k_mlp_forward<1>, lds, "k_mlp_forward"));
             hipLaunchKernelGGL(k_mlp_forward<1>, dim3((B + 15) / 16), dim3(kThreads), lds, st, *h_plan, blob, x,
-                               (long long)ldx, x_rows, y, (long long)ldy, B);
+                               (long long)ldx, x_rows, y, (long long)ldy, B, softmax_times, argmax);
             return mz::check_launch("k_mlp_forward<1>");
         },
         [&](size_t lds) {
             MZ_TRY(allow_lds(k_mlp_forward<2>, lds, "k_mlp_forward"));
             hipLaunchKernelGGL(k_mlp_forward<2>, dim3((B + 31) / 32), dim3(kThreads), lds, st, *h_plan, blob, x,
-                               (long long)ldx, x_rows, y, (long long)ldy, B);
+                               (long long)ldx, x_rows, y, (long long)ldy, B, softmax_times, argmax);
             return mz::check_launch("k_mlp_forward<2>");
         });
+}
+
+int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,
+                   const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream) {
+    if (!y) return mz::fail(MZ_ERR_ARG, "mz_mlp_forward: NULL output");
+    return mz_mlp_forward_post(h_plan, blob, x, ldx, x_rows, y, ldy, B, 0, nullptr, stream);
 }
 
 // ---- one layer of any width (read by the chunked kernels of mz_tower.hip)

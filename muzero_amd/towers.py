@@ -426,7 +426,13 @@ class TowerNetworks:
             self._tower_call(self.tower_f, latent, ld or D, rows, None, None, t, D, None, B, 1)
             head = lambda hd, name: self._head(hd, name, t, D, None, B)  # noqa: E731
             p_plan, v_plan = self.policy_head, self.value_head
-        if policy is not None or argmax is not None:
+        if (policy is not None or argmax is not None) and self.bottleneck_f and (policy is None or (
+                policy.dtype == torch.float32 and policy.is_contiguous() and policy.numel() == B * self.A)):
+            # the whole head, the extra softmax passes and the argmax in one launch
+            _hip.check(_hip.lib().mz_mlp_forward_post(C.byref(p_plan), ptr(self.blob), ptr(t), dt, None, ptr(policy),
+                                                      self.A, B, softmax_times, ptr(argmax), _stream()),
+                       "mz_mlp_forward_post")
+        elif policy is not None or argmax is not None:
             p = head(p_plan, "policy")
             _hip.check(_hip.lib().mz_policy_post(ptr(p), B, self.A, softmax_times, ptr(policy), ptr(argmax), _stream()),
                        "mz_policy_post")

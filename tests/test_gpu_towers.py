@@ -523,3 +523,43 @@ def test_graph_replay_equals_launch_by_launch():
         for name in ("visit", "value_sum", "prior", "reward", "first_child", "latent"):
             assert torch.equal(getattr(eager.pool, name), getattr(graphed.pool, name)), (round_, name)
         assert torch.equal(a.policy, b.policy) and torch.equal(a.value, b.value) and torch.equal(a.visits, b.visits)
+
+
+@pytest.mark.parametrize("B", [5, 256, 1000])
+def test_policy_head_with_post_processing_in_one_launch(B):
+    """mz_mlp_forward_post = mz_mlp_forward followed by mz_policy_post, bit for bit: extra softmax
+    passes 0..2, the first-maximum argmax, output only / argmax only."""
+    import ctypes as C
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    from muzero_amd.towers import TowerNetworks
+    g, f, A, shape = load_tower_nets(0)
+    nets = TowerNetworks(g, f)
+    assert nets.bottleneck_f
+    dt = nets.bottleneck_f
+    lib = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device="cuda").manual_seed(B)
+    t = torch.randn(B, dt, device="cuda", generator=gen)
+    t[1] = t[0]  # equal rows: equal outputs
+    raw = torch.empty(B, A, device="cuda")
+    _hip.check(lib.mz_mlp_forward(C.byref(nets.policy_t), ptr(nets.blob), ptr(t), dt, None, ptr(raw), A, B, st), "fwd")
+    for times in (0, 1, 2):
+        want = torch.empty(B, A, device="cuda")
+        want_arg = torch.empty(B, dtype=torch.int32, device="cuda")
+        _hip.check(lib.mz_policy_post(ptr(raw), B, A, times, ptr(want), ptr(want_arg), st), "post")
+        got = torch.full((B, A), -1.0, device="cuda")
+        got_arg = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        _hip.check(lib.mz_mlp_forward_post(C.byref(nets.policy_t), ptr(nets.blob), ptr(t), dt, None, ptr(got), A, B,
+                                           times, ptr(got_arg), st), "fwd_post")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got_arg, want_arg)
+        only_arg = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        _hip.check(lib.mz_mlp_forward_post(C.byref(nets.policy_t), ptr(nets.blob), ptr(t), dt, None, None, A, B, times,
+                                           ptr(only_arg), st), "argmax only")
+        only_out = torch.full((B, A), -1.0, device="cuda")
+        _hip.check(lib.mz_mlp_forward_post(C.byref(nets.policy_t), ptr(nets.blob), ptr(t), dt, None, ptr(only_out), A, B,
+                                           times, None, st), "output only")
+        torch.cuda.synchronize()
+        assert torch.equal(only_arg, want_arg) and torch.equal(only_out, want)
+    assert lib.mz_mlp_forward_post(C.byref(nets.policy_t), ptr(nets.blob), ptr(t), dt, None, None, A, B, 0, None, st) != 0
