@@ -193,15 +193,68 @@ def cpu_baseline_all_cores(budget_s=10.0):
             "sample": f"{ok} processes x {budget_s:.0f}s of single-game MCTS.run calls, 1 torch thread each"}
 
 
+PMC_TRAFFIC_FILES = ("r2_search_pmc_traffic.json", "r1_f_pmc_traffic.json")  # newest first
+
+
 def pmc_traffic(G, S):
-    """HBM bytes per launch of the search kernel from the committed counter passes (FETCH_SIZE and
-    WRITE_SIZE need separate profiler runs, so they cannot be collected inside this process);
-    None when the workload differs from the profiled one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_f_pmc_traffic.json")
-    if not os.path.exists(path) or (G, S) != (4096, 50):
-        return None
-    with open(path) as fh:
-        return json.load(fh)["hbm_bytes_per_launch"]
+    """(HBM bytes per launch of the search kernel, file) from the newest committed counter passes
+    (FETCH_SIZE and WRITE_SIZE need separate profiler runs, so they cannot be collected inside
+    this process); (None, None) when the workload differs from the profiled one."""
+    if (G, S) != (4096, 50):
+        return None, None
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh)["hbm_bytes_per_launch"], "profiles/" + name
+    return None, None
+
+
+def tower_search(G, S, dev, steps, with_roofline):
+    """The lock-step search with the residual-tower g / f of the shipped YAMLs (latent
+    [256, 6, 6], 5 actions; the networks of the CarRacing configuration): whole searches per
+    second in the form self-play uses (bottleneck values per node, recorded launch graph), and
+    the tower kernel's rollout-step call against the HBM roofline."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets, pmc_tower_traffic
+    shape, A = (256, 6, 6), 5
+    D = shape[0] * shape[1] * shape[2]
+    g, f = build_nets(shape, A)
+    nets = TowerNetworks(g, f, device=dev)
+    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev, keep_latents=False)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    lat = torch.randn(G, D, device=dev, generator=gen)
+    eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((G,)).float().to(dev)
+    rand = torch.randint(0, A, (G, S + 1), device=dev, generator=gen, dtype=torch.int32)
+    to_play = torch.zeros(G, dtype=torch.int8, device=dev)
+    for _ in range(3):  # launch by launch, then the recording, then a replay
+        res = mcts.run(lat, to_play, eta, rand)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = mcts.run(lat, to_play, eta, rand)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    assert int(res.visits.sum().item()) == G * S and mcts.replays >= steps
+    out = {"workload": f"{G} trees x {S} sims, residual-tower g/f, latent {list(shape)}, {A} actions, lock-step search",
+           "sims_per_sec": G * S / dt, "ms_per_search": dt * 1e3, "steps": steps}
+    if with_roofline and nets.tower_f_t is not None:
+        dt_ = nets.bottleneck_g
+        base = torch.randn(G, D, device=dev)
+        t_out = torch.empty(G, dt_, device=dev)
+        sel = torch.zeros(G, dtype=torch.int32, device=dev)
+        s = time_kernel(lambda: nets._tower_call(nets.tower_g, base, D, None, nets.table_t, sel, None, 0, None, G, 1,
+                                                 t_out=t_out), iters=20)
+        nbytes = 4.0 * G * (D + dt_)  # fc_merge's latent half read once + the block output written, per call
+        out["roofline_tower"] = {"bound": "hbm", "kernel": "k_tower / k_tower_packed [g rollout step, search form]",
+                                 "achieved": nbytes / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": nbytes / s / 1e9 / HBM_PEAK_GBS, "avg_launch_us": s * 1e6,
+                                 "bytes_per_launch": nbytes, "traffic": pmc_tower_traffic(G),
+                                 "traffic_source": "committed profile (profiles/r1_i_tower_pmc_traffic.json)"}
+    del mcts, nets
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -214,6 +267,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selfplay-moves", type=int, default=8, help="timed self-play moves per game (0 = skip)")
+    ap.add_argument("--min-seconds", type=float, default=1.5,
+                    help="after the K timed steps, keep stepping for this long (a sustained-rate figure)")
+    ap.add_argument("--tower-games", type=int, nargs="*", default=[256, 4096],
+                    help="also time the residual-tower search at these tree counts (empty = skip)")
     ap.add_argument("--cpu-worker", nargs=2, metavar=("SEED", "SECONDS"), help="internal: one CPU-baseline process")
     args = ap.parse_args()
     if args.cpu_worker:  # a child of cpu_baseline_all_cores: CPU only, prints one JSON line
@@ -271,6 +328,19 @@ def main():
                    "games_per_gpu": G, "sims_per_move": S, "parallelism": f"games sharded x{world}, no collective"},
         "searches_per_sec": world * G * args.steps / dt,
     }
+    if dist is not None:
+        # every rank reports in: an N > 1 record shows that RCCL really connected N ranks
+        seen = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(seen)
+        line["rccl_ranks"] = int(seen.item())
+        line["dist_backend"] = backend
+    if args.min_seconds > 0:
+        # the K timed steps above are tens of milliseconds; a sustained region of the same step lets a
+        # sampling monitor see the GPU busy and shows the rate holds under a warm chip
+        n_sus = max(args.steps, int(args.min_seconds / max(dt / args.steps, 1e-6)) + 1)
+        dts = sharding.timed_steps(step, n_sus, dist, device=dev)
+        line["sustained"] = {"steps": n_sus, "seconds": dts, "value": sharding.whole_job_rate(G * S, n_sus, world, dts),
+                             "ms_per_step": dts / n_sus * 1e3}
     if args.selfplay_moves > 0:
         # whole self-play moves: observe -> history -> h -> MCTS.run -> action pick -> env step ->
         # restart of finished games, for G games per GPU; the per-move Dirichlet, child-choice and
@@ -297,17 +367,36 @@ def main():
         alg = G * S * reference_flop_per_sim(nets.plan, mcts.depth)
         tf_alg = alg / ks[dom]["s"] / 1e12
         tf_exe = ks[dom]["flop"] / ks[dom]["s"] / 1e12
-        line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf_alg, "peak": FP32_MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": tf_alg / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(G, S),
+        traffic, traffic_file = pmc_traffic(G, S)
+        # `achieved` / `frac`: what the MFMA pipe EXECUTES (the utilisation figure); the reference
+        # formulation's flops over the same duration are kept beside it as `algorithmic_*`
+        line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf_exe, "peak": FP32_MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": tf_exe / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                            "traffic_source": f"committed profile ({traffic_file}), not measured in this run",
                             "avg_launch_us": ks[dom]["s"] * 1e6, "algorithmic_flop_per_launch": alg,
                             "executed_flop_per_launch": ks[dom]["flop"], "executed_tflops": tf_exe,
                             "executed_frac": tf_exe / FP32_MFMA_PEAK_TFLOPS,
+                            "algorithmic_tflops": tf_alg, "algorithmic_frac": tf_alg / FP32_MFMA_PEAK_TFLOPS,
                             "algorithmic_hbm_GBps": G * S * (TREE_BYTES_PER_SIM + LATENT_BYTES_PER_SIM) / ks[dom]["s"] / 1e9,
                             "hbm_peak_GBps": 8000.0}
         line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
+    if rank == 0 and args.tower_games:
+        del mcts
+        torch.cuda.empty_cache()
+        line["towers"] = {}
+        for tg in args.tower_games:
+            r = tower_search(tg, S, dev, steps=5 if tg <= 1024 else 3, with_roofline=not args.no_roofline)
+            line["towers"][str(tg)] = r
+        first = line["towers"][str(args.tower_games[0])]
+        line["towers"].update(sims_per_sec=first["sims_per_sec"], ms_per_search=first["ms_per_search"],
+                              roofline_tower=first.get("roofline_tower"))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(g, f)
         line["cpu_baseline"]["all_cores"] = multi
+        line["cpu_baseline"]["note"] = ("the per-node CPU port (oracle/pyref.py: the reference's Python/torch call structure, "
+                                        "pinned bit for bit by the reference's trees), not the reference itself, which "
+                                        "cannot run on the GPU box; in the build container the imported reference ran "
+                                        "866 sims/s on one core on this configuration, the port about 4x that")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

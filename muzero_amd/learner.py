@@ -154,6 +154,12 @@ class DataParallelLearner:
         if self.world > 1:
             self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
         norm = flat[-2]
+        if float(norm) <= 0.0:
+            # no usable window on any rank (every draw was an episode too short for a window): the
+            # reference skips the optimizer step then (`if ep_indices_used:`, src/training.py:174);
+            # dividing by the zero weight total would write NaN into every weight
+            self.optimizer.zero_grad(set_to_none=False)
+            return 0.0, per_window.detach().abs().cpu()
         off = 0
         for p in self.params:
             n = p.numel()
@@ -175,7 +181,14 @@ class DataParallelLearner:
         rate that changes must be a tensor).  The first call records (after one trial step whose
         effect on the weights and the optimizer state is undone).  Returns DEVICE tensors
         (normalised loss over all ranks, per-window |loss| of the local windows): nothing here
-        waits for the GPU."""
+        waits for the GPU.
+
+        A batch whose weight total is zero on every rank (only zero-weight windows) cannot skip the
+        recorded optimizer step; its gradient is forced to exactly zero instead of 0/0, and the
+        weights are put back to their values from before the step, so momentum-free and
+        momentum-carrying optimizers alike leave the weights unchanged (the optimizer's own step
+        counter still advances).  DeviceEpisodeStore.sample_prioritized never produces such a
+        batch unless no stored episode is long enough, which it reports as an error."""
         dev = self.params[0].device
         fields = ("history", "actions", "policies", "z", "rewards", "is_weights")
         shapes = tuple(tuple(getattr(local, f).shape) for f in fields)
@@ -202,13 +215,21 @@ class DataParallelLearner:
     def _update_from_flat(self):
         flat = self._rec_flat
         norm = flat[-2]
+        ok = norm > 0
+        scale = torch.where(ok, 1.0 / torch.where(ok, norm, torch.ones_like(norm)), torch.zeros_like(norm))
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad.copy_((flat[off:off + n] / norm).view_as(p))
+            p.grad.copy_((flat[off:off + n] * scale).view_as(p))
             off += n
+        torch._foreach_copy_(self._rec_before, [p.data for p in self.params])
         self.optimizer.step()
-        self._rec_loss.copy_(flat[-1] / norm)
+        # weight total zero: the step above ran on a zero gradient; undo whatever it still moved
+        # (momentum, weight decay) -- the reference takes no step at all for such a batch
+        with torch.no_grad():
+            for p, b in zip(self.params, self._rec_before):
+                p.copy_(torch.where(ok, p, b))
+        self._rec_loss.copy_(flat[-1] * scale)
 
     def _record(self, local: WindowBatch, shapes):
         import copy
@@ -219,6 +240,7 @@ class DataParallelLearner:
         self._rec_flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
         self._rec_per_window = torch.zeros(len(local), dtype=torch.float32, device=dev)
         self._rec_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self._rec_before = [torch.empty_like(p.data) for p in self.params]
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)

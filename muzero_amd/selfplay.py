@@ -48,32 +48,57 @@ class DeviceHistory:
 class RepresentationRunner:
     """h on the GPU.  MLP-style configs (`downsample: [], res_net: []`, latent H, W equal to the
     observation's) are one 1x1 convolution and run the HIP kernel; every other configuration
-    runs the torch module on the GPU (its convolutions are not part of this path yet), with the
-    per-game batch statistics of the reference's one-game-at-a-time calls."""
+    runs a private device copy of the torch module (its convolutions are not part of this path
+    yet), with the per-game batch statistics of the reference's one-game-at-a-time calls.
+
+    The caller's module is never moved or modified: the runner keeps its own device copy of the
+    weights and re-reads them whenever a parameter or buffer of the module has changed
+    (in-place updates bump a tensor's version counter; a replaced tensor has a new address), so
+    a generator that is reused after training searches with the trained weights."""
 
     def __init__(self, repr_net: torch.nn.Module, device="cuda"):
-        self.net = repr_net
+        self.src = repr_net
         self.device = torch.device(device)
         self.pointwise = (len(repr_net.downsample_layers) == 0 and len(repr_net.res_blocks) == 0
                           and isinstance(repr_net.final_conv, torch.nn.Conv2d))
+        self.latent_hw = (repr_net.latent_height, repr_net.latent_width)
+        self._seen = None
+        self.net = None
+        self.refresh()
+
+    def _versions(self):
+        return tuple((t._version, t.data_ptr()) for t in list(self.src.parameters()) + list(self.src.buffers()))
+
+    def refresh(self, force: bool = False) -> None:
+        """Re-reads the module's weights if they changed since the last call (always with `force`)."""
+        seen = self._versions()
+        if not force and seen == self._seen:
+            return
         if self.pointwise:
-            conv = repr_net.final_conv
-            self.weight = conv.weight.detach().to(self.device, torch.float32).reshape(conv.out_channels, -1).contiguous()
-            self.bias = conv.bias.detach().to(self.device, torch.float32).contiguous() if conv.bias is not None else None
+            conv = self.src.final_conv
+            self.weight = conv.weight.detach().to(self.device, torch.float32).reshape(conv.out_channels, -1).contiguous().clone()
+            self.bias = conv.bias.detach().to(self.device, torch.float32).contiguous().clone() if conv.bias is not None else None
+            self.net = None  # the pooled fallback below copies the module again when it is next needed
         else:
-            self.net = repr_net.to(self.device)
+            import copy
+            self.net = copy.deepcopy(self.src).to(self.device)
+        self._seen = seen
 
     def __call__(self, history: torch.Tensor) -> torch.Tensor:
+        self.refresh()
         G, cin, H, W = history.shape
-        if self.pointwise and (H, W) == (self.net.latent_height, self.net.latent_width):
+        if self.pointwise and (H, W) == self.latent_hw:
             x = history.to(self.device, torch.float32).contiguous()
             cout = self.weight.shape[0]
             out = torch.empty((G, cout, H, W), dtype=torch.float32, device=self.device)
             _hip.check(_hip.lib().mz_repr_pointwise(ptr(x), ptr(self.weight), ptr(self.bias), G, cin, cout, H * W,
                                                     ptr(out), _stream()), "mz_repr_pointwise")
             return out
+        if self.net is None:  # a point-wise module asked for another latent size: the torch module handles the pooling
+            import copy
+            self.net = copy.deepcopy(self.src).to(self.device)
         with torch.no_grad(), per_call_statistics(self.net):
-            return self.net.to(self.device)(history.to(self.device))
+            return self.net(history.to(self.device))
 
 
 def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_action: torch.Tensor | None,

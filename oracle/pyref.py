@@ -188,7 +188,7 @@ def run_mcts(root_latent, to_play, ev, num_actions, num_sims, *, discount, noise
         rewards = ev.rollout(child.latent)
         g = backup(child, rewards, leaf.to_play, discount)
         if trace is not None:
-            trace.append((leaf.index, child.index, g))
+            trace.append((leaf.index, child.index, g, list(rewards)))
     utility = root.value_sum / root.visit
     ex = [math.exp(c.value_sum) for c in root.children]
     tot = sum(ex)

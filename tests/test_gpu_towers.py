@@ -310,7 +310,7 @@ def test_selfplay_with_host_environments_conv_h_and_towers():
     assert torch.equal(obs.cpu(), first_obs)
     hist = torch.cat([first_obs.repeat(1, K, 1, 1), torch.zeros(G, K, 8, 8)], dim=1)  # K copies + zero action planes
     with torch.no_grad():
-        lat = torch.cat([h.cpu()(hist[i:i + 1]) for i in range(G)]).reshape(G, -1)   # one game per call
+        lat = torch.cat([h(hist[i:i + 1]) for i in range(G)]).reshape(G, -1)   # one game per call
     mcts = BatchedMCTS(eng.nets, G, S, 1, discount=0.998, noise_frac=0.25)
     res = mcts.run(lat.cuda(), torch.zeros(G, dtype=torch.int8, device="cuda"), torch.from_numpy(eta).cuda(),
                    torch.from_numpy(rand).cuda())
@@ -563,3 +563,108 @@ def test_policy_head_with_post_processing_in_one_launch(B):
         torch.cuda.synchronize()
         assert torch.equal(only_arg, want_arg) and torch.equal(only_out, want)
     assert lib.mz_mlp_forward_post(C.byref(nets.policy_t), ptr(nets.blob), ptr(t), dt, None, None, A, B, 0, None, st) != 0
+
+
+def test_tower_search_at_benchmarked_size():
+    """The configuration the tower numbers are quoted on -- latent [256, 6, 6], 5 actions, 50
+    simulations, 256 trees, bottleneck-form lock-step search -- with and without stored latents,
+    launch by launch and replayed from the recorded HIP graph:
+      (i)  the search's own network outputs replayed through the CPU tree oracle give every tree bit
+           for bit, and the graph replay leaves the same pool as the traced launch-by-launch run;
+      (ii) the prior / reward / rollout streams of 8 trees equal the torch modules called one
+           reference call at a time (src/search/expansion.py:25-33, src/search/simulation.py:31-44)
+           on the search's own latents, to 1e-5 of each output's scale."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    shape, A, G, S, depth = (256, 6, 6), 5, 256, 50, 1
+    D = 9216
+    g, f = build_nets(shape, A)
+    with torch.no_grad():
+        for m in list(g.modules()) + list(f.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    nets = TowerNetworks(g, f)
+    rng = np.random.default_rng(17)
+    lat = rng.standard_normal((G, D)).astype(np.float32)
+    eta = rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)
+    rand = rng.integers(0, A, size=(G, S + 1)).astype(np.int32)
+    to_play = np.zeros(G, np.int8)   # single-player simulators (CarRacing): to_play 0
+    dev = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
+    pools = {}
+    for keep in (True, False):
+        mcts = BatchedMCTS(nets, G, S, depth, discount=0.998, noise_frac=0.25, keep_latents=keep)
+        assert mcts.t_pool is not None and mcts.keep_latents == keep, "the bottleneck form is not in use"
+        trace = {}
+        res = mcts.run(*dev, trace=trace)          # launch by launch (tracing)
+        torch.cuda.synchronize()
+        pool = mcts.pool
+        prior_s = np.stack([p.cpu().numpy() for p in trace["prior"]], axis=1)
+        rollout = np.stack([r.cpu().numpy() for r in trace["rollout"]], axis=1)
+        leaf = np.stack([x.cpu().numpy() for x in trace["leaf"]], axis=1)
+        child = np.stack([x.cpu().numpy() for x in trace["child"]], axis=1)
+        reward_nodes = pool.reward.cpu().numpy()
+        root_prior = torch.empty(G, A, device="cuda")
+        nets.prediction(dev[0], G, softmax_times=1, policy=root_prior)
+        prior_stream = np.concatenate([root_prior.cpu().numpy()[:, None], prior_s], axis=1)
+        reward_stream = np.stack([reward_nodes[:, 1 + e * A:1 + (e + 1) * A] for e in range(S + 1)], axis=1)
+        ref = otree.run_batch(A, S, depth, to_play, prior_stream, reward_stream, rand, rollout, eta, 0.25, 0.998)
+        assert np.array_equal(leaf, ref["leaf"]) and np.array_equal(child, ref["child"])
+        for name in ("visit", "value_sum", "prior", "first_child", "parent"):
+            assert np.array_equal(getattr(pool, name).cpu().numpy(), ref[name]), name
+        assert np.array_equal(res.value.cpu().numpy(), ref["utility"])
+        np.testing.assert_allclose(res.policy.cpu().numpy(), ref["policy"], rtol=1e-12)
+        stats = {n: getattr(pool, n).clone() for n in ("visit", "value_sum", "prior", "reward", "parent", "first_child")}
+        # the same search twice more without tracing: the first records the graph, both replay it
+        for _ in range(2):
+            res2 = mcts.run(*dev)
+            torch.cuda.synchronize()
+            for n, want in stats.items():
+                assert torch.equal(getattr(pool, n), want), f"graph replay: {n}"
+            assert torch.equal(res2.policy32, res.policy32) and torch.equal(res2.value, res.value)
+        assert mcts.replays == 2, "the recorded graph was not used"
+        pools[keep] = dict(prior=prior_stream, reward=reward_stream, rollout=rollout, leaf=leaf, child=child,
+                           latent=pool.latent if keep else None, t_pool=mcts.t_pool.clone())
+        if keep:
+            keep_mcts = mcts   # keeps pool.latent alive for (ii)
+    # storing the latents or not changes nothing the search computes
+    for n in ("prior", "reward", "rollout", "leaf", "child"):
+        assert np.array_equal(pools[True][n], pools[False][n]), n
+    assert torch.equal(pools[True]["t_pool"], pools[False]["t_pool"])
+
+    # ---- (ii) the torch modules, one reference call at a time, on the GPU (rocBLAS / MIOpen fp32)
+    gt, ft = g.cuda(), f.cuda()
+    P = pools[True]
+    latent = keep_mcts.pool.latent   # [G, cap, D]
+    acts = torch.arange(A, device="cuda")
+
+    def close(got, want, what):
+        want = want.detach().cpu().numpy()
+        # 1e-5 relative; absolute floor: 1e-5 of the output's scale, and never below the 2e-6 the
+        # reference-vector comparisons of this file use for head outputs of a few hundredths
+        np.testing.assert_allclose(np.asarray(got).reshape(want.shape), want, rtol=1e-5,
+                                   atol=max(1e-5 * float(np.abs(want).max()), TOL["atol"]), err_msg=what)
+
+    near_ties = 0
+    with torch.no_grad():
+        for gi in range(0, G, G // 8):
+            for s in list(range(0, S, 7)) + [S - 1]:
+                lf, ch = int(P["leaf"][gi, s]), int(P["child"][gi, s])
+                x = latent[gi, lf].reshape(1, *shape)
+                close(P["prior"][gi, s + 1], torch.softmax(ft(x)[0], dim=1)[0], f"prior tree {gi} sim {s}")
+                nxt, rew = gt(x.repeat(A, 1, 1, 1), acts)   # ONE call: batch statistics over the A children
+                base = 1 + (s + 1) * A
+                close(P["reward"][gi, s + 1], rew[:, 0], f"reward tree {gi} sim {s}")
+                close(latent[gi, base:base + A].cpu().numpy(), nxt.reshape(A, D), f"child latents tree {gi} sim {s}")
+                cur = latent[gi, ch].reshape(1, *shape)
+                pol = ft(cur)[0][0]
+                top2 = pol.topk(2).values
+                if float(top2[0] - top2[1]) <= 1e-5 * float(top2[0]):
+                    near_ties += 1     # the greedy action is decided by rounding: nothing to compare
+                    continue
+                cur, r = gt(cur, pol.argmax().reshape(1))
+                v = ft(cur)[1]
+                close(P["rollout"][gi, s], torch.stack([r[0, 0], v[0, 0]]), f"rollout tree {gi} sim {s}")
+    assert near_ties <= 2
+    g.cpu(), f.cpu()

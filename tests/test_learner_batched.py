@@ -194,3 +194,25 @@ def test_batched_unroll_with_residual_towers_equals_per_window_loop():
     for p, wg in zip(params, want_grads):
         torch.testing.assert_close(p.grad, wg, rtol=2e-3, atol=2e-5)
     assert all("forward" not in m.__dict__ for n in (h, g, f) for m in n.modules())
+
+
+def test_zero_weight_batch_leaves_weights_unchanged_and_finite():
+    """A draw made only of episodes too short for a window arrives as zero-weight windows
+    (DeviceEpisodeStore.sample_prioritized keeps the batch shape): the weight total is 0 and the
+    reference skips the optimizer step (`if ep_indices_used:`, src/training.py:174)."""
+    from muzero_amd.learner import DataParallelLearner, windows_to_batch
+    cfg, h, g, f = _nets()
+    params = [p for n in (h, g, f) for p in n.parameters()]
+    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-2)
+    dp = DataParallelLearner(h, g, f, opt, W)
+    wins, R, V, isw = _windows(21, n=4)
+    good = windows_to_batch(wins, _z_targets(R, V), R, isw, h.history_length, LOOKBACK, W)
+    dp.step_local(good)  # momentum buffers exist and are non-zero now
+    before = [p.detach().clone() for p in params]
+    dropped = windows_to_batch(wins, _z_targets(R, V), R, np.zeros(4), h.history_length, LOOKBACK, W)
+    loss, errs = dp.step_local(dropped)
+    assert loss == 0.0 and np.isfinite(errs.numpy()).all()
+    for p, b in zip(params, before):
+        assert torch.isfinite(p).all() and torch.equal(p.detach(), b)
+    loss2, _ = dp.step_local(good)  # and training goes on
+    assert np.isfinite(loss2) and all(torch.isfinite(p).all() for p in params)
