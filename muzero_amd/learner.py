@@ -216,11 +216,11 @@ class DataParallelLearner:
         flat = self._rec_flat
         norm = flat[-2]
         ok = norm > 0
-        scale = torch.where(ok, 1.0 / torch.where(ok, norm, torch.ones_like(norm)), torch.zeros_like(norm))
+        safe, live = torch.where(ok, norm, torch.ones_like(norm)), ok.to(flat.dtype)  # x / safe * live: exact when ok
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad.copy_((flat[off:off + n] * scale).view_as(p))
+            p.grad.copy_((flat[off:off + n] / safe * live).view_as(p))
             off += n
         torch._foreach_copy_(self._rec_before, [p.data for p in self.params])
         self.optimizer.step()
@@ -229,7 +229,7 @@ class DataParallelLearner:
         with torch.no_grad():
             for p, b in zip(self.params, self._rec_before):
                 p.copy_(torch.where(ok, p, b))
-        self._rec_loss.copy_(flat[-1] * scale)
+        self._rec_loss.copy_(flat[-1] / safe * live)
 
     def _record(self, local: WindowBatch, shapes):
         import copy

@@ -61,3 +61,15 @@ def test_recorded_step_equals_eager_step(opt_name):
     for p, q in zip(pa, pb):
         torch.testing.assert_close(p, q, rtol=1e-6, atol=1e-8)
     assert not torch.equal(pb[0], before[0])
+    # a batch of zero-weight windows only (every draw was an episode too short for a window): the
+    # recorded step leaves finite, unchanged weights, as the eager step (which skips the update) does
+    from muzero_amd.learner import WindowBatch
+    dead = batches[0]
+    dead = WindowBatch(dead.history, dead.actions, dead.policies, dead.z, dead.rewards, torch.zeros_like(dead.is_weights))
+    kept = [p.detach().clone() for p in pb]
+    loss_r, _ = rec.step_local_recorded(dead)
+    loss_e, _ = eager.step_local(dead)
+    torch.cuda.synchronize()
+    assert float(loss_r) == 0.0 and loss_e == 0.0
+    for p, q in zip(pb, kept):
+        assert torch.isfinite(p).all() and torch.equal(p, q)
