@@ -347,6 +347,18 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
                     const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
                     int64_t workspace_floats, void *stream);
 
+/* mz_wide_forward for callers that cannot allocate or pass device memory of their own (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
+ * the reference.  The partial sums of the split reduction go to an array built into the library
+ * (mz_wide_static_workspace_floats() floats = 16 MiB, one copy per GPU, held until the process ends)
+ * instead of a caller-provided workspace; the call allocates nothing.  A call whose
+ * mz_wide_workspace() exceeds that size fails with MZ_ERR_ARG.  The device the stream belongs to
+ * must be the current device.  All calls on one GPU share the array: calls that overlap in time on
+ * the same GPU (different streams or threads) race; calls on one stream are ordered and safe. */
+int64_t mz_wide_static_workspace_floats(void);
+int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                           const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream);
+
 /* ResBlock (src/neural_networks/network_builder.py:73-151) with stride 1, padding
  * (kernel_size-1)/2 and no pooling -- the only form that keeps the latent's H x W, which g and f
  * require.  Weights are device pointers in torch layout: conv [out][in][k][k] without bias,

@@ -135,6 +135,8 @@ _SIGS = {
     "mz_wide_workspace": (C.c_int64, [C.POINTER(PackedLayer), C.c_int32]),
     "mz_wide_forward": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P,
                                   C.c_int64, _P]),
+    "mz_wide_static_workspace_floats": (C.c_int64, []),
+    "mz_wide_forward_static": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
                                    _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),

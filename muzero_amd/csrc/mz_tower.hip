@@ -12,6 +12,7 @@
 // 4 x 4 x 1 matrix instruction (16 independent 4-position x 4-channel blocks per wave), where a
 // 16-wide tile would idle on most of its columns.
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 
@@ -21,6 +22,18 @@
 using namespace mzd;
 
 namespace {
+
+// Partial sums of mz_wide_forward_static's split reduction: a fixed device array instead of a
+// caller-provided workspace, for callers that cannot allocate.  One copy per GPU, held until the
+// process ends; its contents are whatever the last call on that GPU left (every call writes each
+// partial sum before k_wide_finish reads it, so nothing needs clearing).  Host code reaches it only
+// through the per-device address hipGetSymbolAddress returns -- the array's name is not a device
+// pointer on the host.
+constexpr long long kWideScratchFloats = 4ll << 20;  // 16 MiB
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) float g_wide_scratch[kWideScratchFloats];
+static float *g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
 
 constexpr int kWT = 256;       // threads per workgroup (the tower kernel has its own count)
 constexpr int kKC = 64;        // floats of the reduction dimension per LDS chunk (4 k-tiles)
@@ -1148,16 +1161,17 @@ extern "C" {
 
 int64_t mz_wide_workspace(const mz_packed_layer *h_plan, int32_t B) {
     if (!h_plan || B < 0) return mz::fail(MZ_ERR_ARG, "mz_wide_workspace: NULL plan or negative B");
+    if (h_plan->Kp <= 0 || h_plan->Np <= 0) return mz::fail(MZ_ERR_ARG, "mz_wide_workspace: the plan is empty (mz_wide_plan failed?)");
     if (B == 0) return 0;
     const WideShape s = wide_shape(*h_plan, B);
     return s.splitk > 1 ? (int64_t)s.splitk * B * h_plan->Np : 0;
 }
 
-int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
-                    const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
-                    int64_t workspace_floats, void *stream) {
-    if (!h_plan || !blob || !x || !y || B < 0 || ldx < h_plan->K || ldy < h_plan->N)
-        return mz::fail(MZ_ERR_ARG, "mz_wide_forward: NULL argument, negative B or row stride below the row width");
+static int wide_forward_impl(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                             const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
+                             int64_t workspace_floats, void *stream) {
+    if (!h_plan || !blob || !x || !y || B < 0 || ldx < h_plan->K || ldy < h_plan->N || h_plan->Kp <= 0 || h_plan->Np <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_forward: NULL argument, empty plan, negative B or row stride below the row width");
     if (h_plan->act < MZ_ACT_NONE || h_plan->act > MZ_ACT_SIGMOID)
         return mz::fail(MZ_ERR_ARG, "mz_wide_forward: activation %d is not element-wise", h_plan->act);
     if (B == 0) return MZ_OK;
@@ -1188,6 +1202,47 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
         MZ_TRY(mz::check_launch("k_wide_finish"));
     }
     return MZ_OK;
+}
+
+int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                    const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
+                    int64_t workspace_floats, void *stream) {
+    return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, workspace, workspace_floats, stream);
+}
+
+int64_t mz_wide_static_workspace_floats(void) { return kWideScratchFloats; }
+
+int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                           const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream) {
+    if (!h_plan || B < 0 || h_plan->Kp <= 0 || h_plan->Np <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_forward_static: NULL or empty plan, or negative B");
+    int64_t need = 0;
+    if (B > 0) {
+        const WideShape s = wide_shape(*h_plan, B);
+        need = s.splitk > 1 ? (int64_t)s.splitk * B * h_plan->Np : 0;
+    }
+    if (need > kWideScratchFloats)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_forward_static: this call needs %lld floats of partial sums, the built-in "
+                        "scratch holds %lld (use mz_wide_forward with a caller-provided workspace)", (long long)need,
+                        (long long)kWideScratchFloats);
+    float *scratch = nullptr;
+    if (need > 0) {
+        // the array's device address, looked up once per device (each GPU holds its own copy)
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+            return mz::fail(MZ_ERR_HIP, "mz_wide_forward_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void *ptr = nullptr;
+            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_wide_scratch));
+            if (e != hipSuccess || !ptr)
+                return mz::fail(MZ_ERR_HIP, "mz_wide_forward_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            g_scratch_ptr[dev] = static_cast<float *>(ptr);
+        }
+        scratch = g_scratch_ptr[dev];
+    }
+    return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, scratch, need, stream);
 }
 
 int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
