@@ -102,7 +102,7 @@ struct Team {
     __device__ __forceinline__ int tid() const { return (int)threadIdx.x - 64 * wave0; }
     __device__ __forceinline__ int nthreads() const { return 64 * nwaves; }
     __device__ __forceinline__ void sync() {
-        if (nwaves == kWaves) {
+        if (ctr == nullptr) {  // the whole workgroup
             __syncthreads();
             return;
         }
@@ -589,11 +589,11 @@ __host__ __device__ inline int narrow_lds_floats(const mz_packed_layer &L) { ret
 __device__ __forceinline__ void stage_narrow(const float *__restrict__ packed, const mz_packed_layer &L, lds_f *dst) {
     const int quads = L.Kp >> 2;
     const f32x4 *wp = reinterpret_cast<const f32x4 *>(packed + L.w_off);
-    for (int i = threadIdx.x; i < quads * L.N; i += kThreads) {
+    for (int i = threadIdx.x; i < quads * L.N; i += blockDim.x) {
         const int q = i / L.N, col = i - q * L.N;
         *reinterpret_cast<lds_f4 *>(dst + i * 4) = wp[(size_t)(q >> 2) * 64 + (q & 3) * 16 + col];
     }
-    for (int i = threadIdx.x; i < 8; i += kThreads) dst[quads * L.N * 4 + i] = (i < L.N) ? packed[L.b_off + i] : 0.0f;
+    for (int i = threadIdx.x; i < 8; i += blockDim.x) dst[quads * L.N * 4 + i] = (i < L.N) ? packed[L.b_off + i] : 0.0f;
 }
 
 // One dense layer over the workgroup's row tile.  Xs: LDS [16*MT][ldx], columns [K, Kp)

@@ -20,80 +20,26 @@
 //
 // Compiled with -ffp-contract=off (every rounding is part of the contract).
 #include <algorithm>
+#include <cstdlib>
 
 #include "mz_common.h"
 #include "mz_mlp_device.h"
+#include "mz_search_lds.h"
 #include "mz_tree_device.h"
 
 using namespace mzd;
+using namespace mzs;
 
 namespace {
 
-constexpr int kTrees = 16;  // trees per workgroup = one MFMA row tile
-
-constexpr int kPathCap = 16;  // select records the first kPathCap levels of its path in LDS
-
-struct Lds {
-    int ld_d, ld_h, ld_r, rows_r, tab_rows;
-    int fold_reward;  // reward head = [wide, one-output]: folded over the children, no r1/r2/rout
-    // byte offsets.  x: leaf latents, later the simulation's current latent; z: merge
-    // pre-activation of the leaf; zs: merge pre-activation along the simulation; he1/he2: hidden
-    // activations of the expansion; hs1/hs2: of the simulation; r1/r2/rout: reward head over the
-    // children
-    size_t x, z, zs, tab, he1, he2, hs1, hs2, r1, r2, rout, dot, dots, dotv, nets, prior, rew, roll, ints, path, tabs, total;
-    int narrow[3][MZ_MAX_LAYERS];  // byte offset of a narrow layer's LDS weight copy (policy, value, reward), or -1
-};
-
-constexpr int kIntsPerTree = 6;  // s_leaf, s_child, s_act, s_leaf_tp, s_depth, s_root
-
-__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
-
-__host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int depth, int tab_len) {
-    Lds L;
-    const int A = P.A;
-    L.ld_d = lds_stride(P.D);
-    int wh = P.policy.max_width > P.value.max_width ? P.policy.max_width : P.value.max_width;
-    if (P.reward.max_width > wh) wh = P.reward.max_width;
-    L.ld_h = lds_stride(wh);
-    const bool first_reward_narrow = P.reward.layer[0].N <= 8;
-    L.ld_r = lds_stride((first_reward_narrow && P.D > P.reward.max_width) ? P.D : P.reward.max_width);
-    L.rows_r = kTrees * mtc;
-    L.tab_rows = ((A + mtc - 1) / mtc) * mtc;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
-    L.x = take(sizeof(float) * kTrees * L.ld_d);
-    L.z = take(sizeof(float) * kTrees * L.ld_d);
-    L.zs = take(sizeof(float) * kTrees * L.ld_d);
-    L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
-    const int ld_he = lds_stride(P.policy.max_width);
-    L.he1 = take(sizeof(float) * kTrees * ld_he);
-    L.he2 = take(P.policy.n_layers >= 2 ? sizeof(float) * kTrees * ld_he : 0);
-    L.hs1 = take(sizeof(float) * kTrees * L.ld_h);
-    L.hs2 = take(sizeof(float) * kTrees * L.ld_h);
-    L.fold_reward = (P.reward.n_layers == 2 && tail_foldable(P.reward)) ? 1 : 0;
-    L.r1 = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * L.ld_r);
-    L.r2 = take(!L.fold_reward && P.reward.n_layers >= 3 ? sizeof(float) * L.rows_r * L.ld_r : 0);
-    L.rout = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * lds_stride(1));
-    L.dot = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * L.rows_r : 0);
-    L.dots = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * kTrees : 0);
-    L.dotv = take(P.value.n_layers == 2 && tail_foldable(P.value) ? sizeof(float) * (P.value.layer[0].Np >> 4) * kTrees : 0);
-    L.nets = take(sizeof(mz_packed_nets) + sizeof(int) * 3 * MZ_MAX_LAYERS);  // plan + narrow-layer offsets
-    L.prior = take(sizeof(float) * kTrees * A);
-    L.rew = take(sizeof(float) * kTrees * L.tab_rows);
-    L.roll = take(sizeof(float) * kTrees * (depth + 1));
-    L.ints = take(sizeof(int) * (kTrees * kIntsPerTree + 4));
-    L.path = take(sizeof(int) * kTrees * kPathCap);
-    L.tabs = take(sizeof(double) * 2 * tab_len);
-    const mz_packed_mlp *mlps[3] = {&P.policy, &P.value, &P.reward};
-    for (int m = 0; m < 3; ++m)
-        for (int i = 0; i < MZ_MAX_LAYERS; ++i) {
-            L.narrow[m][i] = -1;
-            if (i < mlps[m]->n_layers && mlps[m]->layer[i].N <= 8)
-                L.narrow[m][i] = (int)take(sizeof(float) * narrow_lds_floats(mlps[m]->layer[i]));
-        }
-    L.total = off;
-    return L;
-}
+// Diagnostic build only (-DMZ_SEARCH_DIAG, never the shipped library): stages named by the bits of the
+// environment variable MZ_SEARCH_SKIP are left out, so that instruction counters and durations of two
+// runs can be subtracted.  Results are meaningless with any bit set.
+#ifdef MZ_SEARCH_DIAG
+#define MZ_SKIP(bit) ((q.lanes_per_tree >> (8 + (bit))) & 1)
+#else
+#define MZ_SKIP(bit) 0
+#endif
 
 // Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2.
 template <typename MLP>
@@ -194,7 +140,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * kTrees;
     const int trees = min(kTrees, p.G - g0);
-    const int lpt = q.lanes_per_tree;
+    const int lpt = q.lanes_per_tree & 0xff;
     const int ld_p1 = lds_stride(Pk.policy.layer[0].N);
     const int half = uni(tid >> 6) >= kWaves / 2 ? 1 : 0;
     int team_arrived = 0;  // arrivals this wave's team counter shows after the wave's latest team sync
@@ -220,8 +166,9 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
     // ---- the expansion after the leaf's first layers (He1, Z valid) ---------------------------
     auto expand_tail = [&](Team &tm, int e, int base) {
         const int ttid = tm.tid(), tn = tm.nthreads();
-        int ld_p;
-        lds_f *pol = mlp16(tm, P.policy, 1, blob, He1, ld_p1, He1, He2, &ld_p, smem_raw, s_narrow);
+        int ld_p = ld_p1;
+        lds_f *pol = He1;
+        if (!MZ_SKIP(6)) pol = mlp16(tm, P.policy, 1, blob, He1, ld_p1, He1, He2, &ld_p, smem_raw, s_narrow);
         MZ_STAMP(4)  // expand: remaining policy layers
         if (pol0_softmax_only) softmax_rows(pol, ld_p, kTrees, A, 1, tm);
         softmax_rows(pol, ld_p, kTrees, A, 1, tm);  // expand_node's extra softmax (expansion.py:27)
@@ -235,7 +182,8 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         // child latents -> pool (coalesced along the latent).  Written once, read back at most a
         // few times much later: streaming (non-temporal) stores keep them from displacing the
         // weights and tree statistics in L2
-        if ((D & 3) == 0) {
+        if (MZ_SKIP(7)) {
+        } else if ((D & 3) == 0) {
             // one (tree, action) row per wave and pass, lanes along the latent: the row index is
             // wave-uniform, so the index arithmetic stays on the scalar unit
             const int q4 = D >> 2;
@@ -274,7 +222,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         }
         MZ_STAMP(6)  // expand: child latents to the pool
         // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time
-        for (int a0 = 0; a0 < A; a0 += MTC) {
+        for (int a0 = 0; a0 < A && !MZ_SKIP(8); a0 += MTC) {
             if (L.fold_reward) {
                 // hidden layer over the children with the output layer folded into its epilogue
                 const mz_packed_layer L0 = load_layer(P.reward.layer[0]), L1 = load_layer(P.reward.layer[1]);
@@ -479,7 +427,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
 
         // ---- select (simulations only) + leaf latents --------------------------------------
         if (e > 0) {
-            if (tid < kTrees * lpt) {
+            if (!MZ_SKIP(0) && tid < kTrees * lpt) {
                 const int t = tid / lpt, a = tid % lpt;
                 int leaf = 0, dep = 0;
                 if (t < trees) {
@@ -514,7 +462,8 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                 s_child[t] = base + rc;
                 if (q.child_trace && t < trees) q.child_trace[(size_t)(g0 + t) * S + (e - 1)] = base + rc;
             }
-            if ((D & 3) == 0) {  // 16-byte rows: one tree per wave and pass, one float4 per lane
+            if (MZ_SKIP(5)) {
+            } else if ((D & 3) == 0) {  // 16-byte rows: one tree per wave and pass, one float4 per lane
                 const int q4 = ld_d >> 2, d4 = D >> 2;
                 const int wv = uni(tid >> 6), lane = tid & 63;
                 for (int t = wv; t < kTrees; t += kWaves) {
@@ -537,7 +486,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
 
         // ---- the leaf's policy layer 1 and merge layer share the input: whole workgroup --------
         Team all = whole_workgroup();
-        first_layers(all, LdsRows{X, ld_d}, X, He1, Z);
+        if (!MZ_SKIP(3)) first_layers(all, LdsRows{X, ld_d}, X, He1, Z);
         MZ_STAMP(3)  // expand: policy layer 1 | merge
 
         // the root expansion has no simulation: the whole workgroup expands
@@ -550,12 +499,12 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         }
         if (stamping && tid == kThreads / 2) t_prev = clock64();
         if (!sim || half == 0) {
-            expand_tail(tm, e, base);
+            if (!MZ_SKIP(1)) expand_tail(tm, e, base);
         } else {
             // the simulation is the longer chain: its waves issue first whenever both teams'
             // waves of a SIMD are ready
             __builtin_amdgcn_s_setprio(3);
-            simulate(tm, e, base);
+            if (!MZ_SKIP(2)) simulate(tm, e, base);
             __builtin_amdgcn_s_setprio(0);
         }
         if (sim) team_arrived = tm.arrived;
@@ -569,7 +518,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         // lanes (lane i of a tree: i = 0 the drawn child, i >= 1 the node i - 1 levels above the
         // leaf) instead of one lane chasing parent pointers.  Signs follow to_play, which
         // alternates with depth; a root to_play of 0 makes every node equal to the leaf's.
-        if (tid < kTrees * kPathCap) {
+        if (!MZ_SKIP(4) && tid < kTrees * kPathCap) {
             const int t = tid / kPathCap, i = tid % kPathCap;
             if (t < trees) {
                 const size_t o = (size_t)(g0 + t) * p.cap;
@@ -634,6 +583,9 @@ int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *
         return mz::fail(MZ_ERR_ARG, "mz_search_run: tab_len must be in [S+2, 4096]");
     mz_search_params q = *prm;
     q.lanes_per_tree = mz::lanes_per_tree(pool->A);
+#ifdef MZ_SEARCH_DIAG
+    if (const char *e = getenv("MZ_SEARCH_SKIP")) q.lanes_per_tree |= atoi(e) << 8;
+#endif
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (pool->G + kTrees - 1) / kTrees;
     const int candidates[4] = {7, 4, 2, 1};
