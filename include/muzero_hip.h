@@ -293,6 +293,68 @@ int mz_z_targets(const double *R, const double *V, const double *pow_tab, int32_
                  double *z, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Convolutional representation network h: RepresentationNetwork.forward
+ * (src/neural_networks/neural_network.py:83-102) built from ConvLayer, PoolLayer and ResBlock
+ * (src/neural_networks/network_builder.py:32-151), for G games per call.  Activations between
+ * these entry points are channels-last, f32[G][H][W][C]; the host side composes them
+ * (muzero_amd/conv_repr.py).
+ * ------------------------------------------------------------------------------------ */
+
+/* Layout changes at the two ends: the history tensor of mz_history_push_assemble is [G][C][P]
+ * (P = H*W), the latent the search reads is [G][c][h*w]. */
+int mz_nchw_to_nhwc(const float *x, int32_t G, int32_t C, int32_t P, float *y, void *stream);
+int mz_nhwc_to_nchw(const float *x, int32_t G, int32_t C, int32_t P, float *y, void *stream);
+
+/* nn.Conv2d as ONE matrix product (network_builder.py:39-45,87-105,110-118): the pixel index table
+ * idx i32[KS*KS][G*Ho*Wo] names, for every tap (ky, kx) and output pixel (g, oy, ox), the input pixel
+ * (g*H + iy)*W + ix it multiplies, or -1 in the zero padding; mz_wide_forward_gather then evaluates
+ *   y[row][co] = act(sum over taps and ci of x[idx[tap][row]][ci] * Wk[co][tap][ci] + bias[co])
+ * with Wk the weight in [Cout][KS][KS][Cin] order (mz_conv_weight_kmajor) packed by mz_wide_plan /
+ * mz_wide_pack as a Linear layer of KS*KS*Cin inputs.  n_seg = KS*KS segments of Cin floats; Cin must
+ * be a multiple of 64 and x 16-byte aligned with row stride ldx >= Cin (a multiple of 4).
+ * Workspace as for mz_wide_forward. */
+int mz_conv_index(int32_t *idx, int32_t G, int32_t H, int32_t W, int32_t KS, int32_t stride, int32_t pad,
+                  int32_t Ho, int32_t Wo, void *stream);
+int mz_conv_weight_kmajor(const float *weight, int32_t Cout, int32_t Cin, int32_t KS, float *out, void *stream);
+int mz_wide_forward_gather(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                           const int32_t *x_rows, int32_t n_seg, float *y, int64_t ldy, int32_t B,
+                           float *workspace, int64_t workspace_floats, void *stream);
+/* The same convolution evaluated directly (one lane per output value) for the layers the matrix
+ * product does not cover: input channels no multiple of 64, or very few output channels.
+ * weight_kmajor f32[Cout][KS][KS][Cin], bias f32[Cout] or NULL, y f32[G][Ho][Wo][Cout]. */
+int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float *bias, int32_t G, int32_t H,
+                        int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t pad,
+                        int32_t activation, float *y, void *stream);
+
+/* nn.BatchNorm2d in train mode with the batch statistics of ONE game per call, as the reference
+ * evaluates h (src/training_data_generator.py:117 calls it with batch size 1 and no network ever
+ * enters eval mode): per (game, channel) the mean and biased variance over the P positions of
+ * x f32[G][P][C], folded with the affine parameters into scale = weight / sqrt(var + eps) and
+ * shift = bias - mean * scale, both f32[G][C].  mean / var f32[G][C] are optional outputs. */
+int mz_bn_stats(const float *x, int32_t G, int32_t P, int32_t C, const float *weight, const float *bias,
+                float eps, float *scale, float *shift, float *mean, float *var, void *stream);
+/* y = act(x * scale[g][c] + shift[g][c] + r) with r = 0 (residual NULL), the residual itself
+ * (identity skip of a ResBlock, network_builder.py:139-142) or residual * res_scale + res_shift (the
+ * BatchNorm of the 1x1 skip convolution, :108-120).  y may alias x. */
+int mz_bn_apply(const float *x, const float *scale, const float *shift, const float *residual,
+                const float *res_scale, const float *res_shift, int32_t activation, float *y, int32_t G,
+                int32_t P, int32_t C, void *stream);
+/* The running statistics a BatchNorm2d holds after those G calls in game order (momentum m,
+ * unbiased variance of the P values of each call): running <- (1 - m) running + m stat, G times.
+ * mean / var as written by mz_bn_stats; running_mean / running_var f32[C] are updated in place. */
+int mz_bn_running_update(const float *mean, const float *var, int32_t G, int32_t C, int32_t P, float momentum,
+                         float *running_mean, float *running_var, void *stream);
+
+/* nn.MaxPool2d / nn.AvgPool2d with a square window, no padding (PoolLayer, network_builder.py:53-70;
+ * the optional pooling of a ResBlock, :123-129).  y f32[G][Ho][Wo][C], Ho = (H - kernel)/stride + 1. */
+int mz_pool2d_nhwc(const float *x, int32_t G, int32_t H, int32_t W, int32_t C, int32_t kernel, int32_t stride,
+                   int32_t is_max, float *y, void *stream);
+/* F.adaptive_avg_pool2d to the latent's h x w (neural_network.py:100-101), written as the
+ * f32[G][C][h][w] latent the search reads. */
+int mz_adaptive_avg_to_nchw(const float *x, int32_t G, int32_t H, int32_t W, int32_t C, int32_t h, int32_t w,
+                            float *y, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Whole search in one launch: MCTS.run (src/search/mcts.py:44-74) for all G trees of the pool
  * -- root creation, root expansion, prior perturbation, S rounds of select / expand / simulate
  * / backup, and the result -- with every network evaluation fused in (MLP-only g and f).

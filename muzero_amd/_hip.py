@@ -137,6 +137,18 @@ _SIGS = {
                                   C.c_int64, _P]),
     "mz_wide_static_workspace_floats": (C.c_int64, []),
     "mz_wide_forward_static": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P]),
+    "mz_nchw_to_nhwc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mz_nhwc_to_nchw": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mz_conv_index": (C.c_int, [_P] + [C.c_int32] * 8 + [_P]),
+    "mz_conv_weight_kmajor": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mz_wide_forward_gather": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, C.c_int32, _P, C.c_int64,
+                                         C.c_int32, _P, C.c_int64, _P]),
+    "mz_conv_direct_nhwc": (C.c_int, [_P, _P, _P] + [C.c_int32] * 9 + [_P, _P]),
+    "mz_bn_stats": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    "mz_bn_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_bn_running_update": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
+    "mz_pool2d_nhwc": (C.c_int, [_P] + [C.c_int32] * 7 + [_P, _P]),
+    "mz_adaptive_avg_to_nchw": (C.c_int, [_P] + [C.c_int32] * 6 + [_P, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
                                    _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),

@@ -1,0 +1,307 @@
+"""Convolutional representation network h on the HIP kernels, for G games per call.
+
+`ConvRepresentation(repr_net)` evaluates RepresentationNetwork.forward
+(src/neural_networks/neural_network.py:83-102) layer by layer -- ConvLayer, PoolLayer, ResBlock
+(src/neural_networks/network_builder.py:32-151), the optional 1x1 final convolution and the
+adaptive average pool -- on channels-last activations:
+
+* a convolution whose input channel count is a multiple of 64 is ONE fp32 matrix product on the
+  matrix cores (`mz_wide_forward_gather`: rows = output pixels of all games, reduction = (tap, input
+  channel), A operand gathered through a pixel index table), bias and activation in its epilogue;
+  other convolutions (few channels) run on the direct kernel;
+* every BatchNorm2d normalises with the statistics of ONE game, because the reference calls h with
+  batch size 1 and never leaves train mode (src/training_data_generator.py:117, main.py:39 only
+  disables grad): `mz_bn_stats` per (game, channel), `mz_bn_apply` with the residual sum and the
+  activation of the block fused in;
+* `track_running_stats=True` also advances the BatchNorm running statistics exactly as those G
+  batch-size-1 calls in game order would (`mz_bn_running_update`), and `sync_running_stats()` writes
+  them (and num_batches_tracked) back into the caller's module, so that a state_dict saved after
+  self-play equals the reference's.
+
+There is no CPU fallback: every step is a kernel of libmuzero_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from muzero_amd import _hip
+from muzero_amd._hip import ptr
+from muzero_amd.neural_networks.network_builder import ConvLayer, PoolLayer, ResBlock
+
+_ACT_OF = {torch.nn.Identity: "none", torch.nn.ReLU: "relu", torch.nn.Tanh: "tanh", torch.nn.Sigmoid: "sigmoid"}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _act(module) -> int:
+    kind = type(module)
+    if kind not in _ACT_OF:
+        raise NotImplementedError(f"activation {kind.__name__} inside the representation network is not element-wise")
+    return _hip.ACT[_ACT_OF[kind]]
+
+
+def _one(v) -> int:
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            raise NotImplementedError("only square kernels / equal strides and paddings are supported")
+        return int(v[0])
+    return int(v)
+
+
+class _Conv:
+    """One nn.Conv2d: packed for the gathered matrix product, or k-major weights for the direct kernel."""
+
+    def __init__(self, conv: torch.nn.Conv2d, act: int):
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.k, self.stride, self.pad = _one(conv.kernel_size), _one(conv.stride), _one(conv.padding)
+        if _one(conv.dilation) != 1 or conv.groups != 1 or conv.padding_mode != "zeros":
+            raise NotImplementedError("dilated, grouped or non-zero-padded convolutions are not supported")
+        self.act = act
+        self.module = conv
+        self.matrix = self.cin % 64 == 0 and self.cout >= 16
+        self.plan = None      # _hip.PackedLayer (matrix form)
+        self.wk = None        # f32[cout][k][k][cin]
+        self.bias = None
+
+    def out_hw(self, H: int, W: int) -> tuple[int, int]:
+        return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+
+
+class _Bn:
+    def __init__(self, bn: torch.nn.BatchNorm2d):
+        self.module = bn
+        self.C = bn.num_features
+        self.eps = float(bn.eps)
+        self.momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not supported")
+        self.weight = self.bias = None
+        self.running_mean = self.running_var = None
+        self.calls = 0   # batch-size-1 calls since the running statistics were last written back
+
+
+class ConvRepresentation:
+    def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False):
+        self.src = repr_net
+        self.device = torch.device(device)
+        self.track_running_stats = track_running_stats
+        self.latent_hw = (repr_net.latent_height, repr_net.latent_width)
+        self._bufs: dict = {}
+        self._index: dict = {}
+        self.blob = None
+        self._keep: list = []
+        self.refresh()
+
+    # ---- packing ------------------------------------------------------------------------------
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(self.device, torch.float32).contiguous().clone()
+        self._keep.append(t)
+        return t
+
+    def refresh(self) -> None:
+        """Re-reads the module's weights (call after a weight update)."""
+        self._keep = []
+        self.steps = []          # ("conv", _Conv) | ("pool", k, s, is_max) | ("block", conv1, bn1, conv2, bn2, down, dbn, act, pool)
+        self.convs: list[_Conv] = []
+        self.bns: list[_Bn] = []
+
+        def conv(c, act):
+            cv = _Conv(c, act)
+            self.convs.append(cv)
+            return cv
+
+        def bn(b):
+            bb = _Bn(b)
+            self.bns.append(bb)
+            return bb
+
+        def block(blk: ResBlock):
+            act = _act(blk.activation)
+            down = dbn = None
+            if blk.downsample is not None:
+                down, dbn = conv(blk.downsample[0], _hip.ACT["none"]), bn(blk.downsample[1])
+            pool = None
+            if not isinstance(blk.pool, torch.nn.Identity):
+                pool = (_one(blk.pool.kernel_size), _one(blk.pool.stride))
+                if _one(blk.pool.padding) != 0:
+                    raise NotImplementedError("padded pooling is not supported")
+            self.steps.append(("block", conv(blk.conv1, _hip.ACT["none"]), bn(blk.bn1), conv(blk.conv2, _hip.ACT["none"]),
+                               bn(blk.bn2), down, dbn, act, pool))
+
+        for layer in self.src.downsample_layers:
+            if isinstance(layer, ConvLayer):
+                self.steps.append(("conv", conv(layer.conv, _act(layer.activation))))
+            elif isinstance(layer, PoolLayer):
+                p = layer.pool
+                if _one(p.padding) != 0 or getattr(p, "ceil_mode", False):
+                    raise NotImplementedError("padded / ceil-mode pooling is not supported")
+                self.steps.append(("pool", _one(p.kernel_size), _one(p.stride), isinstance(p, torch.nn.MaxPool2d)))
+            elif isinstance(layer, ResBlock):
+                block(layer)
+            else:
+                raise NotImplementedError(f"unexpected layer {type(layer).__name__} in the representation network")
+        for blk in self.src.res_blocks:
+            block(blk)
+        if isinstance(self.src.final_conv, torch.nn.Conv2d):
+            self.steps.append(("conv", conv(self.src.final_conv, _hip.ACT["none"])))
+
+        lib = _hip.lib()
+        off = 0
+        packs = []
+        for cv in self.convs:
+            w = self._dev(cv.module.weight)
+            cv.wk = torch.empty(cv.cout * cv.k * cv.k * cv.cin, dtype=torch.float32, device=self.device)
+            _hip.check(lib.mz_conv_weight_kmajor(ptr(w), cv.cout, cv.cin, cv.k, ptr(cv.wk), _stream()), "mz_conv_weight_kmajor")
+            cv.bias = self._dev(cv.module.bias) if cv.module.bias is not None else None
+            if cv.matrix:
+                dense = _hip.Dense(ptr(cv.wk), ptr(cv.bias), cv.k * cv.k * cv.cin, cv.cout, cv.act, 0)
+                cv.plan = _hip.PackedLayer()
+                n = lib.mz_wide_plan(C.byref(dense), off, C.byref(cv.plan))
+                if n < 0:
+                    _hip.check(int(n), "mz_wide_plan")
+                off += n
+                packs.append((dense, cv.plan))
+        if self.blob is None or self.blob.numel() != max(off, 1):
+            self.blob = torch.empty(max(off, 1), dtype=torch.float32, device=self.device)
+        for dense, plan in packs:
+            _hip.check(lib.mz_wide_pack(C.byref(dense), C.byref(plan), ptr(self.blob), _stream()), "mz_wide_pack")
+        for b in self.bns:
+            m = b.module
+            ones = torch.ones(b.C) if m.weight is None else m.weight
+            zeros = torch.zeros(b.C) if m.bias is None else m.bias
+            b.weight, b.bias = self._dev(ones), self._dev(zeros)
+            if m.track_running_stats and m.running_mean is not None:
+                b.running_mean, b.running_var = self._dev(m.running_mean), self._dev(m.running_var)
+            b.calls = 0
+
+    def sync_running_stats(self) -> None:
+        """Writes the running statistics (and call counts) accumulated by this evaluator into the
+        caller's module, as the reference's own calls would have left them."""
+        with torch.no_grad():
+            for b in self.bns:
+                m = b.module
+                if b.calls == 0 or b.running_mean is None:
+                    continue
+                m.running_mean.copy_(b.running_mean.to(m.running_mean.device))
+                m.running_var.copy_(b.running_var.to(m.running_var.device))
+                if m.num_batches_tracked is not None:
+                    m.num_batches_tracked += b.calls
+                b.calls = 0
+
+    # ---- scratch ------------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype=torch.float32) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        t = self._bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t[:n].view(*shape)
+
+    def _index_table(self, G, H, W, cv: _Conv, Ho, Wo) -> torch.Tensor:
+        key = (G, H, W, cv.k, cv.stride, cv.pad)
+        t = self._index.get(key)
+        if t is None:
+            t = torch.empty((cv.k * cv.k, G * Ho * Wo), dtype=torch.int32, device=self.device)
+            _hip.check(_hip.lib().mz_conv_index(ptr(t), G, H, W, cv.k, cv.stride, cv.pad, Ho, Wo, _stream()), "mz_conv_index")
+            self._index[key] = t
+        return t
+
+    # ---- layers -------------------------------------------------------------------------------
+    def _conv(self, x, G, H, W, cv: _Conv, name: str):
+        """x f32[G, H, W, cin] -> (y f32[G, Ho, Wo, cout], Ho, Wo)."""
+        lib = _hip.lib()
+        Ho, Wo = cv.out_hw(H, W)
+        if Ho <= 0 or Wo <= 0:
+            raise ValueError(f"convolution kernel {cv.k} does not fit a {H}x{W} input")
+        y = self._buf(name, (G, Ho, Wo, cv.cout))
+        rows = G * Ho * Wo
+        if cv.matrix:
+            need = lib.mz_wide_workspace(C.byref(cv.plan), rows)
+            ws = self._buf("ws", (need,)) if need > 0 else None
+            if cv.k == 1 and cv.stride == 1 and cv.pad == 0:
+                _hip.check(lib.mz_wide_forward(C.byref(cv.plan), ptr(self.blob), ptr(x), cv.cin, None, ptr(y), cv.cout, rows,
+                                               ptr(ws), need, _stream()), "mz_wide_forward")
+            else:
+                idx = self._index_table(G, H, W, cv, Ho, Wo)
+                _hip.check(lib.mz_wide_forward_gather(C.byref(cv.plan), ptr(self.blob), ptr(x), cv.cin, ptr(idx), cv.k * cv.k,
+                                                      ptr(y), cv.cout, rows, ptr(ws), need, _stream()), "mz_wide_forward_gather")
+        else:
+            _hip.check(lib.mz_conv_direct_nhwc(ptr(x), ptr(cv.wk), ptr(cv.bias), G, H, W, cv.cin, cv.cout, cv.k, cv.stride,
+                                               cv.pad, cv.act, ptr(y), _stream()), "mz_conv_direct_nhwc")
+        return y, Ho, Wo
+
+    def _stats(self, x, G, P, b: _Bn, name: str):
+        lib = _hip.lib()
+        scale, shift = self._buf(name + "_scale", (G, b.C)), self._buf(name + "_shift", (G, b.C))
+        track = self.track_running_stats and b.running_mean is not None
+        mean = self._buf(name + "_mean", (G, b.C)) if track else None
+        var = self._buf(name + "_var", (G, b.C)) if track else None
+        _hip.check(lib.mz_bn_stats(ptr(x), G, P, b.C, ptr(b.weight), ptr(b.bias), b.eps, ptr(scale), ptr(shift), ptr(mean),
+                                   ptr(var), _stream()), "mz_bn_stats")
+        if track:
+            _hip.check(lib.mz_bn_running_update(ptr(mean), ptr(var), G, b.C, P, b.momentum, ptr(b.running_mean),
+                                                ptr(b.running_var), _stream()), "mz_bn_running_update")
+            b.calls += G
+        return scale, shift
+
+    def _pool(self, x, G, H, W, Cc, k, s, is_max, name):
+        Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
+        y = self._buf(name, (G, Ho, Wo, Cc))
+        _hip.check(_hip.lib().mz_pool2d_nhwc(ptr(x), G, H, W, Cc, k, s, 1 if is_max else 0, ptr(y), _stream()), "mz_pool2d_nhwc")
+        return y, Ho, Wo
+
+    def __call__(self, history: torch.Tensor) -> torch.Tensor:
+        """history f32[G, C*K+K, H, W] (the tensor of mz_history_push_assemble) -> latent f32[G, c, h, w]."""
+        lib = _hip.lib()
+        G, Cc, H, W = history.shape
+        x_in = history.to(self.device, torch.float32).contiguous()
+        x = self._buf("in_nhwc", (G, H, W, Cc))
+        _hip.check(lib.mz_nchw_to_nhwc(ptr(x_in), G, Cc, H * W, ptr(x), _stream()), "mz_nchw_to_nhwc")
+        # activations ping-pong between named buffers; a block's input must survive until its skip sum
+        for si, step in enumerate(self.steps):
+            tag = f"s{si % 2}"
+            if step[0] == "conv":
+                cv = step[1]
+                if cv.cin != Cc:
+                    raise ValueError(f"layer {si} expects {cv.cin} channels, got {Cc}")
+                x, H, W = self._conv(x, G, H, W, cv, tag + "_y")
+                Cc = cv.cout
+            elif step[0] == "pool":
+                _, k, s, is_max = step
+                x, H, W = self._pool(x, G, H, W, Cc, k, s, is_max, tag + "_y")
+            else:
+                _, c1, b1, c2, b2, down, dbn, act, pool = step
+                if c1.cin != Cc:
+                    raise ValueError(f"block {si} expects {c1.cin} channels, got {Cc}")
+                a, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1")
+                sc1, sh1 = self._stats(a, G, H1 * W1, b1, tag + "_bn1")
+                _hip.check(lib.mz_bn_apply(ptr(a), ptr(sc1), ptr(sh1), None, None, None, act, ptr(a), G, H1 * W1, c1.cout,
+                                           _stream()), "mz_bn_apply")
+                b, H2, W2 = self._conv(a, G, H1, W1, c2, tag + "_c2")
+                sc2, sh2 = self._stats(b, G, H2 * W2, b2, tag + "_bn2")
+                y = self._buf(tag + "_y", (G, H2, W2, c2.cout))
+                if down is not None:
+                    d, Hd, Wd = self._conv(x, G, H, W, down, tag + "_d")
+                    if (Hd, Wd) != (H2, W2):
+                        raise ValueError("the skip path and the main path of a residual block disagree in size")
+                    scd, shd = self._stats(d, G, Hd * Wd, dbn, tag + "_bnd")
+                    _hip.check(lib.mz_bn_apply(ptr(b), ptr(sc2), ptr(sh2), ptr(d), ptr(scd), ptr(shd), act, ptr(y), G, H2 * W2,
+                                               c2.cout, _stream()), "mz_bn_apply")
+                else:
+                    if (H, W, Cc) != (H2, W2, c2.cout):
+                        raise ValueError("an identity skip needs equal input and output shapes")
+                    _hip.check(lib.mz_bn_apply(ptr(b), ptr(sc2), ptr(sh2), ptr(x), None, None, act, ptr(y), G, H2 * W2, c2.cout,
+                                               _stream()), "mz_bn_apply")
+                x, H, W, Cc = y, H2, W2, c2.cout
+                if pool is not None:
+                    x, H, W = self._pool(x, G, H, W, Cc, pool[0], pool[1], True, tag + "_p")
+        h, w = self.latent_hw
+        out = torch.empty((G, Cc, h, w), dtype=torch.float32, device=self.device)
+        _hip.check(lib.mz_adaptive_avg_to_nchw(ptr(x), G, H, W, Cc, h, w, ptr(out), _stream()), "mz_adaptive_avg_to_nchw")
+        return out

@@ -44,11 +44,16 @@ constexpr size_t kMaxLds = 160 * 1024;
 // Workgroup = 2 x 2 waves, wave tile = (16 MTW) x (16 NTW), workgroup tile TM x TN = 32 MTW x 32 NTW.
 // Activations: global -> registers -> LDS chunk (double buffered, one barrier per chunk);
 // weights: packed tiles straight from global/L2 into registers, one k-tile ahead.
-template <int MTW, int NTW, bool VEC>
+//
+// SEG (convolutions as gathered products): the reduction dimension is `n_seg` segments of
+// seg_chunks * 64 floats, and segment s of output row r is read from input row x_rows[s * B + r]
+// (negative: zeros) -- one segment per kernel tap, the input rows being the pixels of a
+// channels-last image whose channel count is the segment length.
+template <int MTW, int NTW, bool VEC, bool SEG = false>
 __global__ void __launch_bounds__(kWT) __attribute__((amdgpu_waves_per_eu(2)))
 k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restrict__ x, long long ldx,
        const int32_t *__restrict__ x_rows, float *__restrict__ y, long long ldy, int B, int splitk,
-       int chunks_per_split, float *__restrict__ ws) {
+       int chunks_per_split, float *__restrict__ ws, int seg_chunks = 0) {
     constexpr int TM = 32 * MTW, TN = 32 * NTW, XR = TM / 16;
     extern __shared__ __align__(16) float xs[];  // [2][TM][kLdX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,19 +72,30 @@ k_wide(mz_packed_layer L, const float *__restrict__ blob, const float *__restric
     for (int i = 0; i < XR; ++i) {
         const int r = m0 + sr + 16 * i;
         int src = -1;
-        if (r < B) src = x_rows ? x_rows[r] : r;
+        if (!SEG && r < B) src = x_rows ? x_rows[r] : r;
         srow[i] = src;
     }
     constexpr int XH = XR / 2;  // the chunk is fetched in two halves to halve the registers it holds
     // VEC: branch-free -- an absent row or a column past K reads a valid address here and is
     // zeroed when it is written to LDS (so nothing waits for the load where it is issued)
     auto fetch = [&](int c, int half, f32x4 (&v)[XH]) {
-        const int k = c * kKC + sc;
+        int k = c * kKC + sc;
+        if (SEG) {
+            const int seg = c / seg_chunks;
+            k -= seg * seg_chunks * kKC;  // offset inside the segment = channel of the pixel
+            if (half == 0 && (c == c_lo || c - seg * seg_chunks == 0)) {
+#pragma unroll
+                for (int i = 0; i < XR; ++i) {
+                    const int r = m0 + sr + 16 * i;
+                    srow[i] = r < B ? x_rows[(long long)seg * B + r] : -1;
+                }
+            }
+        }
 #pragma unroll
         for (int ii = 0; ii < XH; ++ii) {
             const int i = half * XH + ii;
             if (VEC) {
-                const float *p = x + (long long)max(srow[i], 0) * ldx + min(k, L.K - 4);
+                const float *p = x + (long long)max(srow[i], 0) * ldx + (SEG ? k : min(k, L.K - 4));
                 v[ii] = *reinterpret_cast<const f32x4 *>(p);
             } else {
                 f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1169,8 +1185,8 @@ int64_t mz_wide_workspace(const mz_packed_layer *h_plan, int32_t B) {
 
 static int wide_forward_impl(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
                              const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
-                             int64_t workspace_floats, void *stream) {
-    if (!h_plan || !blob || !x || !y || B < 0 || ldx < h_plan->K || ldy < h_plan->N || h_plan->Kp <= 0 || h_plan->Np <= 0)
+                             int64_t workspace_floats, void *stream, int n_seg = 0) {
+    if (!h_plan || !blob || !x || !y || B < 0 || (n_seg == 0 && ldx < h_plan->K) || ldy < h_plan->N || h_plan->Kp <= 0 || h_plan->Np <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_wide_forward: NULL argument, empty plan, negative B or row stride below the row width");
     if (h_plan->act < MZ_ACT_NONE || h_plan->act > MZ_ACT_SIGMOID)
         return mz::fail(MZ_ERR_ARG, "mz_wide_forward: activation %d is not element-wise", h_plan->act);
@@ -1185,13 +1201,22 @@ static int wide_forward_impl(const mz_packed_layer *h_plan, const float *blob, c
     const bool vec = (ldx % 4 == 0) && (L.K % 4 == 0) && L.K >= 4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const dim3 grid(s.tiles_n, s.tiles_m, s.splitk);
     const size_t lds = (size_t)2 * s.tm * kLdX * sizeof(float);
+    int seg_chunks = 0;
+    if (n_seg > 0) {
+        const int seg_k = L.K / n_seg;
+        if (!x_rows || (long long)seg_k * n_seg != L.K || seg_k % kKC != 0 || ldx < seg_k || !vec)
+            return mz::fail(MZ_ERR_ARG, "mz_wide_forward_gather: K=%d must be n_seg=%d segments of a multiple of %d floats, "
+                            "rows 16-byte aligned with a stride of at least one segment, and x_rows given", L.K, n_seg, kKC);
+        seg_chunks = seg_k / kKC;
+    }
     auto launch = [&](auto kernel) -> int {
         MZ_TRY(allow_lds(kernel, lds, "k_wide"));
         hipLaunchKernelGGL(kernel, grid, dim3(kWT), lds, st, L, blob, x, (long long)ldx, x_rows, y, (long long)ldy, B,
-                           s.splitk, s.chunks_per_split, workspace);
+                           s.splitk, s.chunks_per_split, workspace, seg_chunks);
         return MZ_OK;
     };
-    if (s.big) MZ_TRY(vec ? launch(k_wide<4, 4, true>) : launch(k_wide<4, 4, false>));
+    if (n_seg > 0) MZ_TRY(s.big ? launch(k_wide<4, 4, true, true>) : launch(k_wide<2, 2, true, true>));
+    else if (s.big) MZ_TRY(vec ? launch(k_wide<4, 4, true>) : launch(k_wide<4, 4, false>));
     else MZ_TRY(vec ? launch(k_wide<2, 2, true>) : launch(k_wide<2, 2, false>));
     MZ_TRY(mz::check_launch("k_wide"));
     if (s.splitk > 1) {
@@ -1208,6 +1233,13 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
                     const int32_t *x_rows, float *y, int64_t ldy, int32_t B, float *workspace,
                     int64_t workspace_floats, void *stream) {
     return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, workspace, workspace_floats, stream);
+}
+
+int mz_wide_forward_gather(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
+                           const int32_t *x_rows, int32_t n_seg, float *y, int64_t ldy, int32_t B, float *workspace,
+                           int64_t workspace_floats, void *stream) {
+    if (n_seg <= 0) return mz::fail(MZ_ERR_ARG, "mz_wide_forward_gather: n_seg must be positive");
+    return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, workspace, workspace_floats, stream, n_seg);
 }
 
 int64_t mz_wide_static_workspace_floats(void) { return kWideScratchFloats; }

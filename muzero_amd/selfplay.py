@@ -22,7 +22,7 @@ from muzero_amd import _hip
 from muzero_amd._hip import ptr
 from muzero_amd.engine import BatchedMCTS, _stream, make_networks
 from muzero_amd.environments.connect_four import BatchedConnectFour
-from muzero_amd.neural_networks.per_call import per_call_statistics  # noqa: F401  (re-exported)
+from muzero_amd.neural_networks.per_call import per_call_statistics  # noqa: F401  (re-exported: batched torch evaluation with per-game statistics)
 
 
 class DeviceHistory:
@@ -47,27 +47,31 @@ class DeviceHistory:
 
 class RepresentationRunner:
     """h on the GPU.  MLP-style configs (`downsample: [], res_net: []`, latent H, W equal to the
-    observation's) are one 1x1 convolution and run the HIP kernel; every other configuration
-    runs a private device copy of the torch module (its convolutions are not part of this path
-    yet), with the per-game batch statistics of the reference's one-game-at-a-time calls.
+    observation's) are one 1x1 convolution and run the point-wise HIP kernel; every other
+    configuration runs layer by layer on the convolution kernels (muzero_amd.conv_repr:
+    gathered fp32 matrix products, BatchNorm with the per-game batch statistics of the reference's
+    one-game-at-a-time calls).
 
     The caller's module is never moved or modified: the runner keeps its own device copy of the
-    weights and re-reads them whenever a parameter or buffer of the module has changed
-    (in-place updates bump a tensor's version counter; a replaced tensor has a new address), so
-    a generator that is reused after training searches with the trained weights."""
+    weights and re-reads them whenever a parameter of the module has changed (in-place updates
+    bump a tensor's version counter; a replaced tensor has a new address), so a generator that is
+    reused after training searches with the trained weights.  `track_running_stats=True`
+    additionally advances the BatchNorm running statistics as the reference's calls would;
+    `sync_running_stats()` writes them back into the caller's module."""
 
-    def __init__(self, repr_net: torch.nn.Module, device="cuda"):
+    def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False):
         self.src = repr_net
         self.device = torch.device(device)
         self.pointwise = (len(repr_net.downsample_layers) == 0 and len(repr_net.res_blocks) == 0
                           and isinstance(repr_net.final_conv, torch.nn.Conv2d))
         self.latent_hw = (repr_net.latent_height, repr_net.latent_width)
+        self.track_running_stats = track_running_stats
         self._seen = None
-        self.net = None
+        self.conv = None
         self.refresh()
 
     def _versions(self):
-        return tuple((t._version, t.data_ptr()) for t in list(self.src.parameters()) + list(self.src.buffers()))
+        return tuple((t._version, t.data_ptr()) for t in self.src.parameters())
 
     def refresh(self, force: bool = False) -> None:
         """Re-reads the module's weights if they changed since the last call (always with `force`)."""
@@ -78,11 +82,17 @@ class RepresentationRunner:
             conv = self.src.final_conv
             self.weight = conv.weight.detach().to(self.device, torch.float32).reshape(conv.out_channels, -1).contiguous().clone()
             self.bias = conv.bias.detach().to(self.device, torch.float32).contiguous().clone() if conv.bias is not None else None
-            self.net = None  # the pooled fallback below copies the module again when it is next needed
-        else:
-            import copy
-            self.net = copy.deepcopy(self.src).to(self.device)
+        if self.conv is not None:
+            self.conv.sync_running_stats()
+            self.conv.refresh()
+        elif not self.pointwise:
+            from muzero_amd.conv_repr import ConvRepresentation
+            self.conv = ConvRepresentation(self.src, device=self.device, track_running_stats=self.track_running_stats)
         self._seen = seen
+
+    def sync_running_stats(self) -> None:
+        if self.conv is not None:
+            self.conv.sync_running_stats()
 
     def __call__(self, history: torch.Tensor) -> torch.Tensor:
         self.refresh()
@@ -94,11 +104,10 @@ class RepresentationRunner:
             _hip.check(_hip.lib().mz_repr_pointwise(ptr(x), ptr(self.weight), ptr(self.bias), G, cin, cout, H * W,
                                                     ptr(out), _stream()), "mz_repr_pointwise")
             return out
-        if self.net is None:  # a point-wise module asked for another latent size: the torch module handles the pooling
-            import copy
-            self.net = copy.deepcopy(self.src).to(self.device)
-        with torch.no_grad(), per_call_statistics(self.net):
-            return self.net(history.to(self.device))
+        if self.conv is None:  # a point-wise module asked for another latent size: 1x1 convolution + adaptive pool
+            from muzero_amd.conv_repr import ConvRepresentation
+            self.conv = ConvRepresentation(self.src, device=self.device, track_running_stats=self.track_running_stats)
+        return self.conv(history)
 
 
 def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_action: torch.Tensor | None,

@@ -1,0 +1,158 @@
+"""The convolutional representation network h on the HIP kernels (muzero_amd.conv_repr) against the
+torch module evaluated as the reference evaluates it: ONE game per call, train mode (per-call
+BatchNorm statistics), src/training_data_generator.py:117 with
+src/neural_networks/neural_network.py:83-102 and network_builder.py:32-151.
+
+Tolerance: 1e-5 relative with an absolute floor of 1e-5 of the output's scale.  The float32 torch
+reference is itself a rounded computation; where the shapes allow it the float64 evaluation of the
+same module is the yardstick and the float32 torch result is shown to be no closer to it than ours.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(obs, latent, K, downsample, res_net, seed=0):
+    from muzero_amd.config import RepresentationNetworkConfig
+    from muzero_amd.neural_networks import RepresentationNetwork
+    torch.manual_seed(seed)
+    h = RepresentationNetwork(obs, latent, RepresentationNetworkConfig(history_length=K, downsample=downsample, res_net=res_net))
+    with torch.no_grad():
+        for m in h.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    return h
+
+
+def _cv(c, k, s, p, act="relu"):
+    from muzero_amd.config import ConvLayerConfig
+    return ConvLayerConfig(out_channels=c, kernel_size=k, stride=s, padding=p, activation=act)
+
+
+def _rb(c, k=3, s=1, p=1, act="relu", pk=1, ps=1):
+    from muzero_amd.config import ResBlockConfig
+    return ResBlockConfig(out_channels=c, kernel_size=k, stride=s, padding=p, activation=act, pool_kernel_size=pk, pool_stride=ps)
+
+
+def _pool(k, s, kind):
+    from muzero_amd.config import PoolLayerConfig
+    return PoolLayerConfig(kernel_size=k, stride=s, pool_type=kind)
+
+
+def _per_game(h, x, dtype=torch.float32, device="cpu"):
+    m = copy.deepcopy(h).to(device=device, dtype=dtype)
+    m.train()
+    with torch.no_grad():
+        out = torch.cat([m(x[i:i + 1].to(device=device, dtype=dtype)) for i in range(x.shape[0])])
+    return out, m
+
+
+def _close(got, want, tol=1e-5):
+    want = want.double().cpu().numpy()
+    np.testing.assert_allclose(got.double().cpu().numpy(), want, rtol=tol, atol=tol * float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("case", ["direct-small", "matrix-64", "mixed-strides", "avgpool-tanh", "pointwise-pooled"])
+def test_conv_representation_matches_torch_per_game(case):
+    from muzero_amd.conv_repr import ConvRepresentation
+    if case == "direct-small":      # few channels everywhere: the direct kernel; identity-skip and 1x1-skip blocks
+        h = _net((2, 8, 8), (5, 4, 4), 2, [_cv(6, 2, 2, 0), _rb(6), _rb(4)], [_rb(4, k=1, p=0)])
+        G, obs = 5, (2, 8, 8)
+    elif case == "matrix-64":       # 64-channel layers: gathered matrix products (3x3, 2x2 stride 2, 1x1 skip, 1x1 final)
+        h = _net((3, 12, 12), (16, 3, 3), 16, [_cv(64, 2, 2, 0), _rb(64), _cv(128, 2, 2, 0), _rb(128), _rb(3)], [])
+        G, obs = 4, (3, 12, 12)
+    elif case == "mixed-strides":   # a strided block with pooling, 5x5 kernels, a block that changes the channel count
+        h = _net((1, 20, 20), (8, 2, 2), 3, [_cv(64, 3, 1, 1, act="tanh"), _rb(64, k=3, s=2, p=1, pk=2, ps=2), _rb(32, k=5, p=2)], [_rb(8)])
+        G, obs = 3, (1, 20, 20)
+    elif case == "avgpool-tanh":    # average pooling layer, sigmoid / tanh activations, non-square-divisible adaptive pool
+        h = _net((2, 14, 14), (6, 3, 3), 1, [_cv(8, 3, 1, 1, act="sigmoid"), _pool(2, 2, "avg"), _rb(6, act="tanh")], [])
+        G, obs = 4, (2, 14, 14)
+    else:                           # a point-wise network whose latent is smaller than the observation: 1x1 conv + adaptive pool
+        h = _net((2, 6, 7), (4, 3, 3), 1, [], [])
+        G, obs = 6, (2, 6, 7)
+    K = h.history_length
+    torch.manual_seed(1)
+    x = torch.rand(G, obs[0] * K + K, obs[1], obs[2])
+    want64, _ = _per_game(h, x, torch.float64)
+    want32, _ = _per_game(h, x, torch.float32)
+    run = ConvRepresentation(h)
+    got = run(x.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == want64.shape
+    _close(got, want64)
+    # our distance from the float64 result is of the order of float32 torch's own
+    scale = float(want64.abs().max())
+    ours = float((got.double().cpu() - want64).abs().max()) / scale
+    theirs = float((want32.double() - want64).abs().max()) / scale
+    assert ours <= max(4 * theirs, 2e-6), (ours, theirs)
+    # a batch must NOT share statistics: the batched torch call differs from the per-game result
+    if any(isinstance(m, torch.nn.BatchNorm2d) for m in h.modules()):
+        with torch.no_grad():
+            batched = copy.deepcopy(h).train()(x)
+        assert float((batched - want32).abs().max()) > 1e-3 * scale
+
+
+def test_running_statistics_follow_the_reference_calls():
+    """track_running_stats: after G games the BatchNorm buffers equal those the reference's G
+    batch-size-1 train-mode calls leave (network_builder.py:94,104,118; momentum 0.1, unbiased
+    variance), twice in a row, and sync_running_stats writes them into the caller's module."""
+    from muzero_amd.conv_repr import ConvRepresentation
+    h = _net((3, 12, 12), (16, 3, 3), 4, [_cv(64, 2, 2, 0), _rb(64), _rb(3)], [_rb(3)])
+    G = 7
+    K = h.history_length
+    torch.manual_seed(2)
+    xs = [torch.rand(G, 3 * K + K, 12, 12) for _ in range(2)]
+    ref = copy.deepcopy(h).train()
+    run = ConvRepresentation(h, track_running_stats=True)
+    for x in xs:
+        with torch.no_grad():
+            for i in range(G):
+                ref(x[i:i + 1])
+        run(x.cuda())
+    run.sync_running_stats()
+    for (name, a), (_, b) in zip(h.named_buffers(), ref.named_buffers()):
+        if name.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == 2 * G, name
+        else:
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6, err_msg=name)
+    # the parameters themselves were not touched, so the evaluator did not need to re-read them
+    assert all(torch.equal(p, q) for p, q in zip(h.parameters(), ref.parameters()))
+
+
+def _shipped_h():
+    """The representation network of src/config/config_car_racing.yaml:57-131."""
+    return _net((3, 96, 96), (256, 6, 6), 32,
+                [_cv(128, 2, 2, 0), _rb(128), _rb(128), _cv(256, 2, 2, 0), _rb(256), _rb(256), _rb(256), _pool(2, 2, "max")],
+                [_rb(3)], seed=3)
+
+
+def test_shipped_representation_network_256_games():
+    """The shipped CarRacing h (32-frame history of 3x96x96 -> latent [256, 6, 6]) for 256 games in one
+    call against the torch module called once per game on the GPU (float32, MIOpen)."""
+    from muzero_amd.conv_repr import ConvRepresentation
+    h = _shipped_h()
+    G = 256
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(G, 128, 96, 96, device="cuda", generator=gen) * 255.0  # CarRacing frames are 0..255 (car_racing.py:66)
+    x[:, 96:] = torch.randint(0, 5, (G, 32, 1, 1), device="cuda", generator=gen).float()  # action planes
+    run = ConvRepresentation(h)
+    got = run(x)
+    torch.cuda.synchronize()
+    want, _ = _per_game(h, x, torch.float32, device="cuda")
+    assert got.shape == (G, 256, 6, 6)
+    scale = float(want.abs().max())
+    err = (got - want).abs().amax(dim=(1, 2, 3)) / scale
+    print(f"shipped h, 256 games: max |HIP - torch| / scale = {float(err.max()):.2e} (median game {float(err.median()):.2e})")
+    # float64 yardstick for three of the games (CPU): both float32 results sit at the same distance from it
+    idx = [0, 100, 255]
+    want64, _ = _per_game(h, x[idx].cpu(), torch.float64)
+    ours = float((got[idx].double().cpu() - want64).abs().max()) / scale
+    theirs = float((want[idx].double().cpu() - want64).abs().max()) / scale
+    print(f"against float64: ours {ours:.2e}, float32 torch {theirs:.2e}")
+    assert ours <= 1e-5 or ours <= 2 * theirs, (ours, theirs)
+    assert float(err.max()) <= 1e-5 + 2 * (ours + theirs)
