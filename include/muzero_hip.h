@@ -355,6 +355,43 @@ int mz_adaptive_avg_to_nchw(const float *x, int32_t G, int32_t H, int32_t W, int
                             float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Replay side of the learner on the device: the prioritised episode sampling of
+ * ReplayBuffer.sample_batch / update_priorities (src/replay_buffer.py:72-130) over the priorities of a
+ * fixed-shape episode store, and the cut of training windows (src/training.py:131-160, history as
+ * assembled by bptt, :252-262).
+ * ------------------------------------------------------------------------------------ */
+
+/* sample_batch for n stored episodes: P(i) = priority[i]^alpha / sum (uniform when the sum is below
+ * 1e-8), B draws with replacement by numpy's inverse-CDF search (RandomState.choice: cumulative sum
+ * normalised by its last entry, searchsorted(side="right")) on the caller's uniform numbers u f64[B]
+ * (what RandomState.random_sample(B) returns), weight f64[B] = (n P(draw))^-beta / max over the draw.
+ * probs / cdf f64[n] are outputs (and the kernel's scratch).
+ * Optional window choice (done_len i64[n] != NULL; episode lengths): a draw whose episode has fewer
+ * than `need` = lookback + roll_ahead + 1 chunks is dropped (src/training.py:210-221) -- it stays in
+ * the batch as a window of the longest stored episode with weight32 = 0 and slot = cap -- and
+ * start = lookback + floor(u_start * span) over the span admissible window starts (:139-142);
+ * cut_from i32[B] is the episode row to cut the window from, slot i32[B] what mz_per_update takes. */
+int mz_per_sample(const double *priority, int32_t n, double alpha, double beta, const double *u, int32_t B,
+                  double *probs, double *cdf, int32_t *draw, double *weight, const int64_t *done_len,
+                  int32_t need, int32_t lookback, int32_t roll_ahead, int32_t cap, const double *u_start,
+                  float *weight32, int32_t *slot, int32_t *cut_from, int32_t *start, void *stream);
+/* update_priorities: priority[slot[b]] = |error[b]| + 1e-6 in draw order (the last occurrence of a
+ * slot wins), *max_priority follows; entries with slot outside [0, cap) are ignored. */
+int mz_per_update(double *priority, double *max_priority, const int32_t *slot, const float *error, int32_t B,
+                  int32_t cap, void *stream);
+/* B training windows (rows[b], k[b]) out of the store obs f32[rows][T][C][H][W], action i64[rows][T],
+ * policy f32[rows][T][A], value f64[rows][T], reward f32[rows][T]: history f32[B][C*K+K][H][W] (the
+ * K-slot ring filled with the first of the `lookback` past frames, the later ones added; frames in
+ * slot order, then K planes with each slot's action id), actions i64[B][w+1], policies f32[B][w+1][A],
+ * rewards f32[B][w+1] of chunks k .. k+w, and the value targets z f32[B][w+1] of _compute_z_targets
+ * (src/training.py:223-242; pow_tab = device copy of mz_gamma_powers). */
+int mz_replay_cut_windows(const float *obs, const int64_t *action, const float *policy, const double *value,
+                          const float *reward, int32_t T, int32_t C, int32_t H, int32_t W, int32_t A,
+                          const int32_t *rows, const int32_t *k, int32_t B, int32_t lookback,
+                          int32_t roll_ahead, int32_t K, const double *pow_tab, float *history,
+                          int64_t *actions, float *policies, float *z, float *rewards, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Whole search in one launch: MCTS.run (src/search/mcts.py:44-74) for all G trees of the pool
  * -- root creation, root expansion, prior perturbation, S rounds of select / expand / simulate
  * / backup, and the result -- with every network evaluation fused in (MLP-only g and f).

@@ -149,6 +149,11 @@ _SIGS = {
     "mz_bn_running_update": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, _P]),
     "mz_pool2d_nhwc": (C.c_int, [_P] + [C.c_int32] * 7 + [_P, _P]),
     "mz_adaptive_avg_to_nchw": (C.c_int, [_P] + [C.c_int32] * 6 + [_P, _P]),
+    "mz_per_sample": (C.c_int, [_P, C.c_int32, C.c_double, C.c_double, _P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "mz_per_update": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "mz_replay_cut_windows": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 5 + [_P, _P] + [C.c_int32] * 4 +
+                              [_P, _P, _P, _P, _P, _P, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
                                    _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),

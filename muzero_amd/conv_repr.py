@@ -8,7 +8,7 @@ adaptive average pool -- on channels-last activations:
 * a convolution whose input channel count is a multiple of 64 is ONE fp32 matrix product on the
   matrix cores (`mz_wide_forward_gather`: rows = output pixels of all games, reduction = (tap, input
   channel), A operand gathered through a pixel index table), bias and activation in its epilogue;
-  other convolutions (few channels) run on the direct kernel;
+  other convolutions (few input channels) run on the direct kernel;
 * every BatchNorm2d normalises with the statistics of ONE game, because the reference calls h with
   batch size 1 and never leaves train mode (src/training_data_generator.py:117, main.py:39 only
   disables grad): `mz_bn_stats` per (game, channel), `mz_bn_apply` with the residual sum and the
@@ -62,7 +62,9 @@ class _Conv:
             raise NotImplementedError("dilated, grouped or non-zero-padded convolutions are not supported")
         self.act = act
         self.module = conv
-        self.matrix = self.cin % 64 == 0 and self.cout >= 16
+        # the matrix product pads the output channels to 16: still far cheaper than one lane per output value
+        # once the reduction is long
+        self.matrix = self.cin % 64 == 0
         self.plan = None      # _hip.PackedLayer (matrix form)
         self.wk = None        # f32[cout][k][k][cin]
         self.bias = None

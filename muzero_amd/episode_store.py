@@ -12,9 +12,16 @@ into tensors `[slot, step, ...]` and windows are cut out of them with gathers:
 `to_episodes()` converts back to the reference's Episode/Chunk lists, and
 `tests/test_episode_store.py` checks that windows cut from the tensors equal the windows the
 list-based path (muzero_amd.learner.windows_to_batch) cuts from those lists.
+
+A store on a CUDA device samples, cuts and re-prioritises with the kernels of libmuzero_hip.so
+(`mz_per_sample`, `mz_replay_cut_windows`, `mz_per_update`: one launch each); a store on the CPU
+(host-side tests of the window semantics) evaluates the same definitions with torch operations.
 """
 from __future__ import annotations
 
+import ctypes as C
+
+import numpy as np
 import torch
 
 from muzero_amd.learner import WindowBatch
@@ -89,6 +96,8 @@ class DeviceEpisodeStore:
         first past frame if there was none.  `z_targets(R, V, discount) -> Z` (f64 [B, w+1])."""
         dev, K, w = self.device, history_length, roll_ahead
         B = int(slots.numel())
+        if dev.type == "cuda":
+            return self._cut_windows_kernel(slots, k, lookback, roll_ahead, history_length, discount, is_weights)
         start = torch.clamp(k - lookback, min=0)
         n_add = k - start - 1
         j = torch.arange(K, device=dev)[None, :]
@@ -107,6 +116,40 @@ class DeviceEpisodeStore:
         isw = torch.ones(B, device=dev) if is_weights is None else torch.as_tensor(is_weights, dtype=torch.float32, device=dev)
         return WindowBatch(history, self.done["action"][sl, steps], self.done["policy"][sl, steps],
                            torch.as_tensor(Z, device=dev).to(torch.float32), R.to(torch.float32), isw)
+
+    def _pow_tab(self, discount: float, w: int) -> torch.Tensor:
+        key = (float(discount), int(w))
+        tab = getattr(self, "_pow_tabs", {}).get(key)
+        if tab is None:
+            from muzero_amd import _hip
+            host = np.zeros(w + 2, np.float64)
+            _hip.check(_hip.lib().mz_gamma_powers(float(discount), w, _hip.ptr(host)), "mz_gamma_powers")
+            tab = torch.from_numpy(host).to(self.device)
+            self.__dict__.setdefault("_pow_tabs", {})[key] = tab
+        return tab
+
+    def _cut_windows_kernel(self, rows, k, lookback, roll_ahead, history_length, discount, is_weights) -> WindowBatch:
+        """cut_windows in one launch (mz_replay_cut_windows), value targets included."""
+        from muzero_amd import _hip
+        from muzero_amd._hip import ptr
+        dev, K, w = self.device, history_length, roll_ahead
+        B = int(rows.numel())
+        obs = self.done["obs"]
+        C_, H, W = obs.shape[2:]
+        rows32 = rows.to(torch.int32).contiguous()
+        k32 = k.to(torch.int32).contiguous()
+        history = torch.empty((B, C_ * K + K, H, W), dtype=torch.float32, device=dev)
+        actions = torch.empty((B, w + 1), dtype=torch.int64, device=dev)
+        policies = torch.empty((B, w + 1, self.A), dtype=torch.float32, device=dev)
+        z = torch.empty((B, w + 1), dtype=torch.float32, device=dev)
+        rewards = torch.empty((B, w + 1), dtype=torch.float32, device=dev)
+        _hip.check(_hip.lib().mz_replay_cut_windows(
+            ptr(obs), ptr(self.done["action"]), ptr(self.done["policy"]), ptr(self.done["value"]), ptr(self.done["reward"]),
+            self.T, C_, H, W, self.A, ptr(rows32), ptr(k32), B, lookback, w, K, ptr(self._pow_tab(discount, w)),
+            ptr(history), ptr(actions), ptr(policies), ptr(z), ptr(rewards), torch.cuda.current_stream().cuda_stream),
+            "mz_replay_cut_windows")
+        isw = torch.ones(B, device=dev) if is_weights is None else torch.as_tensor(is_weights, dtype=torch.float32, device=dev)
+        return WindowBatch(history, actions, policies, z, rewards, isw)
 
     def sample_windows(self, batch_size: int, lookback: int, roll_ahead: int, history_length: int, discount: float,
                        z_targets, generator=None):
@@ -132,7 +175,8 @@ class DeviceEpisodeStore:
         return torch.where(total < 1e-8, uniform, scaled / total)
 
     def sample_prioritized(self, batch_size: int, lookback: int, roll_ahead: int, history_length: int,
-                           discount: float, z_targets, alpha: float = 0.6, beta: float = 1.0, generator=None):
+                           discount: float, z_targets, alpha: float = 0.6, beta: float = 1.0, generator=None,
+                           uniforms=None):
         """ReplayBuffer.sample_batch + the learner's window cut, on the device
         (src/replay_buffer.py:72-119, src/training.py:115-142): min(batch_size, n) episodes drawn
         with replacement with P(i) ~ priority^alpha, importance weights (n P(i))^-beta divided
@@ -142,6 +186,10 @@ class DeviceEpisodeStore:
         episode with importance weight 0 (no contribution to the weighted loss, its gradient or
         the weight total) and slot = capacity (the scratch row, ignored by update_priorities), so
         the learner sees `min(batch_size, n)` windows every step instead of a new shape per step.
+
+        `uniforms` (CUDA stores): (u f64[B], u_start f64[B]) to use instead of torch's generator --
+        with u = np.random.random_sample(B) the draw equals np.random.choice's on the same stream, i.e.
+        the episodes ReplayBuffer.sample_batch would pick.
 
         Returns (WindowBatch, slots, k); `slots` are what update_priorities takes.  Each kept
         window carries the weight and the slot of ITS episode (the reference indexes both by the
@@ -154,6 +202,9 @@ class DeviceEpisodeStore:
         longest = torch.argmax(self.done_len[:n])
         if int(self.done_len[longest]) < need:
             raise ValueError("no stored episode is long enough for a training window")
+        if self.device.type == "cuda":
+            return self._sample_prioritized_kernel(min(batch_size, n), n, lookback, roll_ahead, history_length, discount,
+                                                   alpha, beta, generator, uniforms)
         probs = self.sampling_probabilities(alpha)
         draw = torch.multinomial(probs, min(batch_size, n), replacement=True, generator=generator)
         weights = (n * probs[draw]) ** (-beta)
@@ -167,10 +218,45 @@ class DeviceEpisodeStore:
                                  is_weights=torch.where(keep, weights, torch.zeros_like(weights)).to(torch.float32))
         return batch, torch.where(keep, draw, torch.full_like(draw, self.cap)), k
 
+    def _sample_prioritized_kernel(self, B, n, lookback, roll_ahead, history_length, discount, alpha, beta, generator,
+                                   uniforms):
+        from muzero_amd import _hip
+        from muzero_amd._hip import ptr
+        dev = self.device
+        if uniforms is None:
+            u = torch.rand(B, dtype=torch.float64, device=dev, generator=generator)
+            u_start = torch.rand(B, dtype=torch.float64, device=dev, generator=generator)
+        else:
+            u, u_start = (torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float64).to(dev).contiguous()
+                          for x in uniforms)
+            assert u.numel() == B and u_start.numel() == B
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.last_probs, cdf = torch.empty(n, **f64), torch.empty(n, **f64)
+        draw, self.last_weights = torch.empty(B, **i32), torch.empty(B, **f64)
+        weight32 = torch.empty(B, dtype=torch.float32, device=dev)
+        slot, cut_from, start = torch.empty(B, **i32), torch.empty(B, **i32), torch.empty(B, **i32)
+        _hip.check(_hip.lib().mz_per_sample(
+            ptr(self.priority), n, float(alpha), float(beta), ptr(u), B, ptr(self.last_probs), ptr(cdf), ptr(draw),
+            ptr(self.last_weights), ptr(self.done_len), lookback + roll_ahead + 1, lookback, roll_ahead, self.cap, ptr(u_start),
+            ptr(weight32), ptr(slot), ptr(cut_from), ptr(start), torch.cuda.current_stream().cuda_stream), "mz_per_sample")
+        self.last_draw = draw
+        batch = self._cut_windows_kernel(cut_from, start, lookback, roll_ahead, history_length, discount, weight32)
+        return batch, slot.to(torch.int64), start.to(torch.int64)
+
     def update_priorities(self, slots: torch.Tensor, errors: torch.Tensor) -> None:
         """priority[slot] = |error| + 1e-6, the running maximum follows
         (src/replay_buffer.py:121-130).  When a slot occurs more than once the last occurrence
         wins, as in the reference's loop; entries with slot = capacity are ignored."""
+        if self.device.type == "cuda":
+            from muzero_amd import _hip
+            from muzero_amd._hip import ptr
+            s32 = slots.to(device=self.device, dtype=torch.int32).contiguous()
+            err = errors.to(device=self.device, dtype=torch.float32).contiguous()
+            _hip.check(_hip.lib().mz_per_update(ptr(self.priority), ptr(self.max_priority), ptr(s32), ptr(err), int(s32.numel()),
+                                                self.cap, torch.cuda.current_stream().cuda_stream), "mz_per_update")
+            self.priority[self.cap] = 0.0  # the scratch row never carries a priority
+            return
         slots = slots.to(self.device)
         pri = errors.to(device=self.device, dtype=torch.float64).abs() + 1e-6
         pos = torch.arange(slots.numel(), device=self.device)
