@@ -391,6 +391,21 @@ int mz_replay_cut_windows(const float *obs, const int64_t *action, const float *
                           int32_t roll_ahead, int32_t K, const double *pow_tab, float *history,
                           int64_t *actions, float *policies, float *z, float *rewards, void *stream);
 
+/* The learner's unroll loss for B windows in one launch, with its gradients with respect to the
+ * network outputs: policy_loss / value_loss / reward_loss of src/training.py:307-320 summed over the
+ * steps of bptt (:275-303; the final step adds value and policy, :297-303).
+ *   pred_p f32[w+1][B][A] (the networks' softmaxed policies, used as logits by F.cross_entropy),
+ *   pred_v f32[w+1][B], pred_r f32[w][B]: step-major, as the batched unroll produces them;
+ *   target_p f32[B][w+1][A], z f32[B][w+1], r f32[B][w+1] (its first w columns are used), is_weights f32[B].
+ * per_window f32[B] = cp * sum CE + cv * sum (v - z)^2 + cr * sum (r_pred - r)^2 (the |loss| that
+ * becomes the episode's priority, :171), parts f32[3][B] its three terms, sums f32[4] =
+ * [sum_b is_weights_b * per_window_b, sum policy, sum value, sum reward] (fixed summation order),
+ * g_p / g_v / g_r = d sums[0] / d pred_p / pred_v / pred_r in the predictions' layouts. */
+int mz_unroll_loss(const float *pred_p, const float *pred_v, const float *pred_r, const float *target_p,
+                   const float *z, const float *r, const float *is_weights, int32_t B, int32_t w, int32_t A,
+                   float cp, float cv, float cr, float *per_window, float *parts, float *sums, float *g_p,
+                   float *g_v, float *g_r, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Whole search in one launch: MCTS.run (src/search/mcts.py:44-74) for all G trees of the pool
  * -- root creation, root expansion, prior perturbation, S rounds of select / expand / simulate

@@ -154,6 +154,7 @@ _SIGS = {
     "mz_per_update": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "mz_replay_cut_windows": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 5 + [_P, _P] + [C.c_int32] * 4 +
                               [_P, _P, _P, _P, _P, _P, _P]),
+    "mz_unroll_loss": (C.c_int, [_P] * 7 + [C.c_int32] * 3 + [C.c_float] * 3 + [_P] * 7),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
                                    _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),

@@ -78,9 +78,54 @@ def batched_unroll_loss(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ah
         return _unroll(repr_net, dyn_net, pred_net, batch, roll_ahead, cp, cv, cr)
 
 
+class _FusedUnrollLoss(torch.autograd.Function):
+    """The three losses over all unroll steps and windows in one launch (mz_unroll_loss); the kernel
+    also leaves d(weighted sum)/d(prediction), so backward is a scaling."""
+
+    @staticmethod
+    def forward(ctx, pred_p, pred_v, pred_r, target_p, z, r, is_weights, cp, cv, cr):
+        from muzero_amd import _hip
+        from muzero_amd._hip import ptr
+        W1, B, A = pred_p.shape
+        w = W1 - 1
+        dev = pred_p.device
+        pred_p, pred_v, pred_r = pred_p.contiguous(), pred_v.contiguous(), pred_r.contiguous()
+        target_p, z, r, is_weights = (t.to(torch.float32).contiguous() for t in (target_p, z, r, is_weights))
+        per_window = torch.empty(B, dtype=torch.float32, device=dev)
+        parts = torch.empty((3, B), dtype=torch.float32, device=dev)
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        g_p, g_v, g_r = torch.empty_like(pred_p), torch.empty_like(pred_v), torch.empty_like(pred_r)
+        _hip.check(_hip.lib().mz_unroll_loss(ptr(pred_p), ptr(pred_v), ptr(pred_r) if w > 0 else None, ptr(target_p), ptr(z),
+                                             ptr(r), ptr(is_weights), B, w, A, float(cp), float(cv), float(cr),
+                                             ptr(per_window), ptr(parts), ptr(sums), ptr(g_p), ptr(g_v),
+                                             ptr(g_r) if w > 0 else None, torch.cuda.current_stream().cuda_stream),
+                   "mz_unroll_loss")
+        ctx.save_for_backward(g_p, g_v, g_r)
+        ctx.mark_non_differentiable(per_window, sums)
+        return sums[0], per_window, sums
+
+    @staticmethod
+    def backward(ctx, g_weighted, _g_per_window, _g_sums):
+        g_p, g_v, g_r = ctx.saved_tensors
+        return g_p * g_weighted, g_v * g_weighted, g_r * g_weighted, None, None, None, None, None, None, None
+
+
 def _unroll(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, cp: float, cv: float, cr: float):
     latent = repr_net(batch.history)
     B = len(batch)
+    if latent.is_cuda:
+        # the networks step by step (torch / rocBLAS, autograd), the losses of all steps in one kernel
+        pp, pv, pr = [], [], []
+        for i in range(roll_ahead):
+            pred_p, pred_v = pred_net(latent)
+            latent, pred_r = dyn_net(latent, batch.actions[:, i])
+            pp.append(pred_p), pv.append(pred_v[:, 0]), pr.append(pred_r[:, 0])
+        final_p, final_v = pred_net(latent)
+        pp.append(final_p), pv.append(final_v[:, 0])
+        pr_t = torch.stack(pr) if pr else torch.zeros((0, B), dtype=torch.float32, device=latent.device)
+        weighted, per_window, sums = _FusedUnrollLoss.apply(torch.stack(pp), torch.stack(pv), pr_t, batch.policies, batch.z,
+                                                            batch.rewards, batch.is_weights, cp, cv, cr)
+        return weighted, per_window, (sums[1], sums[2], sums[3])
     lp = torch.zeros(B, dtype=torch.float32, device=latent.device)
     lv = torch.zeros_like(lp)
     lr = torch.zeros_like(lp)
@@ -134,39 +179,94 @@ class DataParallelLearner:
         loss, per_window = self.step_local(batch.rows(mine) if len(mine) > 0 else None)
         return loss, per_window, mine
 
+    def _buckets(self):
+        """One flat gradient buffer per network (the order backward finishes them in: f and g, whose
+        first use is the first unroll step, then h), every parameter's .grad a view into it: no copy
+        into a flat buffer before the collective, none back after it."""
+        if getattr(self, "_bucket_list", None) is None:
+            self._bucket_list = []
+            for net in (self.nets[2], self.nets[1], self.nets[0]):
+                ps = [p for p in net.parameters() if p.requires_grad]
+                if not ps:
+                    continue
+                flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+                off = 0
+                for p in ps:
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+                self._bucket_list.append((flat, ps))
+        return self._bucket_list
+
     def step_local(self, local: WindowBatch | None):
         """One optimizer step where every rank brings its OWN windows (e.g. cut from its own
         episode store): the gradient of the weighted loss sum and the weight total are summed
         over ranks, so the result is the step a single rank would take on the union of the
-        windows.  Returns (normalised loss over all ranks, per-window |loss| of the local ones)."""
-        self.optimizer.zero_grad(set_to_none=False)
+        windows.  Returns (normalised loss over all ranks, per-window |loss| of the local ones).
+
+        Communication overlaps the backward pass: the [weight total, weighted loss] pair is reduced
+        while backward runs, and each network's flat gradient bucket starts its all-reduce from the
+        hook of the last parameter whose gradient arrives (src/training.py:174-191 does backward and
+        step on one device; here the collective of a bucket runs beside the rest of backward)."""
         dev = self.params[0].device
+        buckets = self._buckets()
+        for flat, ps in buckets:
+            flat.zero_()
+            off = 0
+            for p in ps:  # an optimizer or a caller may have replaced .grad: point it at the bucket again
+                if p.grad is None or p.grad.data_ptr() != flat[off:off + 1].data_ptr():
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
         flat_extra = torch.zeros(2, dtype=torch.float32, device=dev)  # [sum of weights, weighted loss sum]
         per_window = torch.zeros(0)
+        works, handles = [], []
+        multi = self.world > 1
         if local is not None and len(local) > 0:
             local = local.to(dev)
             wsum, per_window, _ = batched_unroll_loss(*self.nets, local, self.roll_ahead, self.coeff)
-            wsum.backward()
             flat_extra[0] = local.is_weights.sum()
             flat_extra[1] = wsum.detach()
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        flat = torch.cat([g.reshape(-1) for g in grads] + [flat_extra])
-        if self.world > 1:
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
-        norm = flat[-2]
+            ready = [False] * len(buckets)
+            nxt = [0]  # buckets are reduced in list order on every rank, whatever order backward finishes them in
+
+            def launch_ready():
+                while nxt[0] < len(buckets) and ready[nxt[0]]:
+                    works.append(self.dist.all_reduce(buckets[nxt[0]][0], op=self.dist.ReduceOp.SUM, async_op=True))
+                    nxt[0] += 1
+            if multi:
+                works.append(self.dist.all_reduce(flat_extra, op=self.dist.ReduceOp.SUM, async_op=True))
+                for bi, (flat, ps) in enumerate(buckets):
+                    left = [len(ps)]
+
+                    def arrived(_p, bi=bi, left=left):
+                        left[0] -= 1
+                        if left[0] == 0:
+                            ready[bi] = True
+                            launch_ready()
+                    handles += [p.register_post_accumulate_grad_hook(arrived) for p in ps]
+            wsum.backward()
+            for hnd in handles:
+                hnd.remove()
+            if multi:  # a parameter no window reached never fires its hook: reduce what is left, in order
+                ready = [True] * len(buckets)
+                launch_ready()
+        elif multi:  # a rank without windows still takes part in every collective
+            works.append(self.dist.all_reduce(flat_extra, op=self.dist.ReduceOp.SUM, async_op=True))
+            for flat, _ in buckets:
+                works.append(self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True))
+        for wk in works:
+            wk.wait()
+        norm = flat_extra[0]
         if float(norm) <= 0.0:
             # no usable window on any rank (every draw was an episode too short for a window): the
             # reference skips the optimizer step then (`if ep_indices_used:`, src/training.py:174);
             # dividing by the zero weight total would write NaN into every weight
-            self.optimizer.zero_grad(set_to_none=False)
+            for flat, _ in buckets:
+                flat.zero_()
             return 0.0, per_window.detach().abs().cpu()
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = (flat[off:off + n] / norm).view_as(p).clone()
-            off += n
+        for flat, _ in buckets:
+            flat.div_(norm)
         self.optimizer.step()
-        return float(flat[-1] / norm), per_window.detach().abs().cpu()
+        return float(flat_extra[1] / norm), per_window.detach().abs().cpu()
 
     # ------------------------------------------------------------------ recorded step
     def step_local_recorded(self, local: WindowBatch):

@@ -73,3 +73,86 @@ def test_recorded_step_equals_eager_step(opt_name):
     assert float(loss_r) == 0.0 and loss_e == 0.0
     for p, q in zip(pb, kept):
         assert torch.isfinite(p).all() and torch.equal(p, q)
+
+
+def test_batched_learner_step_reproduces_the_reference_learner():
+    """The batched step (one unroll over all windows, fused loss kernel, SGD) against the run of the
+    REFERENCE's NeuralNetworkManager.train recorded in tests/golden/selfplay_learner.npz
+    (src/training.py:110-208): same sampled episodes and window starts (numpy / random seeded as the
+    reference's run), so the same losses, priorities and trained weights -- eagerly and with the step
+    replayed from HIP graphs."""
+    import os
+    import random
+    from muzero_amd.config import TrainingConfig
+    from muzero_amd.learner import DataParallelLearner, windows_to_batch
+    from muzero_amd.replay_buffer import ReplayBuffer
+    from muzero_amd.training import compute_z_targets_batch
+    from muzero_amd.training_data_generator import Chunk, Episode
+    from tests.conftest import GOLDEN
+    from tests.test_gpu_dropin import _c4_nets_k2
+    z = np.load(os.path.join(GOLDEN, "selfplay_learner.npz"))
+    episodes = []
+    for e in range(int(z["n_episodes"])):
+        n = z[f"ep{e}_action"].shape[0]
+        episodes.append(Episode(chunks=[Chunk(
+            state=torch.from_numpy(z[f"ep{e}_state"][i:i + 1]), policy=torch.from_numpy(z[f"ep{e}_policy"][i]),
+            reward=float(z[f"ep{e}_reward"][i]), value=float(z[f"ep{e}_value"][i]), best_action=int(z[f"ep{e}_action"][i]))
+            for i in range(n)]))
+    lookback, w, gamma = 2, 2, 0.9
+    for recorded in (False, True):
+        h, g, f = (n.cuda() for n in _c4_nets_k2())
+        params = [p for n in (h, g, f) for p in n.parameters()]
+        opt = torch.optim.SGD(params, lr=0.01, weight_decay=1e-4, momentum=0.9)
+        dp = DataParallelLearner(h, g, f, opt, w, coeff=(0.25, 0.5, 1.0))   # policy, value, reward coefficients
+        random.seed(9)
+        np.random.seed(9)
+        rb = ReplayBuffer(buffer_size=8, batch_size=3, alpha=0.6, beta=1.0)
+        rb.add_episodes(episodes)
+        losses = []
+        for _ in range(3):   # mini_batch_size optimizer steps, as NeuralNetworkManager.train takes them
+            batch, indices, is_w = rb.sample_batch()
+            wins = [(ep, random.randrange(lookback, len(ep.chunks) - (w + 1) + 1)) for ep in batch]
+            R = np.array([[float(ep.chunks[i].reward) for i in range(k, k + w + 1)] for ep, k in wins], np.float64)
+            V = np.array([[float(ep.chunks[i].value) for i in range(k, k + w + 1)] for ep, k in wins], np.float64)
+            wb = windows_to_batch(wins, compute_z_targets_batch(R, V, gamma), R, is_w, h.history_length, lookback, w).to("cuda")
+            if recorded:
+                loss, per_window = dp.step_local_recorded(wb)
+                loss, per_window = float(loss), per_window.cpu()
+            else:
+                loss, per_window = dp.step_local(wb)
+            losses.append(loss)
+            rb.update_priorities(indices, [float(e) for e in per_window])
+        np.testing.assert_allclose(losses, z["learner_losses"], rtol=1e-5)
+        np.testing.assert_allclose([p for _, p in rb.episode_buffer], z["learner_priorities"], rtol=1e-5)
+        np.testing.assert_allclose(g.fc_merge.bias.detach().cpu().numpy(), z["learner_fc_merge_bias"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(f.policy_mlp[-2].weight.detach().cpu().numpy(), z["learner_policy_last_weight"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(h.final_conv.weight.detach().cpu().numpy(), z["learner_repr_weight"], rtol=1e-4, atol=1e-7)
+
+
+def test_fused_loss_kernel_matches_torch_losses_and_gradients():
+    """mz_unroll_loss against F.cross_entropy / squared errors and autograd on the same predictions."""
+    import torch.nn.functional as F
+    from muzero_amd.learner import _FusedUnrollLoss
+    torch.manual_seed(3)
+    B, w, A = 300, 4, 7
+    pp = torch.softmax(torch.randn(w + 1, B, A, device="cuda"), dim=-1).requires_grad_()
+    pv = torch.randn(w + 1, B, device="cuda", requires_grad=True)
+    pr = torch.randn(w, B, device="cuda", requires_grad=True)
+    tp = torch.softmax(torch.randn(B, w + 1, A, device="cuda"), dim=-1)
+    zt, rt = torch.randn(B, w + 1, device="cuda"), torch.randn(B, w + 1, device="cuda")
+    isw = torch.rand(B, device="cuda")
+    isw[::7] = 0.0
+    cp, cv, cr = 0.25, 0.5, 2.0
+    lp = sum(F.cross_entropy(pp[i], tp[:, i], reduction="none") for i in range(w + 1)) * cp
+    lv = sum((pv[i] - zt[:, i]) ** 2 for i in range(w + 1)) * cv
+    lr = sum((pr[i] - rt[:, i]) ** 2 for i in range(w)) * cr
+    want_pw = lp + lv + lr
+    want = (isw * want_pw).sum()
+    want_grads = torch.autograd.grad(want * 3.0, (pp, pv, pr))
+    got, pw, sums = _FusedUnrollLoss.apply(pp, pv, pr, tp, zt, rt, isw, cp, cv, cr)
+    got_grads = torch.autograd.grad(got * 3.0, (pp, pv, pr))
+    torch.testing.assert_close(pw, want_pw.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got.detach(), want.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(sums[1:].detach(), torch.stack([lp.sum(), lv.sum(), lr.sum()]).detach(), rtol=1e-5, atol=1e-4)
+    for a, b in zip(got_grads, want_grads):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
