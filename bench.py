@@ -257,6 +257,22 @@ def tower_search(G, S, dev, steps, with_roofline):
     return out
 
 
+def representation_time(G, dev, iters=3):
+    """The shipped convolutional h (32-frame history of 3x96x96 -> latent [256, 6, 6]) for G games
+    in one call on the HIP convolution path: milliseconds per self-play move."""
+    from muzero_amd.conv_repr import ConvRepresentation
+    from tools.bench_conv_repr import flops_per_game, shipped_h
+    run = ConvRepresentation(shipped_h(), device=dev)
+    x = torch.rand(G, 128, 96, 96, device=dev) * 255.0
+    run(x)
+    s = time_kernel(lambda: run(x), iters=iters)
+    del run, x
+    torch.cuda.empty_cache()
+    return {"games": G, "ms_per_move": s * 1e3, "tflops": flops_per_game() * G / s / 1e12,
+            "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            "kernel": "convolutions as gathered fp32 MFMA products (k_wide, segmented gather), per-game BatchNorm"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +403,7 @@ def main():
         for tg in args.tower_games:
             r = tower_search(tg, S, dev, steps=5 if tg <= 1024 else 3, with_roofline=not args.no_roofline)
             line["towers"][str(tg)] = r
+        line["towers"]["representation"] = representation_time(256, dev)
         first = line["towers"][str(args.tower_games[0])]
         line["towers"].update(sims_per_sec=first["sims_per_sec"], ms_per_search=first["ms_per_search"],
                               roofline_tower=first.get("roofline_tower"))

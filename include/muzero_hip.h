@@ -97,8 +97,9 @@ int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float 
 /* mz_tree_select / mz_tree_expand_commit that also return pool ROW indices (tree * cap + node),
  * the form the network entry points gather and scatter latents by: out_row i32[G] = row of the
  * selected leaf, out_child_rows i32[G][A] = rows its A children would get (n_nodes .. n_nodes+A-1),
- * out_child_row i32[G] = row of the drawn child (tree * cap - 1 where out_child = -1).  Any of the
- * three may be NULL.  Same reference lines as the two calls above; the lock-step search uses
+ * out_child_row i32[G] = row of the drawn child.  A tree whose descent or expansion failed (leaf or
+ * out_child = -1, a full pool) gets -1 in place of every row, which the network entry points read as a
+ * zero row and skip when scattering.  Any of the three may be NULL.  Same reference lines as the two calls above; the lock-step search uses
  * these to save the index arithmetic launches between selection and the network calls. */
 int mz_tree_select_rows(const mz_pool *pool, const double *sqrt_tab, const double *log_tab,
                         int32_t tab_len, int32_t flags, int32_t *out_leaf, int32_t *out_depth,

@@ -86,10 +86,11 @@ __global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const d
     if (a == 0) {
         out_leaf[g] = leaf;
         if (out_depth) out_depth[g] = depth;
-        if (out_row) out_row[g] = g * p.cap + leaf;
+        if (out_row) out_row[g] = leaf >= 0 ? g * p.cap + leaf : -1;  // a failed descent names no row (read as zeros)
     }
     // pool rows an expansion of this leaf would give its children
-    if (out_child_rows && a < p.A) out_child_rows[g * p.A + a] = g * p.cap + p.n_nodes[g] + a;
+    if (out_child_rows && a < p.A)
+        out_child_rows[g * p.A + a] = (leaf >= 0 && p.n_nodes[g] + p.A <= p.cap) ? g * p.cap + p.n_nodes[g] + a : -1;
 }
 
 // src/search/expansion.py:30-35 + src/search/nodes.py:24-30.
@@ -118,7 +119,7 @@ __global__ void k_expand_commit(mz_pool p, const int32_t *__restrict__ leaf, con
         } else {
             out_child[g] = -1;
         }
-        if (out_child_row) out_child_row[g] = g * p.cap + out_child[g];
+        if (out_child_row) out_child_row[g] = out_child[g] >= 0 ? g * p.cap + out_child[g] : -1;
     }
 }
 

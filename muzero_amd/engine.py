@@ -362,6 +362,14 @@ class BatchedMCTS:
     def finish(self) -> SearchResult:
         return SearchResult(*self.pool.result())
 
+    @staticmethod
+    def check(result: SearchResult) -> None:
+        """Raises if a search reported a failure: the single-launch kernel poisons the root value of a
+        tree (NaN) when a team of waves gave up waiting for its partner, and a lock-step search leaves
+        simulations undone when a descent or an expansion failed.  Waits for the GPU (diagnostic)."""
+        if bool(torch.isnan(result.value).any()):
+            raise _hip.HipError("the search kernel reported a stalled wave team (NaN root value)")
+
     def run(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
             rand_child: torch.Tensor, trace: dict | None = None, fused: bool | None = None) -> SearchResult:
         """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1].

@@ -30,6 +30,10 @@ from muzero_amd.learner import WindowBatch
 class DeviceEpisodeStore:
     def __init__(self, games: int, max_steps: int, obs_shape, num_actions: int, capacity: int, device="cuda"):
         """`capacity`: finished episodes kept (a ring: the oldest is overwritten)."""
+        if capacity < games:
+            # every game may finish in the same move: the finished ring must hold them all, or two games
+            # would be copied into one slot in one record() call
+            raise ValueError(f"capacity ({capacity}) must be at least the number of games ({games})")
         self.G, self.T, self.A, self.cap = games, max_steps, num_actions, capacity
         self.device = torch.device(device)
         C, H, W = obs_shape

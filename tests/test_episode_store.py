@@ -58,7 +58,9 @@ def test_windows_equal_the_list_based_path(K):
 
 
 def test_ring_overwrites_oldest_and_short_episodes_are_not_eligible():
-    store = DeviceEpisodeStore(4, 6, OBS, A, capacity=3, device="cpu")
+    with pytest.raises(ValueError):  # all games may end in one move: the ring must be able to take them
+        DeviceEpisodeStore(4, 6, OBS, A, capacity=3, device="cpu")
+    store = DeviceEpisodeStore(3, 6, OBS, A, capacity=3, device="cpu")
     _play(store, 40, seed=9)  # max_steps 6: every episode is cut at 6 moves at the latest
     assert store.size == 3 and store.n_finished > 3
     assert (store.done_len <= 6).all()
