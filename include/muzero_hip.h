@@ -327,6 +327,29 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
                         int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t pad,
                         int32_t activation, float *y, void *stream);
 
+/* The same convolutions at the bf16 matrix rate with float32 accuracy.  A float32 value is the exact
+ * sum of three bf16 terms (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)); a product x*w is,
+ * up to relative 2^-24, the sum of the six bf16 products x1w1, x1w2, x2w1, x1w3, x2w2, x3w1, which
+ * v_mfma_f32_16x16x32_bf16 accumulates in float32 -- 16/6 of the fp32 matrix rate.  Operands are kept
+ * in that split form: three bf16 planes (u16 bit patterns), plane p at element offset p * plane_stride.
+ *   mz_split3 / mz_unsplit3   float32 <-> planes, element-wise;
+ *   mz_conv3_forward          nn.Conv2d as in mz_wide_forward_gather: x3 planes [input pixels][C], idx the
+ *       table of mz_conv_index (i32[taps][rows]), w3 the split of the k-major weight f32[N][taps*C]
+ *       (mz_conv_weight_kmajor), bias f32[N] or NULL; output rows x N as float32 (y) and / or split (y3).
+ *       C must be a multiple of 64 and N of 128;
+ *   mz_bn_apply3              mz_bn_apply on a raw float32 convolution output, with the residual either
+ *       float32 (`residual`, optionally with the skip path's scale / shift) or split (`residual3`, the
+ *       block's own input), writing float32 and / or split. */
+int mz_split3(const float *x, int64_t total, uint16_t *out, int64_t plane_stride, void *stream);
+int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *out, void *stream);
+int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps,
+                     const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y,
+                     uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N, void *stream);
+int mz_bn_apply3(const float *x, const float *scale, const float *shift, const float *residual,
+                 const float *res_scale, const float *res_shift, const uint16_t *residual3, int64_t res_plane,
+                 int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t G, int32_t P, int32_t C,
+                 void *stream);
+
 /* nn.BatchNorm2d in train mode with the batch statistics of ONE game per call, as the reference
  * evaluates h (src/training_data_generator.py:117 calls it with batch size 1 and no network ever
  * enters eval mode): per (game, channel) the mean and biased variance over the P positions of

@@ -155,6 +155,12 @@ _SIGS = {
     "mz_replay_cut_windows": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 5 + [_P, _P] + [C.c_int32] * 4 +
                               [_P, _P, _P, _P, _P, _P, _P]),
     "mz_unroll_loss": (C.c_int, [_P] * 7 + [C.c_int32] * 3 + [C.c_float] * 3 + [_P] * 7),
+    "mz_split3": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P]),
+    "mz_unsplit3": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
+                                   C.c_int32, C.c_int32, _P]),
+    "mz_bn_apply3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32,
+                               C.c_int32, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,
                                    _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_action_table": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),

@@ -5,10 +5,15 @@
 (src/neural_networks/network_builder.py:32-151), the optional 1x1 final convolution and the
 adaptive average pool -- on channels-last activations:
 
-* a convolution whose input channel count is a multiple of 64 is ONE fp32 matrix product on the
-  matrix cores (`mz_wide_forward_gather`: rows = output pixels of all games, reduction = (tap, input
-  channel), A operand gathered through a pixel index table), bias and activation in its epilogue;
-  other convolutions (few input channels) run on the direct kernel;
+* a convolution is ONE matrix product on the matrix cores (rows = output pixels of all games,
+  reduction = (tap, input channel), A operand gathered through a pixel index table, bias and
+  activation in the epilogue).  Layers with input channels a multiple of 64 and output channels a
+  multiple of 128 -- all the heavy ones -- run at the bf16 matrix rate with float32 accuracy
+  (`mz_conv3_forward`: every float32 operand is the exact sum of three bf16 terms, six bf16 products
+  per float32 product, float32 accumulation; activations stay in that split form between layers);
+  other layers with 64-multiple input channels use the fp32 matrix instruction
+  (`mz_wide_forward_gather`), the rest (few input channels) the direct kernel.
+  `fast_convolutions=False` keeps everything on the fp32 instruction;
 * every BatchNorm2d normalises with the statistics of ONE game, because the reference calls h with
   batch size 1 and never leaves train mode (src/training_data_generator.py:117, main.py:39 only
   disables grad): `mz_bn_stats` per (game, channel), `mz_bn_apply` with the residual sum and the
@@ -65,6 +70,8 @@ class _Conv:
         # the matrix product pads the output channels to 16: still far cheaper than one lane per output value
         # once the reduction is long
         self.matrix = self.cin % 64 == 0
+        self.fast = self.cin % 64 == 0 and self.cout % 128 == 0 and self.k <= 4   # split-bf16 product (mz_conv3_forward)
+        self.w3 = None        # i16[3][cout * k * k * cin]: the split k-major weight
         self.plan = None      # _hip.PackedLayer (matrix form)
         self.wk = None        # f32[cout][k][k][cin]
         self.bias = None
@@ -87,10 +94,12 @@ class _Bn:
 
 
 class ConvRepresentation:
-    def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False):
+    def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False,
+                 fast_convolutions: bool = True):
         self.src = repr_net
         self.device = torch.device(device)
         self.track_running_stats = track_running_stats
+        self.fast_convolutions = fast_convolutions
         self.latent_hw = (repr_net.latent_height, repr_net.latent_width)
         self._bufs: dict = {}
         self._index: dict = {}
@@ -159,7 +168,12 @@ class ConvRepresentation:
             cv.wk = torch.empty(cv.cout * cv.k * cv.k * cv.cin, dtype=torch.float32, device=self.device)
             _hip.check(lib.mz_conv_weight_kmajor(ptr(w), cv.cout, cv.cin, cv.k, ptr(cv.wk), _stream()), "mz_conv_weight_kmajor")
             cv.bias = self._dev(cv.module.bias) if cv.module.bias is not None else None
-            if cv.matrix:
+            cv.fast = cv.fast and self.fast_convolutions
+            if cv.fast:
+                n = cv.wk.numel()
+                cv.w3 = torch.empty((3, n), dtype=torch.int16, device=self.device)
+                _hip.check(lib.mz_split3(ptr(cv.wk), n, ptr(cv.w3), n, _stream()), "mz_split3")
+            elif cv.matrix:
                 dense = _hip.Dense(ptr(cv.wk), ptr(cv.bias), cv.k * cv.k * cv.cin, cv.cout, cv.act, 0)
                 cv.plan = _hip.PackedLayer()
                 n = lib.mz_wide_plan(C.byref(dense), off, C.byref(cv.plan))
@@ -215,28 +229,62 @@ class ConvRepresentation:
         return t
 
     # ---- layers -------------------------------------------------------------------------------
-    def _conv(self, x, G, H, W, cv: _Conv, name: str):
-        """x f32[G, H, W, cin] -> (y f32[G, Ho, Wo, cout], Ho, Wo)."""
+    # An activation is held as float32 [G, H, W, C] (`f`), as three bf16 planes i16[3, G*H*W*C] (`s`), or
+    # both; whichever form a consumer lacks is made on demand.
+    class _Act:
+        __slots__ = ("f", "s", "n")
+
+        def __init__(self, f=None, s=None, n=0):
+            self.f, self.s, self.n = f, s, n
+
+    def _f32(self, a, name):
+        if a.f is None:
+            a.f = self._buf(name + "_f", (a.n,))
+            _hip.check(_hip.lib().mz_unsplit3(ptr(a.s), a.n, a.n, ptr(a.f), _stream()), "mz_unsplit3")
+        return a.f
+
+    def _s3(self, a, name):
+        if a.s is None:
+            a.s = self._buf(name + "_s", (3, a.n), torch.int16)
+            _hip.check(_hip.lib().mz_split3(ptr(a.f), a.n, ptr(a.s), a.n, _stream()), "mz_split3")
+        return a.s
+
+    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False):
+        """a: input activation [G, H, W, cin] -> (output activation, Ho, Wo).  The output is float32
+        unless `split_out` and the layer runs on the split-bf16 product (then split only)."""
         lib = _hip.lib()
         Ho, Wo = cv.out_hw(H, W)
         if Ho <= 0 or Wo <= 0:
             raise ValueError(f"convolution kernel {cv.k} does not fit a {H}x{W} input")
-        y = self._buf(name, (G, Ho, Wo, cv.cout))
         rows = G * Ho * Wo
+        n_out = rows * cv.cout
+        out = self._Act(n=n_out)
+        if cv.fast:
+            x3 = self._s3(a, name + "_in")
+            idx = self._index_table(G, H, W, cv, Ho, Wo)
+            if split_out:
+                out.s = self._buf(name + "_s", (3, n_out), torch.int16)
+            else:
+                out.f = self._buf(name, (n_out,))
+            _hip.check(lib.mz_conv3_forward(ptr(x3), a.n, cv.cin, ptr(idx), cv.k * cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
+                                            cv.act, ptr(out.f), ptr(out.s), n_out, rows, cv.cout, _stream()), "mz_conv3_forward")
+            return out, Ho, Wo
+        x = self._f32(a, name + "_in")
+        out.f = self._buf(name, (n_out,))
         if cv.matrix:
             need = lib.mz_wide_workspace(C.byref(cv.plan), rows)
             ws = self._buf("ws", (need,)) if need > 0 else None
             if cv.k == 1 and cv.stride == 1 and cv.pad == 0:
-                _hip.check(lib.mz_wide_forward(C.byref(cv.plan), ptr(self.blob), ptr(x), cv.cin, None, ptr(y), cv.cout, rows,
+                _hip.check(lib.mz_wide_forward(C.byref(cv.plan), ptr(self.blob), ptr(x), cv.cin, None, ptr(out.f), cv.cout, rows,
                                                ptr(ws), need, _stream()), "mz_wide_forward")
             else:
                 idx = self._index_table(G, H, W, cv, Ho, Wo)
                 _hip.check(lib.mz_wide_forward_gather(C.byref(cv.plan), ptr(self.blob), ptr(x), cv.cin, ptr(idx), cv.k * cv.k,
-                                                      ptr(y), cv.cout, rows, ptr(ws), need, _stream()), "mz_wide_forward_gather")
+                                                      ptr(out.f), cv.cout, rows, ptr(ws), need, _stream()), "mz_wide_forward_gather")
         else:
             _hip.check(lib.mz_conv_direct_nhwc(ptr(x), ptr(cv.wk), ptr(cv.bias), G, H, W, cv.cin, cv.cout, cv.k, cv.stride,
-                                               cv.pad, cv.act, ptr(y), _stream()), "mz_conv_direct_nhwc")
-        return y, Ho, Wo
+                                               cv.pad, cv.act, ptr(out.f), _stream()), "mz_conv_direct_nhwc")
+        return out, Ho, Wo
 
     def _stats(self, x, G, P, b: _Bn, name: str):
         lib = _hip.lib()
@@ -252,58 +300,93 @@ class ConvRepresentation:
             b.calls += G
         return scale, shift
 
-    def _pool(self, x, G, H, W, Cc, k, s, is_max, name):
-        Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
-        y = self._buf(name, (G, Ho, Wo, Cc))
-        _hip.check(_hip.lib().mz_pool2d_nhwc(ptr(x), G, H, W, Cc, k, s, 1 if is_max else 0, ptr(y), _stream()), "mz_pool2d_nhwc")
-        return y, Ho, Wo
+    def _apply(self, raw, scale, shift, act, G, P, Cc, name, split_out, res=None, res_scale=None, res_shift=None):
+        """BatchNorm scale / shift (+ residual) + activation on the raw convolution output `raw`;
+        `res`: None, an activation (identity skip) or a raw float32 tensor with its own scale / shift."""
+        lib = _hip.lib()
+        n = G * P * Cc
+        out = self._Act(n=n)
+        if split_out:
+            out.s = self._buf(name + "_s", (3, n), torch.int16)
+        else:
+            out.f = self._buf(name, (n,))
+        res_f = res3 = None
+        if res is not None and res_scale is not None:
+            res_f = res
+        elif res is not None:
+            if res.f is not None:
+                res_f = res.f
+            else:
+                res3 = res.s
+        _hip.check(lib.mz_bn_apply3(ptr(raw), ptr(scale), ptr(shift), ptr(res_f), ptr(res_scale), ptr(res_shift), ptr(res3), n,
+                                    act, ptr(out.f), ptr(out.s), n, G, P, Cc, _stream()), "mz_bn_apply3")
+        return out
+
+    def _wants_split(self, si: int) -> bool:
+        """Whether the consumer of step si's output reads the split form."""
+        if si + 1 >= len(self.steps):
+            return False
+        nxt = self.steps[si + 1]
+        if nxt[0] == "conv":
+            return nxt[1].fast
+        if nxt[0] == "block":
+            return nxt[1].fast
+        return False
 
     def __call__(self, history: torch.Tensor) -> torch.Tensor:
         """history f32[G, C*K+K, H, W] (the tensor of mz_history_push_assemble) -> latent f32[G, c, h, w]."""
         lib = _hip.lib()
         G, Cc, H, W = history.shape
         x_in = history.to(self.device, torch.float32).contiguous()
-        x = self._buf("in_nhwc", (G, H, W, Cc))
-        _hip.check(lib.mz_nchw_to_nhwc(ptr(x_in), G, Cc, H * W, ptr(x), _stream()), "mz_nchw_to_nhwc")
+        x = self._Act(f=self._buf("in_nhwc", (G * H * W * Cc,)), n=G * H * W * Cc)
+        _hip.check(lib.mz_nchw_to_nhwc(ptr(x_in), G, Cc, H * W, ptr(x.f), _stream()), "mz_nchw_to_nhwc")
         # activations ping-pong between named buffers; a block's input must survive until its skip sum
         for si, step in enumerate(self.steps):
             tag = f"s{si % 2}"
+            split_next = self._wants_split(si)
             if step[0] == "conv":
                 cv = step[1]
                 if cv.cin != Cc:
                     raise ValueError(f"layer {si} expects {cv.cin} channels, got {Cc}")
-                x, H, W = self._conv(x, G, H, W, cv, tag + "_y")
+                x, H, W = self._conv(x, G, H, W, cv, tag + "_y", split_out=split_next)
                 Cc = cv.cout
             elif step[0] == "pool":
-                _, k, s, is_max = step
-                x, H, W = self._pool(x, G, H, W, Cc, k, s, is_max, tag + "_y")
+                _, k, s_, is_max = step
+                Ho, Wo = (H - k) // s_ + 1, (W - k) // s_ + 1
+                y = self._Act(f=self._buf(tag + "_y", (G * Ho * Wo * Cc,)), n=G * Ho * Wo * Cc)
+                _hip.check(lib.mz_pool2d_nhwc(ptr(self._f32(x, tag + "_pin")), G, H, W, Cc, k, s_, 1 if is_max else 0, ptr(y.f),
+                                              _stream()), "mz_pool2d_nhwc")
+                x, H, W = y, Ho, Wo
             else:
                 _, c1, b1, c2, b2, down, dbn, act, pool = step
                 if c1.cin != Cc:
                     raise ValueError(f"block {si} expects {c1.cin} channels, got {Cc}")
-                a, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1")
-                sc1, sh1 = self._stats(a, G, H1 * W1, b1, tag + "_bn1")
-                _hip.check(lib.mz_bn_apply(ptr(a), ptr(sc1), ptr(sh1), None, None, None, act, ptr(a), G, H1 * W1, c1.cout,
-                                           _stream()), "mz_bn_apply")
-                b, H2, W2 = self._conv(a, G, H1, W1, c2, tag + "_c2")
-                sc2, sh2 = self._stats(b, G, H2 * W2, b2, tag + "_bn2")
-                y = self._buf(tag + "_y", (G, H2, W2, c2.cout))
+                raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1")
+                sc1, sh1 = self._stats(raw1.f, G, H1 * W1, b1, tag + "_bn1")
+                a1 = self._apply(raw1.f, sc1, sh1, act, G, H1 * W1, c1.cout, tag + "_a1", split_out=c2.fast)
+                raw2, H2, W2 = self._conv(a1, G, H1, W1, c2, tag + "_c2")
+                sc2, sh2 = self._stats(raw2.f, G, H2 * W2, b2, tag + "_bn2")
+                out_split = split_next and pool is None
                 if down is not None:
                     d, Hd, Wd = self._conv(x, G, H, W, down, tag + "_d")
                     if (Hd, Wd) != (H2, W2):
                         raise ValueError("the skip path and the main path of a residual block disagree in size")
-                    scd, shd = self._stats(d, G, Hd * Wd, dbn, tag + "_bnd")
-                    _hip.check(lib.mz_bn_apply(ptr(b), ptr(sc2), ptr(sh2), ptr(d), ptr(scd), ptr(shd), act, ptr(y), G, H2 * W2,
-                                               c2.cout, _stream()), "mz_bn_apply")
+                    scd, shd = self._stats(d.f, G, Hd * Wd, dbn, tag + "_bnd")
+                    y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=d.f, res_scale=scd,
+                                    res_shift=shd)
                 else:
                     if (H, W, Cc) != (H2, W2, c2.cout):
                         raise ValueError("an identity skip needs equal input and output shapes")
-                    _hip.check(lib.mz_bn_apply(ptr(b), ptr(sc2), ptr(sh2), ptr(x), None, None, act, ptr(y), G, H2 * W2, c2.cout,
-                                               _stream()), "mz_bn_apply")
+                    y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=x)
                 x, H, W, Cc = y, H2, W2, c2.cout
                 if pool is not None:
-                    x, H, W = self._pool(x, G, H, W, Cc, pool[0], pool[1], True, tag + "_p")
+                    k, s_ = pool
+                    Ho, Wo = (H - k) // s_ + 1, (W - k) // s_ + 1
+                    y = self._Act(f=self._buf(tag + "_p", (G * Ho * Wo * Cc,)), n=G * Ho * Wo * Cc)
+                    _hip.check(lib.mz_pool2d_nhwc(ptr(x.f), G, H, W, Cc, k, s_, 1, ptr(y.f), _stream()), "mz_pool2d_nhwc")
+                    x, H, W = y, Ho, Wo
         h, w = self.latent_hw
         out = torch.empty((G, Cc, h, w), dtype=torch.float32, device=self.device)
-        _hip.check(lib.mz_adaptive_avg_to_nchw(ptr(x), G, H, W, Cc, h, w, ptr(out), _stream()), "mz_adaptive_avg_to_nchw")
+        _hip.check(lib.mz_adaptive_avg_to_nchw(ptr(self._f32(x, "last")), G, H, W, Cc, h, w, ptr(out), _stream()),
+                   "mz_adaptive_avg_to_nchw")
         return out

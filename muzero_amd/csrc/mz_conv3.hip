@@ -1,0 +1,289 @@
+// Convolutions of the representation network at the bf16 matrix rate with float32 accuracy (gfx950).
+//
+// The fp32 matrix instruction of gfx950 runs at 1/16 of the bf16 rate.  A float32 value splits
+// exactly into three bf16 terms, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 =
+// bf16(x - x1 - x2): 3 x 8 significant bits), and a product of two such values is, up to terms of
+// relative size 2^-24,
+//     x w = x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1),
+// six bf16 products accumulated in float32 by v_mfma_f32_16x16x32_bf16 -- the accuracy of an fp32
+// product at 16 / 6 = 2.7 times the fp32 matrix rate.  Activations between the layers are kept in
+// this split form (three bf16 planes [rows][C], channels-last), written by the producing kernel, so
+// the nine-fold re-reads of a 3 x 3 convolution's gather cost no conversion work.
+//
+//   k_conv3        implicit-GEMM convolution: 256 output pixels x 128 output channels per workgroup
+//                  (8 waves, 64 x 64 per wave), reduction over (tap, input channel) in steps of 32,
+//                  A rows gathered through the pixel index table of mz_conv_index, both operands
+//                  staged through a double-buffered, XOR-swizzled LDS image (conflict-free b128
+//                  reads), one barrier per step; channel chunks outermost so that the taps of a
+//                  chunk find their pixels in cache
+//   k_split3       float32 rows -> the three planes (weights at pack time, network input)
+//   k_bn_apply3    BatchNorm scale/shift + residual + activation of a ResBlock, reading the raw
+//                  float32 convolution output, writing the split activation of the next layer
+//   k_unsplit3     planes -> float32 (for the few consumers outside this path)
+#include <algorithm>
+
+#include "mz_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+constexpr int kT3 = 512;          // threads: 8 waves
+constexpr int kTM = 256, kTN = 128, kTK = 32;
+constexpr int kARow = 64;         // bytes of one LDS row: 32 bf16
+constexpr int kAStage = 3 * kTM * kARow, kBStage = 3 * kTN * kARow;
+constexpr int kStage = kAStage + kBStage;   // 73,728 bytes; two stages
+
+__device__ __forceinline__ float act3(float v, int act) {
+    switch (act) {
+        case MZ_ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case MZ_ACT_TANH: return tanhf(v);
+        case MZ_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    const __bf16 b = (__bf16)v;  // round to nearest even
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_value(unsigned short b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
+
+// x = p1 + p2 + p3 with every term a bf16 value
+__device__ __forceinline__ void split3(float x, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
+    p1 = bf16_bits(x);
+    const float r1 = x - bf16_value(p1);
+    p2 = bf16_bits(r1);
+    const float r2 = r1 - bf16_value(p2);
+    p3 = bf16_bits(r2);
+}
+
+// byte offset of the 16-byte piece `pc` (8 reduction indices) of row `r` inside one plane image:
+// the piece index is XOR-ed with bits 2..3 of the row so that the 16 rows a b128 read touches
+// (fixed piece, rows r0 .. r0+15) fall into 64 different banks
+__device__ __forceinline__ int lds_off(int r, int pc) { return r * kARow + ((pc ^ ((r >> 2) & 3)) << 4); }
+
+__global__ void __launch_bounds__(kT3)
+k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const int32_t *__restrict__ idx, int taps,
+        const unsigned short *__restrict__ w3, long long w_plane, int K, const float *__restrict__ bias, int act,
+        float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    const int chunks = C / kTK, steps = taps * chunks;
+    // Reduction order: channel chunk outermost, taps innermost -- the taps of one chunk re-read nearly
+    // the same pixels (shifted by a column or a row), so their gathers hit in L1 / L2 instead of
+    // returning to each pixel once per tap with the whole channel sweep in between.
+    // The pixel indices of this workgroup's 256 rows for every tap sit in LDS behind the two stages.
+    int *s_idx = reinterpret_cast<int *>(lds + 2 * kStage);  // [taps][kTM]
+    for (int i = tid; i < taps * kTM; i += kT3) {
+        const int tap = i / kTM, r = m0 + (i - tap * kTM);
+        s_idx[i] = r < rows ? idx[(long long)tap * rows + r] : -1;
+    }
+    __syncthreads();
+
+    // staging roles: A rows ra and ra + 128 (three planes each), B column rb, piece pc
+    const int ra = tid >> 2, pc = tid & 3, rb = tid >> 2;
+    int srow[2];
+    u32x4 ga[6], gb[3];
+    auto fetch = [&](int s) {
+        const int chunk = s / taps, tap = s - chunk * taps, c0 = chunk * kTK + pc * 8;
+        srow[0] = s_idx[tap * kTM + ra];
+        srow[1] = s_idx[tap * kTM + ra + 128];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned short *src = x3 + p * x_plane + (long long)max(srow[h], 0) * C + c0;
+                ga[h * 3 + p] = *reinterpret_cast<const u32x4 *>(src);
+            }
+        const int kk = tap * C + c0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
+    };
+    auto stash = [&](int stage) {
+        unsigned char *base = lds + stage * kStage;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                u32x4 v = ga[h * 3 + p];
+                if (srow[h] < 0) v = u32x4{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4 *>(base + p * (kTM * kARow) + lds_off(ra + 128 * h, pc)) = v;
+            }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(base + kAStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int stage = s & 1;
+        const bool more = s + 1 < steps;
+        if (more) fetch(s + 1);
+        const unsigned char *sa = lds + stage * kStage, *sb = sa + kAStage;
+        bf16x8 a[3][4], b[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[p][t] = *reinterpret_cast<const bf16x8 *>(sa + p * (kTM * kARow) + lds_off(wm * 64 + t * 16 + m, kg));
+                b[p][t] = *reinterpret_cast<const bf16x8 *>(sb + p * (kTN * kARow) + lds_off(wn * 64 + t * 16 + m, kg));
+            }
+        // smallest terms first; consecutive instructions never share an accumulator
+#define MZ_TERM(P, Q)                                                                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0);
+        MZ_TERM(2, 0)
+        MZ_TERM(1, 1)
+        MZ_TERM(0, 2)
+        MZ_TERM(1, 0)
+        MZ_TERM(0, 1)
+        MZ_TERM(0, 0)
+#undef MZ_TERM
+        if (more) stash(stage ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = n0 + wn * 64 + nt * 16 + m;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = m0 + wm * 64 + mt * 16 + kg * 4 + j;
+                if (row >= rows) continue;
+                const float v = act3(acc[mt][nt][j] + bv, act);
+                const long long o = (long long)row * N + col;
+                if (y) y[o] = v;
+                if (y3) {
+                    unsigned short p1, p2, p3;
+                    split3(v, p1, p2, p3);
+                    y3[o] = p1;
+                    y3[y_plane + o] = p2;
+                    y3[2 * y_plane + o] = p3;
+                }
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_split3(const float *__restrict__ x, long long total, unsigned short *__restrict__ out, long long plane) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        unsigned short p1, p2, p3;
+        split3(x[i], p1, p2, p3);
+        out[i] = p1;
+        out[plane + i] = p2;
+        out[2 * plane + i] = p3;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_unsplit3(const unsigned short *__restrict__ x3, long long plane, long long total, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        out[i] = (bf16_value(x3[i]) + bf16_value(x3[plane + i])) + bf16_value(x3[2 * plane + i]);
+}
+
+// y = act(x * scale[g][c] + shift[g][c] + r): r = 0, the split activation res3 (identity skip) or
+// res * rscale + rshift (raw output of the 1x1 skip convolution with its BatchNorm).
+__global__ void __launch_bounds__(256)
+k_bn_apply3(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+            const float *__restrict__ res, const float *__restrict__ rscale, const float *__restrict__ rshift,
+            const unsigned short *__restrict__ res3, long long res_plane, int act, float *__restrict__ y,
+            unsigned short *__restrict__ y3, long long y_plane, long long total, int PC, int C) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i / PC), c = (int)(i % C);
+        const long long o = (long long)g * C + c;
+        float v = x[i] * scale[o] + shift[o];
+        if (res) v += rscale ? (res[i] * rscale[o] + rshift[o]) : res[i];
+        if (res3) v += (bf16_value(res3[i]) + bf16_value(res3[res_plane + i])) + bf16_value(res3[2 * res_plane + i]);
+        v = act3(v, act);
+        if (y) y[i] = v;
+        if (y3) {
+            unsigned short p1, p2, p3;
+            split3(v, p1, p2, p3);
+            y3[i] = p1;
+            y3[y_plane + i] = p2;
+            y3[2 * y_plane + i] = p3;
+        }
+    }
+}
+
+inline int blocks3(long long total) { return (int)std::min<long long>((total + 255) / 256, 1 << 20); }
+
+}  // namespace
+
+extern "C" {
+
+int mz_split3(const float *x, int64_t total, uint16_t *out, int64_t plane_stride, void *stream) {
+    if (!x || !out || total <= 0 || plane_stride < total) return mz::fail(MZ_ERR_ARG, "mz_split3: NULL argument or planes that overlap");
+    hipLaunchKernelGGL(k_split3, dim3(blocks3(total)), dim3(256), 0, (hipStream_t)stream, x, (long long)total, out,
+                       (long long)plane_stride);
+    return mz::check_launch("k_split3");
+}
+
+int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *out, void *stream) {
+    if (!x3 || !out || total <= 0 || plane_stride < total) return mz::fail(MZ_ERR_ARG, "mz_unsplit3: NULL argument or planes that overlap");
+    hipLaunchKernelGGL(k_unsplit3, dim3(blocks3(total)), dim3(256), 0, (hipStream_t)stream, x3, (long long)plane_stride,
+                       (long long)total, out);
+    return mz::check_launch("k_unsplit3");
+}
+
+int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps, const uint16_t *w3,
+                     int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane,
+                     int32_t rows, int32_t N, void *stream) {
+    if (!x3 || !idx || !w3 || (!y && !y3) || rows <= 0 || taps <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: NULL argument or non-positive size");
+    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: input channels (%d) must be a multiple of 64 and output channels (%d) "
+                        "a multiple of %d (other layers use mz_wide_forward_gather / mz_conv_direct_nhwc)", C, N, kTN);
+    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: activation %d is not element-wise", activation);
+    const long long K = (long long)taps * C;
+    if (w_plane < K * N || x_plane <= 0 || (y3 && y_plane < (long long)rows * N) || K > 0x7fffffffLL)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: plane strides too small");
+    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) || (w_plane & 7))
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: operands must be 16-byte aligned");
+    if (taps > 16) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: at most 16 taps (kernel size up to 4)");
+    const size_t lds = 2 * (size_t)kStage + (size_t)taps * kTM * sizeof(int);
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(2 * (size_t)kStage + 16 * kTM * sizeof(int)));
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_conv3: cannot enable %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    }
+    const dim3 grid(N / kTN, (rows + kTM - 1) / kTM);
+    hipLaunchKernelGGL(k_conv3, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, idx, taps, w3,
+                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, rows, N);
+    return mz::check_launch("k_conv3");
+}
+
+int mz_bn_apply3(const float *x, const float *scale, const float *shift, const float *residual, const float *res_scale,
+                 const float *res_shift, const uint16_t *residual3, int64_t res_plane, int32_t activation, float *y,
+                 uint16_t *y3, int64_t y_plane, int32_t G, int32_t P, int32_t C, void *stream) {
+    if (!x || !scale || !shift || (!y && !y3) || G <= 0 || P <= 0 || C <= 0 || (res_scale && (!residual || !res_shift)) ||
+        (residual && residual3))
+        return mz::fail(MZ_ERR_ARG, "mz_bn_apply3: NULL or inconsistent argument");
+    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "mz_bn_apply3: activation %d is not element-wise", activation);
+    const long long total = (long long)G * P * C;
+    if ((y3 && y_plane < total) || (residual3 && res_plane < total)) return mz::fail(MZ_ERR_ARG, "mz_bn_apply3: plane stride too small");
+    hipLaunchKernelGGL(k_bn_apply3, dim3(blocks3(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual,
+                       res_scale, res_shift, residual3, (long long)res_plane, activation, y, y3, (long long)y_plane, total,
+                       P * C, C);
+    return mz::check_launch("k_bn_apply3");
+}
+
+}  // extern "C"

@@ -57,8 +57,9 @@ def _close(got, want, tol=1e-5):
     np.testing.assert_allclose(got.double().cpu().numpy(), want, rtol=tol, atol=tol * float(np.abs(want).max()))
 
 
-@pytest.mark.parametrize("case", ["direct-small", "matrix-64", "mixed-strides", "avgpool-tanh", "pointwise-pooled"])
-def test_conv_representation_matches_torch_per_game(case):
+@pytest.mark.parametrize("fast", [True, False], ids=["split-bf16", "fp32-only"])
+@pytest.mark.parametrize("case", ["direct-small", "matrix-64", "mixed-strides", "avgpool-tanh", "pointwise-pooled", "wide-128"])
+def test_conv_representation_matches_torch_per_game(case, fast):
     from muzero_amd.conv_repr import ConvRepresentation
     if case == "direct-small":      # few channels everywhere: the direct kernel; identity-skip and 1x1-skip blocks
         h = _net((2, 8, 8), (5, 4, 4), 2, [_cv(6, 2, 2, 0), _rb(6), _rb(4)], [_rb(4, k=1, p=0)])
@@ -72,6 +73,10 @@ def test_conv_representation_matches_torch_per_game(case):
     elif case == "avgpool-tanh":    # average pooling layer, sigmoid / tanh activations, non-square-divisible adaptive pool
         h = _net((2, 14, 14), (6, 3, 3), 1, [_cv(8, 3, 1, 1, act="sigmoid"), _pool(2, 2, "avg"), _rb(6, act="tanh")], [])
         G, obs = 4, (2, 14, 14)
+    elif case == "wide-128":        # 128 / 256-channel layers: the split-bf16 product everywhere (3x3, 2x2 stride 2, 1x1 skip, tanh)
+        h = _net((2, 16, 16), (256, 2, 2), 31, [_cv(128, 2, 2, 0), _rb(128), _rb(256, act="tanh"), _cv(256, 3, 1, 1, act="sigmoid"),
+                                                 _rb(256, k=3, s=2, p=1)], [])
+        G, obs = 3, (2, 16, 16)
     else:                           # a point-wise network whose latent is smaller than the observation: 1x1 conv + adaptive pool
         h = _net((2, 6, 7), (4, 3, 3), 1, [], [])
         G, obs = 6, (2, 6, 7)
@@ -80,7 +85,9 @@ def test_conv_representation_matches_torch_per_game(case):
     x = torch.rand(G, obs[0] * K + K, obs[1], obs[2])
     want64, _ = _per_game(h, x, torch.float64)
     want32, _ = _per_game(h, x, torch.float32)
-    run = ConvRepresentation(h)
+    run = ConvRepresentation(h, fast_convolutions=fast)
+    if case == "wide-128":
+        assert any(c.fast for c in run.convs) == fast
     got = run(x.cuda())
     torch.cuda.synchronize()
     assert got.shape == want64.shape
@@ -131,7 +138,8 @@ def _shipped_h():
                 [_rb(3)], seed=3)
 
 
-def test_shipped_representation_network_256_games():
+@pytest.mark.parametrize("fast", [True, False], ids=["split-bf16", "fp32-only"])
+def test_shipped_representation_network_256_games(fast):
     """The shipped CarRacing h (32-frame history of 3x96x96 -> latent [256, 6, 6]) for 256 games in one
     call against the torch module called once per game on the GPU (float32, MIOpen)."""
     from muzero_amd.conv_repr import ConvRepresentation
@@ -140,7 +148,7 @@ def test_shipped_representation_network_256_games():
     gen = torch.Generator(device="cuda").manual_seed(5)
     x = torch.rand(G, 128, 96, 96, device="cuda", generator=gen) * 255.0  # CarRacing frames are 0..255 (car_racing.py:66)
     x[:, 96:] = torch.randint(0, 5, (G, 32, 1, 1), device="cuda", generator=gen).float()  # action planes
-    run = ConvRepresentation(h)
+    run = ConvRepresentation(h, fast_convolutions=fast)
     got = run(x)
     torch.cuda.synchronize()
     want, _ = _per_game(h, x, torch.float32, device="cuda")

@@ -44,15 +44,16 @@ def main():
     ap.add_argument("--games", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--no-torch", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="keep every convolution on the fp32 matrix instruction")
     args = ap.parse_args()
     from muzero_amd.conv_repr import ConvRepresentation
     from muzero_amd.neural_networks.per_call import per_call_statistics
     G = args.games
     h = shipped_h()
     x = torch.rand(G, 128, 96, 96, device="cuda") * 255.0
-    run = ConvRepresentation(h)
+    run = ConvRepresentation(h, fast_convolutions=not args.fp32)
     t_hip = timed(lambda: run(x), args.iters)
-    out = {"games": G, "hip_ms": t_hip * 1e3, "flop_per_game": flops_per_game(),
+    out = {"games": G, "convolutions": "fp32 MFMA" if args.fp32 else "split-bf16 MFMA (6 products)", "hip_ms": t_hip * 1e3, "flop_per_game": flops_per_game(),
            "hip_tflops": flops_per_game() * G / t_hip / 1e12, "fp32_mfma_peak_tflops": 157.3}
     if not args.no_torch:
         import copy
