@@ -43,21 +43,33 @@ const char *mz_last_error(void);
 int mz_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
- * Node pool: G trees x cap nodes, structure-of-arrays.  Node 0 of every tree is its root;
- * an expansion appends A children in action order, so the children of node i are
- * first_child[i] .. first_child[i]+A-1.   Replaces the per-node Python object
- * src/search/nodes.py:7-30 (fields visit_count, value_sum, policy_priority, reward,
- * parent, children, to_play, latent_state).
+ * Node pool: G trees x cap nodes, one 32-byte record per node.  Node 0 of every tree is its
+ * root; an expansion appends A children in action order, so the children of node i are
+ * first_child .. first_child+A-1 and their records are adjacent in memory.   Replaces the
+ * per-node Python object src/search/nodes.py:7-30 (fields visit_count, value_sum,
+ * policy_priority, reward, parent, children, to_play, latent_state).
+ *
+ * The first 16 bytes of a record are all a path update touches (one read-modify-write per
+ * node, src/search/backpropagation.py:15-18); a descent reads both halves of the A adjacent
+ * child records (src/search/selection.py:43-59).
  * ------------------------------------------------------------------------------------ */
+typedef struct mz_node {
+    double value_sum;    /* Node.value_sum                                                  */
+    int32_t visit;       /* Node.visit_count                                                */
+    int32_t link;        /* bits 0..23: parent index, all ones for the root (no parent);    */
+                         /* bits 24..31: Node.to_play as a signed byte                      */
+    double prior;        /* Node.policy_priority                                            */
+    float reward;        /* Node.reward                                                     */
+    int32_t first_child; /* -1 while the node has no children                               */
+} mz_node;
+
+#define MZ_LINK(parent, to_play) ((int32_t)(((uint32_t)(uint8_t)(int8_t)(to_play) << 24) | ((uint32_t)(parent) & 0xFFFFFFu)))
+#define MZ_LINK_PARENT(link) ((int32_t)((uint32_t)(link) << 8) >> 8)
+#define MZ_LINK_TO_PLAY(link) ((int32_t)(link) >> 24)
+
 typedef struct mz_pool {
-    int32_t G, A, cap, D;
-    int32_t *visit;       /* [G][cap]      Node.visit_count                                  */
-    double *value_sum;    /* [G][cap]      Node.value_sum                                    */
-    double *prior;        /* [G][cap]      Node.policy_priority (a float32 value, widened)   */
-    float *reward;        /* [G][cap]      Node.reward                                       */
-    int32_t *parent;      /* [G][cap]      -1 for the root                                   */
-    int32_t *first_child; /* [G][cap]      -1 while the node has no children                 */
-    int8_t *to_play;      /* [G][cap]      Node.to_play                                      */
+    int32_t G, A, cap, D; /* cap <= 2^23 nodes per tree                                      */
+    mz_node *node;        /* [G][cap]      32-byte aligned                                   */
     int32_t *n_nodes;     /* [G]           nodes in use                                      */
     float *latent;        /* [G][cap][D]   Node.latent_state (may be NULL: statistics only)  */
 } mz_pool;

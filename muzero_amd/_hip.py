@@ -23,9 +23,7 @@ class HipError(RuntimeError):
 
 class Pool(C.Structure):
     _fields_ = [("G", C.c_int32), ("A", C.c_int32), ("cap", C.c_int32), ("D", C.c_int32),
-                ("visit", C.c_void_p), ("value_sum", C.c_void_p), ("prior", C.c_void_p),
-                ("reward", C.c_void_p), ("parent", C.c_void_p), ("first_child", C.c_void_p),
-                ("to_play", C.c_void_p), ("n_nodes", C.c_void_p), ("latent", C.c_void_p)]
+                ("node", C.c_void_p), ("n_nodes", C.c_void_p), ("latent", C.c_void_p)]
 
 
 class Dense(C.Structure):

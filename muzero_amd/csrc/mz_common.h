@@ -36,9 +36,9 @@ inline int check_pool(const mz_pool *p, bool need_latent) {
     if (!p) return fail(MZ_ERR_ARG, "pool is NULL");
     if (p->G <= 0 || p->A <= 0 || p->A > 64 || p->cap < 1 + p->A)
         return fail(MZ_ERR_ARG, "bad pool dims G=%d A=%d cap=%d (need G>0, 1<=A<=64, cap>=1+A)", p->G, p->A, p->cap);
-    if (!p->visit || !p->value_sum || !p->prior || !p->reward || !p->parent || !p->first_child || !p->to_play ||
-        !p->n_nodes)
-        return fail(MZ_ERR_ARG, "pool has a NULL statistics array");
+    if (!p->node || !p->n_nodes) return fail(MZ_ERR_ARG, "pool has no node records or node counts");
+    if (((uintptr_t)p->node & 31) != 0) return fail(MZ_ERR_ARG, "pool node records must be 32-byte aligned");
+    if (p->cap > (1 << 23)) return fail(MZ_ERR_ARG, "cap %d exceeds the 2^23 nodes a parent link can name", p->cap);
     if (need_latent && (!p->latent || p->D <= 0)) return fail(MZ_ERR_ARG, "pool has no latent storage (D=%d)", p->D);
     if ((long long)p->G * p->cap > 0x7fffffffLL) return fail(MZ_ERR_ARG, "G*cap exceeds 2^31-1 nodes");
     return MZ_OK;

@@ -276,7 +276,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
             float pr = s_prior[t * A + a];
             if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
             mzt::write_child(p, o, base, a, s_leaf[t], pr, s_rew[t * L.tab_rows + a], (int8_t)s_leaf_tp[t]);
-            if (a == 0) p.first_child[o + s_leaf[t]] = base;
+            if (a == 0) p.node[o + s_leaf[t]].first_child = base;
         }
         MZ_STAMP(9)  // commit
     };
@@ -403,13 +403,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         if (tid < trees) {
             const size_t o = (size_t)(g0 + tid) * p.cap;
             tp = q.root_to_play[g0 + tid];
-            p.visit[o] = 0;
-            p.value_sum[o] = 0.0;
-            p.prior[o] = 0.0;
-            p.reward[o] = 0.0f;
-            p.parent[o] = -1;
-            p.first_child[o] = -1;
-            p.to_play[o] = (int8_t)tp;
+            mzt::write_node(p, o, -1, tp, 0.0, 0.0f);
         }
         s_leaf[tid] = 0;
         s_leaf_tp[tid] = tp;
@@ -533,9 +527,11 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                         const int node = (i == 0) ? s_child[t] : s_path[t * kPathCap + (dl - (i - 1))];
                         const bool same = s_root[t] == 0 || (i >= 1 && ((i - 1) & 1) == 0);
                         const size_t c = o + node;
-                        p.visit[c] += 1;
+                        mzt::NodeStat st = mzt::load_stat(p, c);
+                        st.visit += 1;
                         const double add = same ? ret : -ret;
-                        p.value_sum[c] = p.value_sum[c] + add;
+                        st.value_sum = st.value_sum + add;
+                        mzt::store_stat(p, c, st);
                     }
                 } else if (i == 0) {  // deeper than the recorded path: walk the parent pointers
                     mzt::backup_path(p, o, s_child[t], (int8_t)s_leaf_tp[t], ret);

@@ -1,4 +1,4 @@
-// Tree kernels for gfx950: G independent MCTS trees held as a flat SoA node pool in HBM.
+// Tree kernels for gfx950: G independent MCTS trees held as a flat pool of 32-byte node records in HBM.
 //
 // Work decomposition: each tree is served by a group of LPT = next_pow2(A) adjacent lanes
 // of one wavefront (LPT = 64 -> one wavefront per tree); lane a of the group owns child a
@@ -25,13 +25,7 @@ __global__ void k_init(mz_pool p, const int8_t *__restrict__ root_to_play) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.G) return;
     size_t o = (size_t)g * p.cap;
-    p.visit[o] = 0;
-    p.value_sum[o] = 0.0;
-    p.prior[o] = 0.0;
-    p.reward[o] = 0.0f;
-    p.parent[o] = -1;
-    p.first_child[o] = -1;
-    p.to_play[o] = root_to_play[g];
+    mzt::write_node(p, o, -1, root_to_play[g], 0.0, 0.0f);
     p.n_nodes[g] = 1;
 }
 
@@ -105,14 +99,14 @@ __global__ void k_expand_commit(mz_pool p, const int32_t *__restrict__ leaf, con
     const size_t o = (size_t)g * p.cap;
     const int base = p.n_nodes[g];
     const int lf = leaf[g];
-    const bool ok = lf >= 0 && lf < base && base + p.A <= p.cap && p.first_child[o + lf] < 0;
+    const bool ok = lf >= 0 && lf < base && base + p.A <= p.cap && p.node[o + lf].first_child < 0;
     if (ok && a < p.A)
-        mzt::write_child(p, o, base, a, lf, prior[(size_t)g * p.A + a], reward[(size_t)g * p.A + a], p.to_play[o + lf]);
+        mzt::write_child(p, o, base, a, lf, prior[(size_t)g * p.A + a], reward[(size_t)g * p.A + a], (int8_t)mzt::node_to_play(p, o + lf));
     // every lane of the group has read n_nodes / first_child before lane 0 rewrites them
     __builtin_amdgcn_wave_barrier();
     if (a == 0) {
         if (ok) {
-            p.first_child[o + lf] = base;
+            p.node[o + lf].first_child = base;
             p.n_nodes[g] = base + p.A;
             int rc = rand_child[g];
             out_child[g] = (rc >= 0 && rc < p.A) ? base + rc : -1;
@@ -129,9 +123,9 @@ __global__ void k_root_noise(mz_pool p, const float *__restrict__ eta, double no
     int g = t / p.A, a = t % p.A;
     if (g >= p.G) return;
     size_t o = (size_t)g * p.cap;
-    int fc = p.first_child[o];
+    int fc = p.node[o].first_child;
     if (fc < 0) return;
-    p.prior[o + fc + a] = (double)mzt::noisy_prior(p.prior[o + fc + a], eta[(size_t)g * p.A + a], noise_frac);
+    p.node[o + fc + a].prior = (double)mzt::noisy_prior(p.node[o + fc + a].prior, eta[(size_t)g * p.A + a], noise_frac);
 }
 
 // src/search/backpropagation.py:9-18.  One lane per tree: the path is a pointer chase of
@@ -145,7 +139,7 @@ __global__ void k_backup(mz_pool p, const int32_t *__restrict__ child, const int
     if (node < 0 || lf < 0) return;
     size_t o = (size_t)g * p.cap;
     const double ret = mzt::discounted_return(rollout + (size_t)g * n_rollout, n_rollout, discount);
-    mzt::backup_path(p, o, node, p.to_play[o + lf], ret);
+    mzt::backup_path(p, o, node, (int8_t)mzt::node_to_play(p, o + lf), ret);
 }
 
 // src/search/mcts.py:71-72,97-103.

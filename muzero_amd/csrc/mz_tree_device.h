@@ -20,6 +20,40 @@ __device__ __forceinline__ double dpp_f64(double v) {
 
 __device__ __forceinline__ double max_nan_last(double a, double b) { return b > a ? b : a; }
 
+// The two 16-byte halves of a node record, each moved by one dwordx4 access.
+struct alignas(16) NodeStat {
+    double value_sum;
+    int visit;
+    int link;
+};
+struct alignas(16) NodeEdge {
+    double prior;
+    float reward;
+    int first_child;
+};
+static_assert(sizeof(mz_node) == 32 && sizeof(NodeStat) == 16 && sizeof(NodeEdge) == 16, "node record layout");
+
+__device__ __forceinline__ NodeStat load_stat(const mz_pool &p, size_t c) {
+    return *reinterpret_cast<const NodeStat *>(p.node + c);
+}
+__device__ __forceinline__ void store_stat(const mz_pool &p, size_t c, const NodeStat &s) {
+    *reinterpret_cast<NodeStat *>(p.node + c) = s;
+}
+__device__ __forceinline__ NodeEdge load_edge(const mz_pool &p, size_t c) {
+    return *reinterpret_cast<const NodeEdge *>(reinterpret_cast<const char *>(p.node + c) + 16);
+}
+__device__ __forceinline__ void store_edge(const mz_pool &p, size_t c, const NodeEdge &e) {
+    *reinterpret_cast<NodeEdge *>(reinterpret_cast<char *>(p.node + c) + 16) = e;
+}
+__device__ __forceinline__ int node_first_child(const mz_pool &p, size_t c) { return p.node[c].first_child; }
+__device__ __forceinline__ int node_to_play(const mz_pool &p, size_t c) { return MZ_LINK_TO_PLAY(p.node[c].link); }
+
+// A node without statistics or children (src/search/nodes.py:7-22).
+__device__ __forceinline__ void write_node(const mz_pool &p, size_t c, int parent, int to_play, double prior, float reward) {
+    store_stat(p, c, NodeStat{0.0, 0, MZ_LINK(parent, to_play)});
+    store_edge(p, c, NodeEdge{prior, reward, -1});
+}
+
 // Maximum over the LPT adjacent lanes of a group (LPT a power of two, groups aligned to LPT);
 // every lane of the group receives it.
 template <int LPT>
@@ -57,19 +91,21 @@ __device__ __forceinline__ int select_leaf(const mz_pool &p, size_t o, int a, co
     const int group_lane0 = lane - a;
     const bool child_lane = a < p.A;
     int node = 0, depth = 0;
-    int fc = known_root_fc >= 0 ? known_root_fc : p.first_child[o];
-    int n_parent = known_root_visit >= 0 ? known_root_visit : p.visit[o];
+    int fc = known_root_fc >= 0 ? known_root_fc : p.node[o].first_child;
+    int n_parent = known_root_visit >= 0 ? known_root_visit : p.node[o].visit;
     bool failed = false;
     if (path && a == 0 && path_cap > 0) path[0] = 0;
     while (fc >= 0 && depth < p.cap) {
         int n = 0, cfc = -1;
         double w = 0.0, pr = 0.0;
         if (child_lane) {
-            size_t c = o + fc + a;
-            n = p.visit[c];
-            w = p.value_sum[c];
-            pr = p.prior[c];
-            cfc = p.first_child[c];
+            const size_t c = o + fc + a;
+            const NodeStat st = load_stat(p, c);
+            const NodeEdge ed = load_edge(p, c);
+            n = st.visit;
+            w = st.value_sum;
+            pr = ed.prior;
+            cfc = ed.first_child;
         }
         const bool bad = n_parent >= tab_len || n_parent < 0 || n >= tab_len || n < 0;
         if (group_bits<LPT>(__ballot(bad), group_lane0)) {
@@ -107,14 +143,7 @@ __device__ __forceinline__ int select_leaf(const mz_pool &p, size_t o, int a, co
 // Child record a of an expansion (src/search/expansion.py:30-33, src/search/nodes.py:24-30).
 __device__ __forceinline__ void write_child(const mz_pool &p, size_t o, int base, int a, int leaf, float prior,
                                             float reward, int8_t leaf_to_play) {
-    const size_t c = o + base + a;
-    p.visit[c] = 0;
-    p.value_sum[c] = 0.0;
-    p.prior[c] = (double)prior;
-    p.reward[c] = reward;
-    p.parent[c] = leaf;
-    p.first_child[c] = -1;
-    p.to_play[c] = (int8_t)(-leaf_to_play);
+    write_node(p, o + base + a, leaf, (int8_t)(-leaf_to_play), (double)prior, reward);
 }
 
 // Root prior after the perturbation of src/search/mcts.py:94, all in float32:
@@ -140,10 +169,12 @@ __device__ __forceinline__ double discounted_return(const float *rollout, int n,
 __device__ __forceinline__ void backup_path(const mz_pool &p, size_t o, int node, int8_t leaf_to_play, double ret) {
     for (int steps = 0; node >= 0 && steps < p.cap; ++steps) {
         const size_t c = o + node;
-        p.visit[c] += 1;
-        const double add = (p.to_play[c] == leaf_to_play) ? ret : -ret;
-        p.value_sum[c] = p.value_sum[c] + add;
-        node = p.parent[c];
+        NodeStat st = load_stat(p, c);
+        st.visit += 1;
+        const double add = ((int8_t)MZ_LINK_TO_PLAY(st.link) == leaf_to_play) ? ret : -ret;
+        st.value_sum = st.value_sum + add;
+        store_stat(p, c, st);
+        node = MZ_LINK_PARENT(st.link);
     }
 }
 
@@ -151,16 +182,16 @@ __device__ __forceinline__ void backup_path(const mz_pool &p, size_t o, int node
 __device__ __forceinline__ void tree_result(const mz_pool &p, int g, double *policy, float *policy32, double *value,
                                             int32_t *visits) {
     const size_t o = (size_t)g * p.cap;
-    const int fc = p.first_child[o];
-    if (value) value[g] = p.value_sum[o] / (double)p.visit[o];
+    const int fc = p.node[o].first_child;
+    if (value) value[g] = p.node[o].value_sum / (double)p.node[o].visit;
     if (fc < 0) return;
     double s = 0.0;
-    for (int a = 0; a < p.A; ++a) s = s + exp(p.value_sum[o + fc + a]);
+    for (int a = 0; a < p.A; ++a) s = s + exp(p.node[o + fc + a].value_sum);
     for (int a = 0; a < p.A; ++a) {
-        const double e = exp(p.value_sum[o + fc + a]) / s;
+        const double e = exp(p.node[o + fc + a].value_sum) / s;
         if (policy) policy[(size_t)g * p.A + a] = e;
         if (policy32) policy32[(size_t)g * p.A + a] = (float)e;
-        if (visits) visits[(size_t)g * p.A + a] = p.visit[o + fc + a];
+        if (visits) visits[(size_t)g * p.A + a] = p.node[o + fc + a].visit;
     }
 }
 

@@ -27,7 +27,10 @@ def _stream() -> int:
 
 
 class TreePool:
-    """Device storage of G trees x cap nodes (SoA) and the PUCT lookup tables."""
+    """Device storage of G trees x cap nodes, one 32-byte record per node (include/muzero_hip.h,
+    mz_node), and the PUCT lookup tables.  `visit`, `value_sum`, `prior`, `reward` and `first_child`
+    are strided views of the records (readable and writable in place); `parent` and `to_play` share
+    one word of the record, so they are read as decoded copies and written with set_link."""
 
     def __init__(self, G: int, A: int, num_simulations: int, D: int, device="cuda", with_latent=True,
                  cap: int | None = None):
@@ -35,19 +38,21 @@ class TreePool:
         self.cap = cap or (1 + A + num_simulations * A)
         self.device = torch.device(device)
         dev = self.device
-        n = G * self.cap
-        self.visit = torch.zeros(n, dtype=torch.int32, device=dev).view(G, self.cap)
-        self.value_sum = torch.zeros(n, dtype=torch.float64, device=dev).view(G, self.cap)
-        self.prior = torch.zeros(n, dtype=torch.float64, device=dev).view(G, self.cap)
-        self.reward = torch.zeros(n, dtype=torch.float32, device=dev).view(G, self.cap)
-        self.parent = torch.full((G, self.cap), -1, dtype=torch.int32, device=dev)
-        self.first_child = torch.full((G, self.cap), -1, dtype=torch.int32, device=dev)
-        self.to_play = torch.zeros(n, dtype=torch.int8, device=dev).view(G, self.cap)
+        self.node = torch.zeros((G, self.cap, 8), dtype=torch.int32, device=dev)
+        assert self.node.data_ptr() % 32 == 0
+        as_f64 = self.node.view(torch.float64)   # [G, cap, 4]
+        as_f32 = self.node.view(torch.float32)   # [G, cap, 8]
+        self.value_sum = as_f64[..., 0]
+        self.visit = self.node[..., 2]
+        self.link = self.node[..., 3]
+        self.prior = as_f64[..., 2]
+        self.reward = as_f32[..., 6]
+        self.first_child = self.node[..., 7]
+        self.link.fill_(0xFFFFFF)      # no parent, to_play 0
+        self.first_child.fill_(-1)
         self.n_nodes = torch.zeros(G, dtype=torch.int32, device=dev)
         self.latent = torch.zeros((G, self.cap, D), dtype=torch.float32, device=dev) if with_latent else None
-        self.c = _hip.Pool(G, A, self.cap, D, ptr(self.visit), ptr(self.value_sum), ptr(self.prior),
-                           ptr(self.reward), ptr(self.parent), ptr(self.first_child), ptr(self.to_play),
-                           ptr(self.n_nodes), ptr(self.latent))
+        self.c = _hip.Pool(G, A, self.cap, D, ptr(self.node), ptr(self.n_nodes), ptr(self.latent))
         self.set_table_len(max(num_simulations + 2, 64))
 
     def set_table_len(self, n: int) -> None:
@@ -57,6 +62,27 @@ class TreePool:
         self.tab_len = n
         self.sqrt_tab = torch.from_numpy(sq).to(self.device)
         self.log_tab = torch.from_numpy(lg).to(self.device)
+
+    @property
+    def parent(self) -> torch.Tensor:
+        """i32 [G, cap]: parent index of every node, -1 for a root (a decoded copy)."""
+        return ((self.link & 0xFFFFFF) ^ 0x800000) - 0x800000
+
+    @property
+    def to_play(self) -> torch.Tensor:
+        """i8 [G, cap]: Node.to_play of every node (a decoded copy)."""
+        return (self.link >> 24).to(torch.int8)
+
+    def set_link(self, where, parent=None, to_play=None) -> None:
+        """Writes the parent index and / or to_play of the nodes `where` selects (an index into [G, cap])."""
+        word = self.link[where]
+        if parent is not None:
+            parent = torch.as_tensor(parent, dtype=torch.int32, device=self.device)
+            word = (word & ~0xFFFFFF) | (parent & 0xFFFFFF)
+        if to_play is not None:
+            to_play = torch.as_tensor(to_play, dtype=torch.int32, device=self.device)
+            word = (word & 0xFFFFFF) | (to_play << 24)
+        self.link[where] = word
 
     # ---- thin wrappers over the C ABI -------------------------------------------------
     def init(self, root_to_play: torch.Tensor, root_latent: torch.Tensor | None = None) -> None:

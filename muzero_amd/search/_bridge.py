@@ -43,10 +43,10 @@ def upload(root: Node, device="cuda"):
     pool.visit[0, :n] = torch.tensor([int(nd.visit_count) for nd in order], dtype=torch.int32, device=dev)
     pool.value_sum[0, :n] = torch.tensor([float(nd.value_sum) for nd in order], dtype=torch.float64, device=dev)
     pool.prior[0, :n] = torch.tensor([float(nd.policy_priority) for nd in order], dtype=torch.float64, device=dev)
-    pool.parent[0, :n] = torch.tensor([-1 if nd.parent is None or id(nd.parent) not in index else index[id(nd.parent)]
-                                       for nd in order], dtype=torch.int32, device=dev)
     pool.first_child[0, :n] = torch.tensor([first_child.get(id(nd), -1) for nd in order], dtype=torch.int32, device=dev)
-    pool.to_play[0, :n] = torch.tensor([int(nd.to_play) for nd in order], dtype=torch.int8, device=dev)
+    pool.set_link((0, slice(0, n)),
+                  parent=[-1 if nd.parent is None or id(nd.parent) not in index else index[id(nd.parent)] for nd in order],
+                  to_play=[int(nd.to_play) for nd in order])
     pool.n_nodes[0] = n
     return pool, order, index
 

@@ -21,7 +21,7 @@ class Backpropagation:
         # the kernel takes the sign reference from a node's to_play: park the requested value
         # in the spare slot behind the tree
         spare = len(order)
-        pool.to_play[0, spare] = int(to_play)
+        pool.set_link((0, spare), to_play=int(to_play))
         child = torch.tensor([start], dtype=torch.int32, device=dev)
         ref = torch.tensor([spare], dtype=torch.int32, device=dev)
         rollout = torch.tensor([[float(r) for r in rewards]], dtype=torch.float32, device=dev)

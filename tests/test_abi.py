@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_header():
     assert set(_declared()) <= set(_hip.exported_symbols())
     lib = _hip.lib()
-    assert lib.mz_abi_version() >= 1
+    assert lib.mz_abi_version() == 2  # 2: one 32-byte record per node
 
 
 def test_host_only_entry_points():
@@ -59,7 +59,7 @@ def _search_args(A=7, D=8, G=4, S=5, cap=None, depth=1, tab_len=None):
     dummy = 0x1000
     pool = _hip.Pool()
     pool.G, pool.A, pool.cap, pool.D = G, A, (1 + (S + 1) * A) if cap is None else cap, D
-    for n in ("visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes", "latent"):
+    for n in ("node", "n_nodes", "latent"):
         setattr(pool, n, dummy)
     plan = _hip.PackedNets()
     plan.D, plan.A = D, A

@@ -106,8 +106,8 @@ def test_selection_and_backup_known_answers():
     assert leaf.tolist() == [2, 2, 2] and depth.tolist() == [1, 1, 1]
     # backup: tree 0 single player (all to_play equal), tree 1 two player, tree 2 skipped
     pool.value_sum[:, 1] = 5.0
-    pool.to_play[0, 1:3] = 1
-    pool.to_play[1, 1:3] = 2
+    pool.set_link((0, slice(1, 3)), to_play=1)
+    pool.set_link((1, slice(1, 3)), to_play=2)
     start = torch.tensor([2, 2, -1], **i32)
     pool.backup(start, start.clamp(min=0), torch.full((3, 1), 5.0, dtype=torch.float32, device="cuda"), 1.0)
     torch.cuda.synchronize()
