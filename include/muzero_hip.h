@@ -349,6 +349,11 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  *       table of mz_conv_index (i32[taps][rows]), w3 the split of the k-major weight f32[N][taps*C]
  *       (mz_conv_weight_kmajor), bias f32[N] or NULL; output rows x N as float32 (y) and / or split (y3).
  *       C must be a multiple of 64 and N of 128;
+ *   mz_conv3_same_forward     the same product for stride-1 convolutions with kernel size 1 or 3 and padding
+ *       (k-1)/2 on G images of H x W pixels (ResBlock.conv1 / conv2, network_builder.py:84-120): the
+ *       pixels a tile's taps read are one contiguous range of the flat pixel index, staged in LDS once
+ *       per channel chunk instead of once per tap; needs no index table.  Bit-identical to
+ *       mz_conv3_forward; W is limited to 63 for k = 3;
  *   mz_bn_apply3              mz_bn_apply on a raw float32 convolution output, with the residual either
  *       float32 (`residual`, optionally with the skip path's scale / shift) or split (`residual3`, the
  *       block's own input), writing float32 and / or split. */
@@ -357,6 +362,9 @@ int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *
 int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps,
                      const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y,
                      uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N, void *stream);
+int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W,
+                          int32_t ksize, const uint16_t *w3, int64_t w_plane, const float *bias,
+                          int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N, void *stream);
 int mz_bn_apply3(const float *x, const float *scale, const float *shift, const float *residual,
                  const float *res_scale, const float *res_shift, const uint16_t *residual3, int64_t res_plane,
                  int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t G, int32_t P, int32_t C,

@@ -157,6 +157,8 @@ _SIGS = {
     "mz_unsplit3": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
                                    C.c_int32, C.c_int32, _P]),
+    "mz_conv3_same_forward": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P,
+                                        C.c_int32, _P, _P, C.c_int64, C.c_int32, _P]),
     "mz_bn_apply3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,

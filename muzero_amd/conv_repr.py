@@ -13,6 +13,9 @@ adaptive average pool -- on channels-last activations:
   per float32 product, float32 accumulation; activations stay in that split form between layers);
   other layers with 64-multiple input channels use the fp32 matrix instruction
   (`mz_wide_forward_gather`), the rest (few input channels) the direct kernel.
+  Stride-1 "same" convolutions among them (the ResBlock convolutions) stage the contiguous pixel
+  range a tile's taps read in LDS once per channel chunk (`mz_conv3_same_forward`; `staged_range=False`
+  keeps them on the gathering kernel, whose bits they reproduce).
   `fast_convolutions=False` keeps everything on the fp32 instruction;
 * every BatchNorm2d normalises with the statistics of ONE game, because the reference calls h with
   batch size 1 and never leaves train mode (src/training_data_generator.py:117, main.py:39 only
@@ -95,8 +98,9 @@ class _Bn:
 
 class ConvRepresentation:
     def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False,
-                 fast_convolutions: bool = True):
+                 fast_convolutions: bool = True, staged_range: bool = True):
         self.src = repr_net
+        self.staged_range = staged_range
         self.device = torch.device(device)
         self.track_running_stats = track_running_stats
         self.fast_convolutions = fast_convolutions
@@ -261,11 +265,17 @@ class ConvRepresentation:
         out = self._Act(n=n_out)
         if cv.fast:
             x3 = self._s3(a, name + "_in")
-            idx = self._index_table(G, H, W, cv, Ho, Wo)
             if split_out:
                 out.s = self._buf(name + "_s", (3, n_out), torch.int16)
             else:
                 out.f = self._buf(name, (n_out,))
+            if self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2 and (cv.k == 1 or W <= 63):
+                # the taps of a stride-1 "same" convolution read one contiguous pixel range per tile
+                _hip.check(lib.mz_conv3_same_forward(ptr(x3), a.n, cv.cin, G, H, W, cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
+                                                     cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout, _stream()),
+                           "mz_conv3_same_forward")
+                return out, Ho, Wo
+            idx = self._index_table(G, H, W, cv, Ho, Wo)
             _hip.check(lib.mz_conv3_forward(ptr(x3), a.n, cv.cin, ptr(idx), cv.k * cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
                                             cv.act, ptr(out.f), ptr(out.s), n_out, rows, cv.cout, _stream()), "mz_conv3_forward")
             return out, Ho, Wo

@@ -180,6 +180,152 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
     }
 }
 
+// Stride-1 "same" convolutions (odd kernel, padding (k-1)/2): the input pixels the taps of a tile
+// of 256 consecutive output pixels read form one contiguous range of the flat pixel index,
+// [m0 - reach, m0 + 255 + reach] with reach = pad * (W + 1).  That range (the halo) of one 32-channel
+// chunk is staged in LDS ONCE and the k*k taps of the chunk read their A operands from it through a
+// per-(tap, row) slot table -- a padded tap names a slot of zeros -- instead of gathering every tap's
+// rows from global memory again: the activation traffic into the compute unit drops by ~k*k / 1.4,
+// which is what bounds k_conv3 on these layers.  Same reduction order and instruction sequence as
+// k_conv3, so the two produce identical bits.
+constexpr int kHaloSlots = 384;                       // 256 rows + 2 * 64 pixels of reach
+constexpr int kHaloPlane = (kHaloSlots + 4) * kARow;  // + the slot of zeros (index kHaloSlots)
+constexpr int kHaloBytes = 3 * kHaloPlane;
+constexpr int kHaloLds = kHaloBytes + 2 * kBStage;    // then the slot table u16[taps][256]
+
+__global__ void __launch_bounds__(kT3)
+k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, int H, int W, int ksize,
+             const unsigned short *__restrict__ w3, long long w_plane, int K, const float *__restrict__ bias, int act,
+             float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
+    const int taps = ksize * ksize, pad = (ksize - 1) >> 1, reach = pad * (W + 1);
+    const int chunks = C / kTK, steps = taps * chunks;
+    unsigned char *s_halo = lds, *s_b = lds + kHaloBytes;
+    unsigned short *s_slot = reinterpret_cast<unsigned short *>(lds + kHaloLds);  // [tap][wm][m][t]
+    for (int i = tid; i < taps * kTM; i += kT3) {
+        const int tap = i / kTM, r = i - tap * kTM;
+        const int dy = tap / ksize - pad, dx = tap % ksize - pad;
+        const int row = m0 + r;
+        int slot = kHaloSlots;
+        if (row < rows) {
+            const int w = row % W, h = (row / W) % H;
+            if (h + dy >= 0 && h + dy < H && w + dx >= 0 && w + dx < W) slot = r + reach + dy * W + dx;
+        }
+        s_slot[((tap * 4 + (r >> 6)) * 16 + (r & 15)) * 4 + ((r >> 4) & 3)] = (unsigned short)slot;
+    }
+    if (tid < 12) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + kHaloSlots * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    // staging roles: halo slots hs, hs + 128, hs + 256 (three planes each), B column rb, piece pc
+    const int hs = tid >> 2, pc = tid & 3, rb = tid >> 2;
+    const int nslots = kTM + 2 * reach;
+    u32x4 gh[9], gb[3];
+    auto fetch_halo = [&](int chunk) {
+        const int c0 = chunk * kTK + pc * 8;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int slot = hs + 128 * j;
+            const long long pix = (long long)m0 - reach + slot;
+            const bool ok = slot < nslots && pix >= 0 && pix < rows;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                gh[j * 3 + p] = ok ? *reinterpret_cast<const u32x4 *>(x3 + p * x_plane + pix * C + c0) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stash_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * 3 + p];
+    };
+    auto fetch_b = [&](int s) {
+        const int chunk = s / taps, tap = s - chunk * taps;
+        const int kk = tap * C + chunk * kTK + pc * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
+    };
+    auto stash_b = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(s_b + stage * kBStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch_halo(0);
+    fetch_b(0);
+    stash_halo();
+    stash_b(0);
+    __syncthreads();
+    int s = 0;
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        const bool next_chunk = chunk + 1 < chunks;
+        if (next_chunk) fetch_halo(chunk + 1);  // in flight behind the taps of this chunk
+        for (int tap = 0; tap < taps; ++tap, ++s) {
+            const int stage = s & 1;
+            const bool more = s + 1 < steps;
+            if (more) fetch_b(s + 1);
+            const unsigned char *sb = s_b + stage * kBStage;
+            const uint2 sl = *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4);
+            const int slot[4] = {(int)(sl.x & 0xffff), (int)(sl.x >> 16), (int)(sl.y & 0xffff), (int)(sl.y >> 16)};
+            bf16x8 a[3][4], b[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[p][t] = *reinterpret_cast<const bf16x8 *>(s_halo + p * kHaloPlane + lds_off(slot[t], kg));
+                    b[p][t] = *reinterpret_cast<const bf16x8 *>(sb + p * (kTN * kARow) + lds_off(wn * 64 + t * 16 + m, kg));
+                }
+#define MZ_TERM(P, Q)                                                                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0);
+            MZ_TERM(2, 0)
+            MZ_TERM(1, 1)
+            MZ_TERM(0, 2)
+            MZ_TERM(1, 0)
+            MZ_TERM(0, 1)
+            MZ_TERM(0, 0)
+#undef MZ_TERM
+            if (more) stash_b(stage ^ 1);
+            __syncthreads();
+        }
+        if (next_chunk) {  // every wave has left the old halo behind the barrier above
+            stash_halo();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = n0 + wn * 64 + nt * 16 + m;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = m0 + wm * 64 + mt * 16 + kg * 4 + j;
+                if (row >= rows) continue;
+                const float v = act3(acc[mt][nt][j] + bv, act);
+                const long long o = (long long)row * N + col;
+                if (y) y[o] = v;
+                if (y3) {
+                    unsigned short p1, p2, p3;
+                    split3(v, p1, p2, p3);
+                    y3[o] = p1;
+                    y3[y_plane + o] = p2;
+                    y3[2 * y_plane + o] = p3;
+                }
+            }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_split3(const float *__restrict__ x, long long total, unsigned short *__restrict__ out, long long plane) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -268,6 +414,40 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
     hipLaunchKernelGGL(k_conv3, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, idx, taps, w3,
                        (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, rows, N);
     return mz::check_launch("k_conv3");
+}
+
+int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,
+                          const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
+                          int64_t y_plane, int32_t N, void *stream) {
+    if (!x3 || !w3 || (!y && !y3) || G <= 0 || H <= 0 || W <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: NULL argument or non-positive size");
+    if (ksize < 1 || (ksize & 1) == 0 || ksize > 3)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: kernel size %d (1 or 3; others use mz_conv3_forward)", ksize);
+    const int reach = ((ksize - 1) / 2) * (W + 1);
+    if (kTM + 2 * reach > kHaloSlots)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: image width %d reaches %d pixels, the staged range holds %d "
+                        "(wider images use mz_conv3_forward)", W, reach, (kHaloSlots - kTM) / 2);
+    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: input channels (%d) must be a multiple of 64 and output channels (%d) "
+                        "a multiple of %d", C, N, kTN);
+    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: activation %d is not element-wise", activation);
+    const long long rows = (long long)G * H * W, K = (long long)ksize * ksize * C;
+    if (rows > 0x7fffffffLL - kTM) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: more than 2^31 pixels");
+    if (w_plane < K * N || x_plane < rows * C || (y3 && y_plane < rows * N))
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: plane strides too small");
+    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) || (w_plane & 7))
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: operands must be 16-byte aligned");
+    const size_t lds = (size_t)kHaloLds + (size_t)ksize * ksize * kTM * sizeof(unsigned short);
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3_same), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)kHaloLds + 9 * kTM * sizeof(unsigned short)));
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_conv3_same: cannot enable %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    }
+    const dim3 grid(N / kTN, (unsigned)((rows + kTM - 1) / kTM));
+    hipLaunchKernelGGL(k_conv3_same, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, H, W, ksize, w3,
+                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, (int)rows, N);
+    return mz::check_launch("k_conv3_same");
 }
 
 int mz_bn_apply3(const float *x, const float *scale, const float *shift, const float *residual, const float *res_scale,

@@ -164,3 +164,47 @@ def test_shipped_representation_network_256_games(fast):
     print(f"against float64: ours {ours:.2e}, float32 torch {theirs:.2e}")
     assert ours <= 1e-5 or ours <= 2 * theirs, (ours, theirs)
     assert float(err.max()) <= 1e-5 + 2 * (ours + theirs)
+
+
+def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
+    """mz_conv3_same_forward against mz_conv3_forward on the same operands: both run the same products
+    in the same order, so the outputs are identical bits -- at an image edge, across images, with a
+    ragged last tile, for 3x3 and 1x1 kernels, float32 and split outputs."""
+    import ctypes as C
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for (G, H, W, Cin, N, k) in [(3, 7, 9, 64, 128, 3), (2, 24, 24, 128, 256, 3), (5, 6, 63, 64, 128, 3), (2, 5, 100, 64, 128, 1)]:
+        rows, taps = G * H * W, k * k
+        x = torch.randn(rows * Cin, device="cuda", generator=gen)
+        w = torch.randn(N * taps * Cin, device="cuda", generator=gen) * 0.05
+        bias = torch.randn(N, device="cuda", generator=gen)
+        x3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
+        w3 = torch.empty((3, N * taps * Cin), dtype=torch.int16, device="cuda")
+        _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
+        _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
+        idx = torch.empty((taps, rows), dtype=torch.int32, device="cuda")
+        _hip.check(lib.mz_conv_index(ptr(idx), G, H, W, k, 1, (k - 1) // 2, H, W, None), "mz_conv_index")
+        outs = []
+        for same in (False, True):
+            y = torch.full((rows * N,), float("nan"), device="cuda")
+            y3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
+            if same:
+                _hip.check(lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], ptr(bias), 1,
+                                                     ptr(y), ptr(y3), y3.shape[1], N, None), "mz_conv3_same_forward")
+            else:
+                _hip.check(lib.mz_conv3_forward(ptr(x3), x3.shape[1], Cin, ptr(idx), taps, ptr(w3), w3.shape[1], ptr(bias), 1,
+                                                ptr(y), ptr(y3), y3.shape[1], rows, N, None), "mz_conv3_forward")
+            outs.append((y, y3))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]), (G, H, W, Cin, N, k)
+        assert torch.equal(outs[0][1], outs[1][1]), (G, H, W, Cin, N, k)
+        # and the product is right: float64 convolution of the same operands
+        ref = torch.nn.functional.conv2d(x.view(G, H, W, Cin).permute(0, 3, 1, 2).double().cpu(),
+                                         w.view(N, k, k, Cin).permute(0, 3, 1, 2).double().cpu(), bias.double().cpu(),
+                                         padding=(k - 1) // 2).relu().permute(0, 2, 3, 1).reshape(-1)
+        _close(outs[1][0], ref)
+    # an image too wide for the staged range is refused, not mis-computed
+    assert lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], 64, 1, 4, 64, 3, ptr(w3), w3.shape[1], None, 0, ptr(y), None, 0, 128, None) != 0
+    assert b"width" in lib.mz_last_error()
