@@ -345,6 +345,8 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  * v_mfma_f32_16x16x32_bf16 accumulates in float32 -- 16/6 of the fp32 matrix rate.  Operands are kept
  * in that split form: three bf16 planes (u16 bit patterns), plane p at element offset p * plane_stride.
  *   mz_split3 / mz_unsplit3   float32 <-> planes, element-wise;
+ *   mz_nchw_split3            mz_nchw_to_nhwc and mz_split3 in one pass: the channels-first network input
+ *       f32[G][C][P] (the argument of RepresentationNetwork.forward, neural_network.py:83) -> planes [G * P][C];
  *   mz_conv3_forward          nn.Conv2d as in mz_wide_forward_gather: x3 planes [input pixels][C], idx the
  *       table of mz_conv_index (i32[taps][rows]), w3 the split of the k-major weight f32[N][taps*C]
  *       (mz_conv_weight_kmajor), bias f32[N] or NULL; output rows x N as float32 (y) and / or split (y3).
@@ -354,17 +356,27 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  *       pixels a tile's taps read are one contiguous range of the flat pixel index, staged in LDS once
  *       per channel chunk instead of once per tap; needs no index table.  Bit-identical to
  *       mz_conv3_forward; W is limited to 63 for k = 3;
+ *   block_sums (both convolutions, optional): f64[rows / 64][N][2] receives the sum and the sum of squares
+ *       of every output column over each block of 64 consecutive rows (rows must be a multiple of 64);
+ *       mz_bn_stats_from_sums turns them into the per-game BatchNorm scale / shift (and mean / variance) of
+ *       mz_bn_stats when a game has a multiple of 64 pixels -- the statistics pass over the convolution
+ *       output (nn.BatchNorm2d in train mode, network_builder.py:94,104,118) then costs no read of it;
  *   mz_bn_apply3              mz_bn_apply on a raw float32 convolution output, with the residual either
  *       float32 (`residual`, optionally with the skip path's scale / shift) or split (`residual3`, the
  *       block's own input), writing float32 and / or split. */
 int mz_split3(const float *x, int64_t total, uint16_t *out, int64_t plane_stride, void *stream);
+int mz_nchw_split3(const float *x, int32_t G, int32_t C, int32_t P, uint16_t *out, int64_t plane_stride, void *stream);
 int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *out, void *stream);
 int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps,
                      const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y,
-                     uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N, void *stream);
+                     uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N, double *block_sums, void *stream);
 int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W,
                           int32_t ksize, const uint16_t *w3, int64_t w_plane, const float *bias,
-                          int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N, void *stream);
+                          int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N, double *block_sums,
+                          void *stream);
+int mz_bn_stats_from_sums(const double *block_sums, int32_t G, int32_t P, int32_t C, const float *weight,
+                          const float *bias, float eps, float *scale, float *shift, float *mean, float *var,
+                          void *stream);
 int mz_bn_apply3(const float *x, const float *scale, const float *shift, const float *residual,
                  const float *res_scale, const float *res_shift, const uint16_t *residual3, int64_t res_plane,
                  int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t G, int32_t P, int32_t C,

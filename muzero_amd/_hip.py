@@ -154,11 +154,13 @@ _SIGS = {
                               [_P, _P, _P, _P, _P, _P, _P]),
     "mz_unroll_loss": (C.c_int, [_P] * 7 + [C.c_int32] * 3 + [C.c_float] * 3 + [_P] * 7),
     "mz_split3": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P]),
+    "mz_nchw_split3": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "mz_unsplit3": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
-                                   C.c_int32, C.c_int32, _P]),
+                                   C.c_int32, C.c_int32, _P, _P]),
+    "mz_bn_stats_from_sums": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     "mz_conv3_same_forward": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P,
-                                        C.c_int32, _P, _P, C.c_int64, C.c_int32, _P]),
+                                        C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     "mz_bn_apply3": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, _P]),
     "mz_tower_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,

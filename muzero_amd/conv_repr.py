@@ -19,8 +19,10 @@ adaptive average pool -- on channels-last activations:
   `fast_convolutions=False` keeps everything on the fp32 instruction;
 * every BatchNorm2d normalises with the statistics of ONE game, because the reference calls h with
   batch size 1 and never leaves train mode (src/training_data_generator.py:117, main.py:39 only
-  disables grad): `mz_bn_stats` per (game, channel), `mz_bn_apply` with the residual sum and the
-  activation of the block fused in;
+  disables grad): `mz_bn_stats` per (game, channel) -- or, after a split-bf16 convolution whose games
+  are whole 64-pixel blocks, `mz_bn_stats_from_sums` on the block sums the convolution's epilogue left,
+  without another pass over its output (`fused_statistics=False` keeps the separate pass) --
+  and `mz_bn_apply` with the residual sum and the activation of the block fused in;
 * `track_running_stats=True` also advances the BatchNorm running statistics exactly as those G
   batch-size-1 calls in game order would (`mz_bn_running_update`), and `sync_running_stats()` writes
   them (and num_batches_tracked) back into the caller's module, so that a state_dict saved after
@@ -98,9 +100,10 @@ class _Bn:
 
 class ConvRepresentation:
     def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False,
-                 fast_convolutions: bool = True, staged_range: bool = True):
+                 fast_convolutions: bool = True, staged_range: bool = True, fused_statistics: bool = True):
         self.src = repr_net
         self.staged_range = staged_range
+        self.fused_statistics = fused_statistics
         self.device = torch.device(device)
         self.track_running_stats = track_running_stats
         self.fast_convolutions = fast_convolutions
@@ -236,10 +239,10 @@ class ConvRepresentation:
     # An activation is held as float32 [G, H, W, C] (`f`), as three bf16 planes i16[3, G*H*W*C] (`s`), or
     # both; whichever form a consumer lacks is made on demand.
     class _Act:
-        __slots__ = ("f", "s", "n")
+        __slots__ = ("f", "s", "n", "sums")
 
         def __init__(self, f=None, s=None, n=0):
-            self.f, self.s, self.n = f, s, n
+            self.f, self.s, self.n, self.sums = f, s, n, None
 
     def _f32(self, a, name):
         if a.f is None:
@@ -253,9 +256,11 @@ class ConvRepresentation:
             _hip.check(_hip.lib().mz_split3(ptr(a.f), a.n, ptr(a.s), a.n, _stream()), "mz_split3")
         return a.s
 
-    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False):
+    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False):
         """a: input activation [G, H, W, cin] -> (output activation, Ho, Wo).  The output is float32
-        unless `split_out` and the layer runs on the split-bf16 product (then split only)."""
+        unless `split_out` and the layer runs on the split-bf16 product (then split only).
+        `sums`: where the kernel can, also leave the column sums of every 64-row block in `out.sums`
+        (the BatchNorm statistics that follow then need no pass over the output)."""
         lib = _hip.lib()
         Ho, Wo = cv.out_hw(H, W)
         if Ho <= 0 or Wo <= 0:
@@ -269,15 +274,18 @@ class ConvRepresentation:
                 out.s = self._buf(name + "_s", (3, n_out), torch.int16)
             else:
                 out.f = self._buf(name, (n_out,))
+            if sums and self.fused_statistics and (Ho * Wo) % 64 == 0:
+                out.sums = self._buf(name + "_sums", (rows // 64, cv.cout, 2), torch.float64)
             if self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2 and (cv.k == 1 or W <= 63):
                 # the taps of a stride-1 "same" convolution read one contiguous pixel range per tile
                 _hip.check(lib.mz_conv3_same_forward(ptr(x3), a.n, cv.cin, G, H, W, cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
-                                                     cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout, _stream()),
+                                                     cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout, ptr(out.sums), _stream()),
                            "mz_conv3_same_forward")
                 return out, Ho, Wo
             idx = self._index_table(G, H, W, cv, Ho, Wo)
             _hip.check(lib.mz_conv3_forward(ptr(x3), a.n, cv.cin, ptr(idx), cv.k * cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
-                                            cv.act, ptr(out.f), ptr(out.s), n_out, rows, cv.cout, _stream()), "mz_conv3_forward")
+                                            cv.act, ptr(out.f), ptr(out.s), n_out, rows, cv.cout, ptr(out.sums), _stream()),
+                       "mz_conv3_forward")
             return out, Ho, Wo
         x = self._f32(a, name + "_in")
         out.f = self._buf(name, (n_out,))
@@ -296,14 +304,19 @@ class ConvRepresentation:
                                                cv.pad, cv.act, ptr(out.f), _stream()), "mz_conv_direct_nhwc")
         return out, Ho, Wo
 
-    def _stats(self, x, G, P, b: _Bn, name: str):
+    def _stats(self, raw, G, P, b: _Bn, name: str):
+        """Per-game BatchNorm scale / shift of the raw convolution output `raw` (an _Act with .f)."""
         lib = _hip.lib()
         scale, shift = self._buf(name + "_scale", (G, b.C)), self._buf(name + "_shift", (G, b.C))
         track = self.track_running_stats and b.running_mean is not None
         mean = self._buf(name + "_mean", (G, b.C)) if track else None
         var = self._buf(name + "_var", (G, b.C)) if track else None
-        _hip.check(lib.mz_bn_stats(ptr(x), G, P, b.C, ptr(b.weight), ptr(b.bias), b.eps, ptr(scale), ptr(shift), ptr(mean),
-                                   ptr(var), _stream()), "mz_bn_stats")
+        if raw.sums is not None:
+            _hip.check(lib.mz_bn_stats_from_sums(ptr(raw.sums), G, P, b.C, ptr(b.weight), ptr(b.bias), b.eps, ptr(scale),
+                                                 ptr(shift), ptr(mean), ptr(var), _stream()), "mz_bn_stats_from_sums")
+        else:
+            _hip.check(lib.mz_bn_stats(ptr(raw.f), G, P, b.C, ptr(b.weight), ptr(b.bias), b.eps, ptr(scale), ptr(shift),
+                                       ptr(mean), ptr(var), _stream()), "mz_bn_stats")
         if track:
             _hip.check(lib.mz_bn_running_update(ptr(mean), ptr(var), G, b.C, P, b.momentum, ptr(b.running_mean),
                                                 ptr(b.running_var), _stream()), "mz_bn_running_update")
@@ -348,8 +361,13 @@ class ConvRepresentation:
         lib = _hip.lib()
         G, Cc, H, W = history.shape
         x_in = history.to(self.device, torch.float32).contiguous()
-        x = self._Act(f=self._buf("in_nhwc", (G * H * W * Cc,)), n=G * H * W * Cc)
-        _hip.check(lib.mz_nchw_to_nhwc(ptr(x_in), G, Cc, H * W, ptr(x.f), _stream()), "mz_nchw_to_nhwc")
+        n_in = G * H * W * Cc
+        if self._wants_split(-1) and self.steps[0][0] == "conv":  # the first layer reads the split form only
+            x = self._Act(s=self._buf("in_nhwc_s", (3, n_in), torch.int16), n=n_in)
+            _hip.check(lib.mz_nchw_split3(ptr(x_in), G, Cc, H * W, ptr(x.s), n_in, _stream()), "mz_nchw_split3")
+        else:
+            x = self._Act(f=self._buf("in_nhwc", (n_in,)), n=n_in)
+            _hip.check(lib.mz_nchw_to_nhwc(ptr(x_in), G, Cc, H * W, ptr(x.f), _stream()), "mz_nchw_to_nhwc")
         # activations ping-pong between named buffers; a block's input must survive until its skip sum
         for si, step in enumerate(self.steps):
             tag = f"s{si % 2}"
@@ -371,17 +389,17 @@ class ConvRepresentation:
                 _, c1, b1, c2, b2, down, dbn, act, pool = step
                 if c1.cin != Cc:
                     raise ValueError(f"block {si} expects {c1.cin} channels, got {Cc}")
-                raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1")
-                sc1, sh1 = self._stats(raw1.f, G, H1 * W1, b1, tag + "_bn1")
+                raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1", sums=True)
+                sc1, sh1 = self._stats(raw1, G, H1 * W1, b1, tag + "_bn1")
                 a1 = self._apply(raw1.f, sc1, sh1, act, G, H1 * W1, c1.cout, tag + "_a1", split_out=c2.fast)
-                raw2, H2, W2 = self._conv(a1, G, H1, W1, c2, tag + "_c2")
-                sc2, sh2 = self._stats(raw2.f, G, H2 * W2, b2, tag + "_bn2")
+                raw2, H2, W2 = self._conv(a1, G, H1, W1, c2, tag + "_c2", sums=True)
+                sc2, sh2 = self._stats(raw2, G, H2 * W2, b2, tag + "_bn2")
                 out_split = split_next and pool is None
                 if down is not None:
-                    d, Hd, Wd = self._conv(x, G, H, W, down, tag + "_d")
+                    d, Hd, Wd = self._conv(x, G, H, W, down, tag + "_d", sums=True)
                     if (Hd, Wd) != (H2, W2):
                         raise ValueError("the skip path and the main path of a residual block disagree in size")
-                    scd, shd = self._stats(d.f, G, Hd * Wd, dbn, tag + "_bnd")
+                    scd, shd = self._stats(d, G, Hd * Wd, dbn, tag + "_bnd")
                     y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=d.f, res_scale=scd,
                                     res_shift=shd)
                 else:

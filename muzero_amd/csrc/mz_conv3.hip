@@ -14,7 +14,7 @@
 //                  (8 waves, 64 x 64 per wave), reduction over (tap, input channel) in steps of 32,
 //                  A rows gathered through the pixel index table of mz_conv_index, both operands
 //                  staged through a double-buffered, XOR-swizzled LDS image (conflict-free b128
-//                  reads), one barrier per step; channel chunks outermost so that the taps of a
+//                  reads: see lds_off), one barrier per step; channel chunks outermost so that the taps of a
 //                  chunk find their pixels in cache
 //   k_split3       float32 rows -> the three planes (weights at pack time, network input)
 //   k_bn_apply3    BatchNorm scale/shift + residual + activation of a ResBlock, reading the raw
@@ -60,15 +60,66 @@ __device__ __forceinline__ void split3(float x, unsigned short &p1, unsigned sho
     p3 = bf16_bits(r2);
 }
 
-// byte offset of the 16-byte piece `pc` (8 reduction indices) of row `r` inside one plane image:
-// the piece index is XOR-ed with bits 2..3 of the row so that the 16 rows a b128 read touches
-// (fixed piece, rows r0 .. r0+15) fall into 64 different banks
-__device__ __forceinline__ int lds_off(int r, int pc) { return r * kARow + ((pc ^ ((r >> 2) & 3)) << 4); }
+// byte offset of the 16-byte piece `pc` (8 reduction indices) of row `r` inside one plane image.
+// A ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
+// the same plus 32 -- each of which must touch 16 different 16-byte columns of the 256-byte bank row.
+// With lane = 16 * piece + row, a group reads piece p of rows 0-3 and 12-15 and piece p ^ 1 of rows
+// 4-11; a row is 64 bytes, so rows r, r+4, r+8, r+12 share their columns and XOR-ing bit 1 of the
+// piece with bit 2 of the row separates them -- for any sixteen consecutive rows, wherever they start.
+__device__ __forceinline__ int lds_off(int r, int pc) { return r * kARow + ((pc ^ ((r >> 1) & 2)) << 4); }
+
+// The 64 x 64 output block of one wave (rows row0 .., columns col0 ..; lane (m, kg) holds rows
+// 16 mt + 4 kg + j of columns 16 nt + m): bias, activation, float32 and / or split stores.
+// `sums` (optional, f64[rows / 64][N][2]): the sum and the sum of squares of the stored values of
+// every column over this block's 64 rows, added in a fixed order in float64 -- the per-game BatchNorm
+// statistics are sums of whole blocks when a game's pixel count is a multiple of 64.
+__device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], int row0, int col0, int m, int kg,
+                                               const float *__restrict__ bias, int act, float *__restrict__ y,
+                                               unsigned short *__restrict__ y3, long long y_plane, int rows, int N,
+                                               double *__restrict__ sums) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = col0 + nt * 16 + m;
+        const float bv = bias ? bias[col] : 0.0f;
+        double cs = 0.0, cq = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + mt * 16 + kg * 4 + j;
+                if (row >= rows) continue;
+                const float v = act3(acc[mt][nt][j] + bv, act);
+                const long long o = (long long)row * N + col;
+                if (y) y[o] = v;
+                if (y3) {
+                    unsigned short p1, p2, p3;
+                    split3(v, p1, p2, p3);
+                    y3[o] = p1;
+                    y3[y_plane + o] = p2;
+                    y3[2 * y_plane + o] = p3;
+                }
+                cs += (double)v;
+                cq += (double)v * (double)v;
+            }
+        if (sums) {  // wave-uniform
+            cs += __shfl_xor(cs, 16, 64);
+            cq += __shfl_xor(cq, 16, 64);
+            cs += __shfl_xor(cs, 32, 64);
+            cq += __shfl_xor(cq, 32, 64);
+            if (kg == 0 && row0 < rows) {
+                double *dst = sums + ((long long)(row0 >> 6) * N + col) * 2;
+                dst[0] = cs;
+                dst[1] = cq;
+            }
+        }
+    }
+}
 
 __global__ void __launch_bounds__(kT3)
 k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const int32_t *__restrict__ idx, int taps,
         const unsigned short *__restrict__ w3, long long w_plane, int K, const float *__restrict__ bias, int act,
-        float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N) {
+        float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N,
+        double *__restrict__ sums) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -156,28 +207,7 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
         __syncthreads();
     }
 
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = n0 + wn * 64 + nt * 16 + m;
-        const float bv = bias ? bias[col] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = m0 + wm * 64 + mt * 16 + kg * 4 + j;
-                if (row >= rows) continue;
-                const float v = act3(acc[mt][nt][j] + bv, act);
-                const long long o = (long long)row * N + col;
-                if (y) y[o] = v;
-                if (y3) {
-                    unsigned short p1, p2, p3;
-                    split3(v, p1, p2, p3);
-                    y3[o] = p1;
-                    y3[y_plane + o] = p2;
-                    y3[2 * y_plane + o] = p3;
-                }
-            }
-    }
+    conv3_epilogue(acc, m0 + wm * 64, n0 + wn * 64, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
 }
 
 // Stride-1 "same" convolutions (odd kernel, padding (k-1)/2): the input pixels the taps of a tile
@@ -196,7 +226,8 @@ constexpr int kHaloLds = kHaloBytes + 2 * kBStage;    // then the slot table u16
 __global__ void __launch_bounds__(kT3)
 k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, int H, int W, int ksize,
              const unsigned short *__restrict__ w3, long long w_plane, int K, const float *__restrict__ bias, int act,
-             float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N) {
+             float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N,
+             double *__restrict__ sums) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -302,28 +333,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, in
         }
     }
 
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = n0 + wn * 64 + nt * 16 + m;
-        const float bv = bias ? bias[col] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = m0 + wm * 64 + mt * 16 + kg * 4 + j;
-                if (row >= rows) continue;
-                const float v = act3(acc[mt][nt][j] + bv, act);
-                const long long o = (long long)row * N + col;
-                if (y) y[o] = v;
-                if (y3) {
-                    unsigned short p1, p2, p3;
-                    split3(v, p1, p2, p3);
-                    y3[o] = p1;
-                    y3[y_plane + o] = p2;
-                    y3[2 * y_plane + o] = p3;
-                }
-            }
-    }
+    conv3_epilogue(acc, m0 + wm * 64, n0 + wn * 64, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
 }
 
 __global__ void __launch_bounds__(256)
@@ -334,6 +344,36 @@ k_split3(const float *__restrict__ x, long long total, unsigned short *__restric
         out[i] = p1;
         out[plane + i] = p2;
         out[2 * plane + i] = p3;
+    }
+}
+
+// The network input: [G][C][P] float32 (channels first) -> the three planes [G * P][C] (channels last),
+// transposed through a 64-channel x 32-pixel LDS tile so that reads run along the pixels and writes
+// along the channels.
+__global__ void __launch_bounds__(256)
+k_nchw_split3(const float *__restrict__ x, int C, int P, unsigned short *__restrict__ out, long long plane) {
+    __shared__ float tile[64][33];
+    const long long img = blockIdx.z;
+    const float *src = x + img * (long long)C * P;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 64;
+    {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 pixels x 8 channels per pass
+        for (int j = ty; j < 64; j += 8) {
+            const int c = c0 + j, p = p0 + tx;
+            tile[j][tx] = (c < C && p < P) ? src[(long long)c * P + p] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int tc = threadIdx.x & 63, tp = threadIdx.x >> 6;  // 64 channels x 4 pixels per pass
+    for (int j = tp; j < 32; j += 4) {
+        const int c = c0 + tc, p = p0 + j;
+        if (c >= C || p >= P) continue;
+        unsigned short p1, p2, p3;
+        split3(tile[tc][j], p1, p2, p3);
+        const long long o = (img * P + p) * C + c;
+        out[o] = p1;
+        out[plane + o] = p2;
+        out[2 * plane + o] = p3;
     }
 }
 
@@ -368,6 +408,33 @@ k_bn_apply3(const float *__restrict__ x, const float *__restrict__ scale, const 
     }
 }
 
+// BatchNorm scale / shift of every (game, channel) from the block sums of conv3_epilogue:
+// mean and biased variance over the P pixels of the game (P / 64 consecutive blocks, added in order),
+// folded with the affine parameters exactly as k_bn_stats does.
+__global__ void __launch_bounds__(64)
+k_bn_from_sums(const double *__restrict__ sums, int P, int C, const float *__restrict__ weight, const float *__restrict__ bias,
+               float eps, float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+               float *__restrict__ var_out) {
+    const int g = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const int nb = P >> 6;
+    const double *src = sums + ((long long)g * nb * C + c) * 2;
+    double S = 0.0, Q = 0.0;
+    for (int i = 0; i < nb; ++i) {
+        S += src[(long long)i * C * 2];
+        Q += src[(long long)i * C * 2 + 1];
+    }
+    const double mean = S / P;
+    double var = Q / P - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)weight[c] / sqrt(var + (double)eps);
+    const long long o = (long long)g * C + c;
+    scale[o] = (float)sc;
+    shift[o] = (float)((double)bias[c] - mean * sc);
+    if (mean_out) mean_out[o] = (float)mean;
+    if (var_out) var_out[o] = (float)var;
+}
+
 inline int blocks3(long long total) { return (int)std::min<long long>((total + 255) / 256, 1 << 20); }
 
 }  // namespace
@@ -381,6 +448,15 @@ int mz_split3(const float *x, int64_t total, uint16_t *out, int64_t plane_stride
     return mz::check_launch("k_split3");
 }
 
+int mz_nchw_split3(const float *x, int32_t G, int32_t C, int32_t P, uint16_t *out, int64_t plane_stride, void *stream) {
+    if (!x || !out || G <= 0 || C <= 0 || P <= 0) return mz::fail(MZ_ERR_ARG, "mz_nchw_split3: NULL or non-positive argument");
+    if (plane_stride < (long long)G * C * P) return mz::fail(MZ_ERR_ARG, "mz_nchw_split3: planes overlap");
+    if (G > 65535 || (C + 63) / 64 > 65535) return mz::fail(MZ_ERR_ARG, "mz_nchw_split3: more than 65535 images or channel tiles");
+    hipLaunchKernelGGL(k_nchw_split3, dim3((P + 31) / 32, (C + 63) / 64, G), dim3(256), 0, (hipStream_t)stream, x, C, P, out,
+                       (long long)plane_stride);
+    return mz::check_launch("k_nchw_split3");
+}
+
 int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *out, void *stream) {
     if (!x3 || !out || total <= 0 || plane_stride < total) return mz::fail(MZ_ERR_ARG, "mz_unsplit3: NULL argument or planes that overlap");
     hipLaunchKernelGGL(k_unsplit3, dim3(blocks3(total)), dim3(256), 0, (hipStream_t)stream, x3, (long long)plane_stride,
@@ -390,7 +466,7 @@ int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *
 
 int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps, const uint16_t *w3,
                      int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane,
-                     int32_t rows, int32_t N, void *stream) {
+                     int32_t rows, int32_t N, double *block_sums, void *stream) {
     if (!x3 || !idx || !w3 || (!y && !y3) || rows <= 0 || taps <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: NULL argument or non-positive size");
     if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
@@ -404,6 +480,7 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
     if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) || (w_plane & 7))
         return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: operands must be 16-byte aligned");
     if (taps > 16) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: at most 16 taps (kernel size up to 4)");
+    if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: block sums need a multiple of 64 rows");
     const size_t lds = 2 * (size_t)kStage + (size_t)taps * kTM * sizeof(int);
     {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -412,13 +489,13 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
     }
     const dim3 grid(N / kTN, (rows + kTM - 1) / kTM);
     hipLaunchKernelGGL(k_conv3, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, idx, taps, w3,
-                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, rows, N);
+                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, rows, N, block_sums);
     return mz::check_launch("k_conv3");
 }
 
 int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,
                           const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
-                          int64_t y_plane, int32_t N, void *stream) {
+                          int64_t y_plane, int32_t N, double *block_sums, void *stream) {
     if (!x3 || !w3 || (!y && !y3) || G <= 0 || H <= 0 || W <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: NULL argument or non-positive size");
     if (ksize < 1 || (ksize & 1) == 0 || ksize > 3)
@@ -434,6 +511,7 @@ int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_
         return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: activation %d is not element-wise", activation);
     const long long rows = (long long)G * H * W, K = (long long)ksize * ksize * C;
     if (rows > 0x7fffffffLL - kTM) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: more than 2^31 pixels");
+    if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: block sums need a multiple of 64 rows");
     if (w_plane < K * N || x_plane < rows * C || (y3 && y_plane < rows * N))
         return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: plane strides too small");
     if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) || (w_plane & 7))
@@ -446,8 +524,18 @@ int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_
     }
     const dim3 grid(N / kTN, (unsigned)((rows + kTM - 1) / kTM));
     hipLaunchKernelGGL(k_conv3_same, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, H, W, ksize, w3,
-                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, (int)rows, N);
+                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, (int)rows, N, block_sums);
     return mz::check_launch("k_conv3_same");
+}
+
+int mz_bn_stats_from_sums(const double *block_sums, int32_t G, int32_t P, int32_t C, const float *weight, const float *bias,
+                          float eps, float *scale, float *shift, float *mean, float *var, void *stream) {
+    if (!block_sums || !weight || !bias || !scale || !shift || G <= 0 || P <= 0 || C <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_bn_stats_from_sums: NULL or non-positive argument");
+    if (P % 64 != 0) return mz::fail(MZ_ERR_ARG, "mz_bn_stats_from_sums: %d pixels per game are not whole 64-row blocks (use mz_bn_stats)", P);
+    hipLaunchKernelGGL(k_bn_from_sums, dim3((C + 63) / 64, G), dim3(64), 0, (hipStream_t)stream, block_sums, P, C, weight, bias,
+                       eps, scale, shift, mean, var);
+    return mz::check_launch("k_bn_from_sums");
 }
 
 int mz_bn_apply3(const float *x, const float *scale, const float *shift, const float *residual, const float *res_scale,

@@ -192,10 +192,10 @@ def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
             y3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
             if same:
                 _hip.check(lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], ptr(bias), 1,
-                                                     ptr(y), ptr(y3), y3.shape[1], N, None), "mz_conv3_same_forward")
+                                                     ptr(y), ptr(y3), y3.shape[1], N, None, None), "mz_conv3_same_forward")
             else:
                 _hip.check(lib.mz_conv3_forward(ptr(x3), x3.shape[1], Cin, ptr(idx), taps, ptr(w3), w3.shape[1], ptr(bias), 1,
-                                                ptr(y), ptr(y3), y3.shape[1], rows, N, None), "mz_conv3_forward")
+                                                ptr(y), ptr(y3), y3.shape[1], rows, N, None, None), "mz_conv3_forward")
             outs.append((y, y3))
         torch.cuda.synchronize()
         assert torch.equal(outs[0][0], outs[1][0]), (G, H, W, Cin, N, k)
@@ -206,5 +206,51 @@ def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
                                          padding=(k - 1) // 2).relu().permute(0, 2, 3, 1).reshape(-1)
         _close(outs[1][0], ref)
     # an image too wide for the staged range is refused, not mis-computed
-    assert lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], 64, 1, 4, 64, 3, ptr(w3), w3.shape[1], None, 0, ptr(y), None, 0, 128, None) != 0
+    assert lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], 64, 1, 4, 64, 3, ptr(w3), w3.shape[1], None, 0, ptr(y), None, 0, 128, None, None) != 0
     assert b"width" in lib.mz_last_error()
+
+
+def test_block_sums_give_the_statistics_of_the_separate_pass():
+    """The column sums a convolution's epilogue leaves per 64-row block, turned into per-game BatchNorm
+    scale / shift / mean / variance by mz_bn_stats_from_sums, against mz_bn_stats on the same output
+    (both add in float64; only the order of the additions differs) -- for both convolution kernels."""
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    G, H, W, Cin, N, k = 5, 8, 16, 64, 128, 3   # 128 pixels per game = 2 blocks; 640 rows = 2.5 tiles
+    rows, taps, P = G * H * W, k * k, H * W
+    x = torch.randn(rows * Cin, device="cuda", generator=gen) * 3.0 + 1.0
+    w = torch.randn(N * taps * Cin, device="cuda", generator=gen) * 0.05
+    bias = torch.randn(N, device="cuda", generator=gen)
+    gamma = torch.rand(N, device="cuda", generator=gen) + 0.5
+    beta = torch.randn(N, device="cuda", generator=gen)
+    x3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
+    w3 = torch.empty((3, N * taps * Cin), dtype=torch.int16, device="cuda")
+    _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
+    _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
+    idx = torch.empty((taps, rows), dtype=torch.int32, device="cuda")
+    _hip.check(lib.mz_conv_index(ptr(idx), G, H, W, k, 1, 1, H, W, None), "mz_conv_index")
+    f32 = dict(dtype=torch.float32, device="cuda")
+    for same in (False, True):
+        y = torch.empty(rows * N, **f32)
+        sums = torch.full((rows // 64, N, 2), float("nan"), dtype=torch.float64, device="cuda")
+        if same:
+            _hip.check(lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], ptr(bias), 0,
+                                                 ptr(y), None, 0, N, ptr(sums), None), "mz_conv3_same_forward")
+        else:
+            _hip.check(lib.mz_conv3_forward(ptr(x3), x3.shape[1], Cin, ptr(idx), taps, ptr(w3), w3.shape[1], ptr(bias), 0,
+                                            ptr(y), None, 0, rows, N, ptr(sums), None), "mz_conv3_forward")
+        got = [torch.empty((G, N), **f32) for _ in range(4)]
+        want = [torch.empty((G, N), **f32) for _ in range(4)]
+        _hip.check(lib.mz_bn_stats_from_sums(ptr(sums), G, P, N, ptr(gamma), ptr(beta), 1e-5, *[ptr(t) for t in got], None),
+                   "mz_bn_stats_from_sums")
+        _hip.check(lib.mz_bn_stats(ptr(y), G, P, N, ptr(gamma), ptr(beta), 1e-5, *[ptr(t) for t in want], None), "mz_bn_stats")
+        torch.cuda.synchronize()
+        yb = y.view(rows // 64, 64, N).double()
+        assert torch.allclose(sums[..., 0], yb.sum(1), rtol=1e-12, atol=1e-9)
+        assert torch.allclose(sums[..., 1], (yb * yb).sum(1), rtol=1e-12, atol=1e-9)
+        for a, b, name in zip(got, want, ("scale", "shift", "mean", "var")):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-7, atol=1e-7, err_msg=name)
+    # games that are not whole blocks are refused
+    assert lib.mz_bn_stats_from_sums(ptr(sums), G, 100, N, ptr(gamma), ptr(beta), 1e-5, *[ptr(t) for t in got], None) != 0
