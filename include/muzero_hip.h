@@ -356,7 +356,12 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  *       pixels a tile's taps read are one contiguous range of the flat pixel index, staged in LDS once
  *       per channel chunk instead of once per tap; needs no index table.  Bit-identical to
  *       mz_conv3_forward; W is limited to 63 for k = 3;
- *   block_sums (both convolutions, optional): f64[rows / 64][N][2] receives the sum and the sum of squares
+ *   mz_conv3_same_bn_forward  mz_conv3_same_forward whose input is the raw float32 output x of the previous
+ *       convolution with that layer's per-game BatchNorm scale / shift f32[G][C] and activation: the operand
+ *       in_activation(x * in_scale + in_shift) is formed and split while it is staged (conv2(relu(bn1(.))) of
+ *       a ResBlock, network_builder.py:131-136), bit-identical to mz_bn_apply3 followed by
+ *       mz_conv3_same_forward;
+ *   block_sums (all three convolutions, optional): f64[rows / 64][N][2] receives the sum and the sum of squares
  *       of every output column over each block of 64 consecutive rows (rows must be a multiple of 64);
  *       mz_bn_stats_from_sums turns them into the per-game BatchNorm scale / shift (and mean / variance) of
  *       mz_bn_stats when a game has a multiple of 64 pixels -- the statistics pass over the convolution
@@ -374,6 +379,10 @@ int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_
                           int32_t ksize, const uint16_t *w3, int64_t w_plane, const float *bias,
                           int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N, double *block_sums,
                           void *stream);
+int mz_conv3_same_bn_forward(const float *x, const float *in_scale, const float *in_shift, int32_t in_activation,
+                             int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, const uint16_t *w3,
+                             int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
+                             int64_t y_plane, int32_t N, double *block_sums, void *stream);
 int mz_bn_stats_from_sums(const double *block_sums, int32_t G, int32_t P, int32_t C, const float *weight,
                           const float *bias, float eps, float *scale, float *shift, float *mean, float *var,
                           void *stream);

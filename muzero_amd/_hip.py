@@ -158,6 +158,8 @@ _SIGS = {
     "mz_unsplit3": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
                                    C.c_int32, C.c_int32, _P, _P]),
+    "mz_conv3_same_bn_forward": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                           C.c_int64, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     "mz_bn_stats_from_sums": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     "mz_conv3_same_forward": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P,
                                         C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P]),

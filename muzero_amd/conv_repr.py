@@ -22,7 +22,9 @@ adaptive average pool -- on channels-last activations:
   disables grad): `mz_bn_stats` per (game, channel) -- or, after a split-bf16 convolution whose games
   are whole 64-pixel blocks, `mz_bn_stats_from_sums` on the block sums the convolution's epilogue left,
   without another pass over its output (`fused_statistics=False` keeps the separate pass) --
-  and `mz_bn_apply` with the residual sum and the activation of the block fused in;
+  and `mz_bn_apply` with the residual sum and the activation of the block fused in; inside a block
+  the first BatchNorm and activation are applied by the second convolution while it stages its input
+  (`mz_conv3_same_bn_forward`; `fused_input_bn=False` writes the normalised activation out instead);
 * `track_running_stats=True` also advances the BatchNorm running statistics exactly as those G
   batch-size-1 calls in game order would (`mz_bn_running_update`), and `sync_running_stats()` writes
   them (and num_batches_tracked) back into the caller's module, so that a state_dict saved after
@@ -100,8 +102,10 @@ class _Bn:
 
 class ConvRepresentation:
     def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False,
-                 fast_convolutions: bool = True, staged_range: bool = True, fused_statistics: bool = True):
+                 fast_convolutions: bool = True, staged_range: bool = True, fused_statistics: bool = True,
+                 fused_input_bn: bool = True):
         self.src = repr_net
+        self.fused_input_bn = fused_input_bn
         self.staged_range = staged_range
         self.fused_statistics = fused_statistics
         self.device = torch.device(device)
@@ -256,11 +260,18 @@ class ConvRepresentation:
             _hip.check(_hip.lib().mz_split3(ptr(a.f), a.n, ptr(a.s), a.n, _stream()), "mz_split3")
         return a.s
 
-    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False):
+    def _staged(self, cv: _Conv, W: int) -> bool:
+        """Whether `cv` runs on the kernel that stages a tile's contiguous pixel range (stride-1 "same")."""
+        return (cv.fast and self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2
+                and (cv.k == 1 or W <= 63))
+
+    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False, pre=None):
         """a: input activation [G, H, W, cin] -> (output activation, Ho, Wo).  The output is float32
         unless `split_out` and the layer runs on the split-bf16 product (then split only).
         `sums`: where the kernel can, also leave the column sums of every 64-row block in `out.sums`
-        (the BatchNorm statistics that follow then need no pass over the output)."""
+        (the BatchNorm statistics that follow then need no pass over the output).
+        `pre` = (scale, shift, activation): `a` is the raw float32 output of the previous convolution and
+        the layer reads activation(a * scale + shift) (only for layers `_staged` accepts)."""
         lib = _hip.lib()
         Ho, Wo = cv.out_hw(H, W)
         if Ho <= 0 or Wo <= 0:
@@ -269,14 +280,19 @@ class ConvRepresentation:
         n_out = rows * cv.cout
         out = self._Act(n=n_out)
         if cv.fast:
-            x3 = self._s3(a, name + "_in")
+            x3 = self._s3(a, name + "_in") if pre is None else None
             if split_out:
                 out.s = self._buf(name + "_s", (3, n_out), torch.int16)
             else:
                 out.f = self._buf(name, (n_out,))
             if sums and self.fused_statistics and (Ho * Wo) % 64 == 0:
                 out.sums = self._buf(name + "_sums", (rows // 64, cv.cout, 2), torch.float64)
-            if self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2 and (cv.k == 1 or W <= 63):
+            if pre is not None:
+                _hip.check(lib.mz_conv3_same_bn_forward(ptr(a.f), ptr(pre[0]), ptr(pre[1]), pre[2], cv.cin, G, H, W, cv.k, ptr(cv.w3),
+                                                        cv.w3.shape[1], ptr(cv.bias), cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout,
+                                                        ptr(out.sums), _stream()), "mz_conv3_same_bn_forward")
+                return out, Ho, Wo
+            if self._staged(cv, W):
                 # the taps of a stride-1 "same" convolution read one contiguous pixel range per tile
                 _hip.check(lib.mz_conv3_same_forward(ptr(x3), a.n, cv.cin, G, H, W, cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
                                                      cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout, ptr(out.sums), _stream()),
@@ -391,8 +407,12 @@ class ConvRepresentation:
                     raise ValueError(f"block {si} expects {c1.cin} channels, got {Cc}")
                 raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1", sums=True)
                 sc1, sh1 = self._stats(raw1, G, H1 * W1, b1, tag + "_bn1")
-                a1 = self._apply(raw1.f, sc1, sh1, act, G, H1 * W1, c1.cout, tag + "_a1", split_out=c2.fast)
-                raw2, H2, W2 = self._conv(a1, G, H1, W1, c2, tag + "_c2", sums=True)
+                if self.fused_input_bn and self._staged(c2, W1) and 2 * c1.cout * 4 * min(G, 382 // (H1 * W1) + 2) <= 20 * 1024:
+                    # bn1 and the activation are applied while conv2 stages its input
+                    raw2, H2, W2 = self._conv(raw1, G, H1, W1, c2, tag + "_c2", sums=True, pre=(sc1, sh1, act))
+                else:
+                    a1 = self._apply(raw1.f, sc1, sh1, act, G, H1 * W1, c1.cout, tag + "_a1", split_out=c2.fast)
+                    raw2, H2, W2 = self._conv(a1, G, H1, W1, c2, tag + "_c2", sums=True)
                 sc2, sh2 = self._stats(raw2, G, H2 * W2, b2, tag + "_bn2")
                 out_split = split_next and pool is None
                 if down is not None:

@@ -223,11 +223,18 @@ constexpr int kHaloPlane = (kHaloSlots + 4) * kARow;  // + the slot of zeros (in
 constexpr int kHaloBytes = 3 * kHaloPlane;
 constexpr int kHaloLds = kHaloBytes + 2 * kBStage;    // then the slot table u16[taps][256]
 
+//
+// RAW: the input is the float32 output xf of the previous convolution, and the operand is
+// in_act(xf * in_scale[game][c] + in_shift[game][c]) -- that layer's BatchNorm and activation --
+// formed and split while the range is staged, so the normalised activation is never written to
+// memory.  The scale / shift rows of the few games a range can touch sit in LDS behind the slot table.
+template <bool RAW>
 __global__ void __launch_bounds__(kT3)
-k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, int H, int W, int ksize,
-             const unsigned short *__restrict__ w3, long long w_plane, int K, const float *__restrict__ bias, int act,
-             float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N,
-             double *__restrict__ sums) {
+k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const float *__restrict__ xf,
+             const float *__restrict__ in_scale, const float *__restrict__ in_shift, int in_act, int bn_games, int C, int H,
+             int W, int ksize, const unsigned short *__restrict__ w3, long long w_plane, int K,
+             const float *__restrict__ bias, int act, float *__restrict__ y, unsigned short *__restrict__ y3,
+             long long y_plane, int rows, int N, double *__restrict__ sums) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -253,7 +260,23 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, in
     // staging roles: halo slots hs, hs + 128, hs + 256 (three planes each), B column rb, piece pc
     const int hs = tid >> 2, pc = tid & 3, rb = tid >> 2;
     const int nslots = kTM + 2 * reach;
-    u32x4 gh[9], gb[3];
+    const int P = H * W;
+    // RAW: scale rows then shift rows [bn_games][C] of the games from the one holding the first staged pixel on
+    float *s_bn = reinterpret_cast<float *>(lds + kHaloLds + 16 * kTM * sizeof(unsigned short));
+    const int g_first = max(m0 - reach, 0) / P;
+    int gl[3] = {0, 0, 0};
+    if constexpr (RAW) {
+        const int G = rows / P;
+        for (int i = tid; i < bn_games * C; i += kT3) {
+            const int g = min(g_first + i / C, G - 1), c = i % C;
+            s_bn[i] = in_scale[(long long)g * C + c];
+            s_bn[bn_games * C + i] = in_shift[(long long)g * C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gl[j] = min(max(m0 - reach + hs + 128 * j, 0) / P - g_first, bn_games - 1);
+    }
+    constexpr int kGH = RAW ? 6 : 9;
+    u32x4 gh[kGH], gb[3];
     auto fetch_halo = [&](int chunk) {
         const int c0 = chunk * kTK + pc * 8;
 #pragma unroll
@@ -261,17 +284,51 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, in
             const int slot = hs + 128 * j;
             const long long pix = (long long)m0 - reach + slot;
             const bool ok = slot < nslots && pix >= 0 && pix < rows;
+            if constexpr (RAW) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                gh[j * 3 + p] = ok ? *reinterpret_cast<const u32x4 *>(x3 + p * x_plane + pix * C + c0) : u32x4{0u, 0u, 0u, 0u};
+                for (int q = 0; q < 2; ++q)
+                    gh[j * 2 + q] = ok ? *reinterpret_cast<const u32x4 *>(xf + pix * C + c0 + 4 * q) : u32x4{0u, 0u, 0u, 0u};
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    gh[j * 3 + p] = ok ? *reinterpret_cast<const u32x4 *>(x3 + p * x_plane + pix * C + c0) : u32x4{0u, 0u, 0u, 0u};
+            }
         }
     };
-    auto stash_halo = [&]() {
+    auto stash_halo = [&](int chunk) {
+        if constexpr (RAW) {
+            const int c0 = chunk * kTK + pc * 8;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j) {
+                const int slot = hs + 128 * j;
+                const long long pix = (long long)m0 - reach + slot;
+                const bool ok = slot < nslots && pix >= 0 && pix < rows;
+                const float *sc = s_bn + gl[j] * C + c0, *sh = sc + bn_games * C;
+                unsigned int pl[3][4];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * 3 + p];
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 x4 = __builtin_bit_cast(f32x4, gh[j * 2 + q]);
+                    const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        unsigned short lo[3], hi[3];
+                        split3(act3(fmaf(x4[e], sc4[e], sh4[e]), in_act), lo[0], lo[1], lo[2]);
+                        split3(act3(fmaf(x4[e + 1], sc4[e + 1], sh4[e + 1]), in_act), hi[0], hi[1], hi[2]);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) pl[p][q * 2 + (e >> 1)] = ok ? ((unsigned int)lo[p] | ((unsigned int)hi[p] << 16)) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(slot, pc)) = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * 3 + p];
+        }
     };
     auto fetch_b = [&](int s) {
         const int chunk = s / taps, tap = s - chunk * taps;
@@ -292,7 +349,8 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, in
 
     fetch_halo(0);
     fetch_b(0);
-    stash_halo();
+    if constexpr (RAW) __syncthreads();  // the scale / shift rows are in place
+    stash_halo(0);
     stash_b(0);
     __syncthreads();
     int s = 0;
@@ -328,7 +386,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, int C, in
             __syncthreads();
         }
         if (next_chunk) {  // every wave has left the old halo behind the barrier above
-            stash_halo();
+            stash_halo(chunk + 1);
             __syncthreads();
         }
     }
@@ -393,8 +451,8 @@ k_bn_apply3(const float *__restrict__ x, const float *__restrict__ scale, const 
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int g = (int)(i / PC), c = (int)(i % C);
         const long long o = (long long)g * C + c;
-        float v = x[i] * scale[o] + shift[o];
-        if (res) v += rscale ? (res[i] * rscale[o] + rshift[o]) : res[i];
+        float v = fmaf(x[i], scale[o], shift[o]);  // the same single rounding as the staged form of k_conv3_same
+        if (res) v += rscale ? fmaf(res[i], rscale[o], rshift[o]) : res[i];
         if (res3) v += (bf16_value(res3[i]) + bf16_value(res3[res_plane + i])) + bf16_value(res3[2 * res_plane + i]);
         v = act3(v, act);
         if (y) y[i] = v;
@@ -493,39 +551,69 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
     return mz::check_launch("k_conv3");
 }
 
+static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plane, const float *xf, const float *in_scale,
+                             const float *in_shift, int32_t in_act, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,
+                             const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
+                             int64_t y_plane, int32_t N, double *block_sums, void *stream) {
+    const bool raw = xf != nullptr;
+    if ((!x3 && !xf) || !w3 || (!y && !y3) || G <= 0 || H <= 0 || W <= 0)
+        return mz::fail(MZ_ERR_ARG, "%s: NULL argument or non-positive size", who);
+    if (ksize < 1 || (ksize & 1) == 0 || ksize > 3)
+        return mz::fail(MZ_ERR_ARG, "%s: kernel size %d (1 or 3; others use mz_conv3_forward)", who, ksize);
+    const int reach = ((ksize - 1) / 2) * (W + 1);
+    if (kTM + 2 * reach > kHaloSlots)
+        return mz::fail(MZ_ERR_ARG, "%s: image width %d reaches %d pixels, the staged range holds %d "
+                        "(wider images use mz_conv3_forward)", who, W, reach, (kHaloSlots - kTM) / 2);
+    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
+        return mz::fail(MZ_ERR_ARG, "%s: input channels (%d) must be a multiple of 64 and output channels (%d) "
+                        "a multiple of %d", who, C, N, kTN);
+    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID || (raw && (in_act < MZ_ACT_NONE || in_act > MZ_ACT_SIGMOID)))
+        return mz::fail(MZ_ERR_ARG, "%s: activation is not element-wise", who);
+    const long long rows = (long long)G * H * W, K = (long long)ksize * ksize * C;
+    if (rows > 0x7fffffffLL - kTM) return mz::fail(MZ_ERR_ARG, "%s: more than 2^31 pixels", who);
+    if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "%s: block sums need a multiple of 64 rows", who);
+    if (w_plane < K * N || (!raw && x_plane < rows * C) || (y3 && y_plane < rows * N))
+        return mz::fail(MZ_ERR_ARG, "%s: plane strides too small", who);
+    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) ||
+        (w_plane & 7))
+        return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
+    // games a staged range can touch: it holds 256 + 2 * reach consecutive pixels
+    int bn_games = 0;
+    if (raw) {
+        if (!in_scale || !in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input scale / shift are NULL", who);
+        bn_games = std::min<long long>(G, (kTM + 2 * reach - 2) / ((long long)H * W) + 2);
+    }
+    const size_t lds = (size_t)kHaloLds + 16 * kTM * sizeof(unsigned short) + (size_t)2 * bn_games * C * sizeof(float);
+    if (lds > 160 * 1024)
+        return mz::fail(MZ_ERR_ARG, "%s: the scale / shift rows of %d games x %d channels do not fit beside the staged range "
+                        "(apply the BatchNorm with mz_bn_apply3 first)", who, bn_games, C);
+    auto launch = [&](auto kernel) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "%s: cannot enable %zu bytes of LDS: %s", who, lds, hipGetErrorString(e));
+        const dim3 grid(N / kTN, (unsigned)((rows + kTM - 1) / kTM));
+        hipLaunchKernelGGL(kernel, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, xf, in_scale, in_shift, in_act,
+                           bn_games, C, H, W, ksize, w3, (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane,
+                           (int)rows, N, block_sums);
+        return mz::check_launch("k_conv3_same");
+    };
+    return raw ? launch(k_conv3_same<true>) : launch(k_conv3_same<false>);
+}
+
 int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,
                           const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
                           int64_t y_plane, int32_t N, double *block_sums, void *stream) {
-    if (!x3 || !w3 || (!y && !y3) || G <= 0 || H <= 0 || W <= 0)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: NULL argument or non-positive size");
-    if (ksize < 1 || (ksize & 1) == 0 || ksize > 3)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: kernel size %d (1 or 3; others use mz_conv3_forward)", ksize);
-    const int reach = ((ksize - 1) / 2) * (W + 1);
-    if (kTM + 2 * reach > kHaloSlots)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: image width %d reaches %d pixels, the staged range holds %d "
-                        "(wider images use mz_conv3_forward)", W, reach, (kHaloSlots - kTM) / 2);
-    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: input channels (%d) must be a multiple of 64 and output channels (%d) "
-                        "a multiple of %d", C, N, kTN);
-    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: activation %d is not element-wise", activation);
-    const long long rows = (long long)G * H * W, K = (long long)ksize * ksize * C;
-    if (rows > 0x7fffffffLL - kTM) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: more than 2^31 pixels");
-    if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: block sums need a multiple of 64 rows");
-    if (w_plane < K * N || x_plane < rows * C || (y3 && y_plane < rows * N))
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: plane strides too small");
-    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) || (w_plane & 7))
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: operands must be 16-byte aligned");
-    const size_t lds = (size_t)kHaloLds + (size_t)ksize * ksize * kTM * sizeof(unsigned short);
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3_same), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)((size_t)kHaloLds + 9 * kTM * sizeof(unsigned short)));
-        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_conv3_same: cannot enable %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    }
-    const dim3 grid(N / kTN, (unsigned)((rows + kTM - 1) / kTM));
-    hipLaunchKernelGGL(k_conv3_same, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, H, W, ksize, w3,
-                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, (int)rows, N, block_sums);
-    return mz::check_launch("k_conv3_same");
+    if (!x3) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_forward: x3 is NULL");
+    return conv3_same_launch("mz_conv3_same_forward", x3, x_plane, nullptr, nullptr, nullptr, 0, C, G, H, W, ksize, w3, w_plane, bias,
+                             activation, y, y3, y_plane, N, block_sums, stream);
+}
+
+int mz_conv3_same_bn_forward(const float *x, const float *in_scale, const float *in_shift, int32_t in_activation, int32_t C,
+                             int32_t G, int32_t H, int32_t W, int32_t ksize, const uint16_t *w3, int64_t w_plane,
+                             const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N,
+                             double *block_sums, void *stream) {
+    if (!x) return mz::fail(MZ_ERR_ARG, "mz_conv3_same_bn_forward: x is NULL");
+    return conv3_same_launch("mz_conv3_same_bn_forward", nullptr, 0, x, in_scale, in_shift, in_activation, C, G, H, W, ksize, w3,
+                             w_plane, bias, activation, y, y3, y_plane, N, block_sums, stream);
 }
 
 int mz_bn_stats_from_sums(const double *block_sums, int32_t G, int32_t P, int32_t C, const float *weight, const float *bias,

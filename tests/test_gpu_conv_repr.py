@@ -254,3 +254,23 @@ def test_block_sums_give_the_statistics_of_the_separate_pass():
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-7, atol=1e-7, err_msg=name)
     # games that are not whole blocks are refused
     assert lib.mz_bn_stats_from_sums(ptr(sums), G, 100, N, ptr(gamma), ptr(beta), 1e-5, *[ptr(t) for t in got], None) != 0
+
+
+def test_fused_forms_reproduce_the_separate_kernels_bit_for_bit():
+    """Each fusion switch of ConvRepresentation changes where work is done, not what is computed:
+    BatchNorm + activation applied while the next convolution stages its input, and the staged pixel
+    range itself, give the bits of the separate kernels; statistics from block sums agree to the last
+    float32 digit or two (float64 sums added in another order)."""
+    from muzero_amd.conv_repr import ConvRepresentation
+    h = _net((2, 16, 16), (256, 2, 2), 31, [_cv(128, 2, 2, 0), _rb(128), _rb(256, act="tanh"), _cv(256, 3, 1, 1, act="sigmoid"),
+                                             _rb(256, k=3, s=2, p=1)], [])
+    torch.manual_seed(4)
+    x = torch.rand(5, 2 * 31 + 31, 16, 16).cuda()
+    full = ConvRepresentation(h)(x).clone()
+    no_bn = ConvRepresentation(h, fused_input_bn=False)(x).clone()
+    no_range = ConvRepresentation(h, fused_input_bn=False, staged_range=False)(x).clone()
+    no_sums = ConvRepresentation(h, fused_statistics=False)(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(full, no_bn)
+    assert torch.equal(no_bn, no_range)
+    np.testing.assert_allclose(full.cpu().numpy(), no_sums.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(full.abs().max()))
