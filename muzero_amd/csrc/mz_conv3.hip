@@ -24,6 +24,13 @@
 
 #include "mz_common.h"
 
+// Diagnostic builds (-DMZ_CONV3_SKIP=mask, tools/diag_conv3.sh) leave parts of k_conv3_same out to
+// see what bounds it: 1 matrix instructions, 2 A operand reads, 4 B operand reads, 8 weight staging,
+// 16 restaging of the pixel range after the first chunk.  Results are wrong in those builds.
+#ifndef MZ_CONV3_SKIP
+#define MZ_CONV3_SKIP 0
+#endif
+
 namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -68,38 +75,40 @@ __device__ __forceinline__ void split3(float x, unsigned short &p1, unsigned sho
 // piece with bit 2 of the row separates them -- for any sixteen consecutive rows, wherever they start.
 __device__ __forceinline__ int lds_off(int r, int pc) { return r * kARow + ((pc ^ ((r >> 1) & 2)) << 4); }
 
-// The 64 x 64 output block of one wave (rows row0 .., columns col0 ..; lane (m, kg) holds rows
-// 16 mt + 4 kg + j of columns 16 nt + m): bias, activation, float32 and / or split stores.
+// Output tile of a workgroup (256 rows x 128 columns from row m0, column n0; wave (wm, wn) owns the
+// 64 x 64 block at (64 wm, 64 wn) and its lane (m, kg) holds rows 16 mt + 4 kg + j of columns
+// 16 nt + m): bias, activation, then float32 and / or split stores.  The accumulator layout gives a
+// lane one column of four rows, which would store 64-byte pieces; the tile goes through LDS (free once
+// the reduction is over; `tile` needs kOutLds bytes) and leaves as whole 512-byte rows.
 // `sums` (optional, f64[rows / 64][N][2]): the sum and the sum of squares of the stored values of
-// every column over this block's 64 rows, added in a fixed order in float64 -- the per-game BatchNorm
+// every column over each wave's 64 rows, added in a fixed order in float64 -- the per-game BatchNorm
 // statistics are sums of whole blocks when a game's pixel count is a multiple of 64.
-__device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], int row0, int col0, int m, int kg,
-                                               const float *__restrict__ bias, int act, float *__restrict__ y,
+// Every wave of the workgroup must call it, after a barrier that ends the last use of LDS.
+constexpr int kOutLd = kTN + 4;                    // floats per staged row: 16-byte aligned, rows 4 banks apart
+constexpr int kOutLds = kTM * kOutLd * 4;          // 135,168 bytes
+
+__device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], unsigned char *lds, int m0, int n0, int wm, int wn, int m,
+                                               int kg, const float *__restrict__ bias, int act, float *__restrict__ y,
                                                unsigned short *__restrict__ y3, long long y_plane, int rows, int N,
                                                double *__restrict__ sums) {
+    float *tile = reinterpret_cast<float *>(lds);
+    const int row0 = m0 + wm * 64;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = col0 + nt * 16 + m;
-        const float bv = bias ? bias[col] : 0.0f;
+        const int lc = wn * 64 + nt * 16 + m;
+        const float bv = bias ? bias[n0 + lc] : 0.0f;
         double cs = 0.0, cq = 0.0;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int row = row0 + mt * 16 + kg * 4 + j;
-                if (row >= rows) continue;
+                const int lr = wm * 64 + mt * 16 + kg * 4 + j;
                 const float v = act3(acc[mt][nt][j] + bv, act);
-                const long long o = (long long)row * N + col;
-                if (y) y[o] = v;
-                if (y3) {
-                    unsigned short p1, p2, p3;
-                    split3(v, p1, p2, p3);
-                    y3[o] = p1;
-                    y3[y_plane + o] = p2;
-                    y3[2 * y_plane + o] = p3;
+                tile[lr * kOutLd + lc] = v;
+                if (m0 + lr < rows) {
+                    cs += (double)v;
+                    cq += (double)v * (double)v;
                 }
-                cs += (double)v;
-                cq += (double)v * (double)v;
             }
         if (sums) {  // wave-uniform
             cs += __shfl_xor(cs, 16, 64);
@@ -107,10 +116,29 @@ __device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], int row
             cs += __shfl_xor(cs, 32, 64);
             cq += __shfl_xor(cq, 32, 64);
             if (kg == 0 && row0 < rows) {
-                double *dst = sums + ((long long)(row0 >> 6) * N + col) * 2;
+                double *dst = sums + ((long long)(row0 >> 6) * N + n0 + lc) * 2;
                 dst[0] = cs;
                 dst[1] = cq;
             }
+        }
+    }
+    __syncthreads();
+    // 32 lanes x 4 columns = one row; a wave stores two whole rows per instruction
+    const int c4 = (threadIdx.x & 31) * 4;
+    for (int lr = threadIdx.x >> 5; lr < kTM; lr += kT3 / 32) {
+        const int row = m0 + lr;
+        if (row >= rows) break;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + lr * kOutLd + c4);
+        const long long o = (long long)row * N + n0 + c4;
+        if (y) *reinterpret_cast<f32x4 *>(y + o) = v;
+        if (y3) {
+            unsigned short p[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<uint2 *>(y3 + q * y_plane + o) =
+                    uint2{(unsigned)p[q][0] | ((unsigned)p[q][1] << 16), (unsigned)p[q][2] | ((unsigned)p[q][3] << 16)};
         }
     }
 }
@@ -207,7 +235,7 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
         __syncthreads();
     }
 
-    conv3_epilogue(acc, m0 + wm * 64, n0 + wn * 64, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
+    conv3_epilogue(acc, lds, m0, n0, wm, wn, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
 }
 
 // Stride-1 "same" convolutions (odd kernel, padding (k-1)/2): the input pixels the taps of a tile
@@ -221,7 +249,8 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
 constexpr int kHaloSlots = 384;                       // 256 rows + 2 * 64 pixels of reach
 constexpr int kHaloPlane = (kHaloSlots + 4) * kARow;  // + the slot of zeros (index kHaloSlots)
 constexpr int kHaloBytes = 3 * kHaloPlane;
-constexpr int kHaloLds = kHaloBytes + 2 * kBStage;    // then the slot table u16[taps][256]
+constexpr int kHaloLds = kHaloBytes + 2 * kBStage;    // then the slot table u16[9][256]
+constexpr int kSlotBytes = 9 * kTM * 2;
 
 //
 // RAW: the input is the float32 output xf of the previous convolution, and the operand is
@@ -236,6 +265,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
              const float *__restrict__ bias, int act, float *__restrict__ y, unsigned short *__restrict__ y3,
              long long y_plane, int rows, int N, double *__restrict__ sums) {
     extern __shared__ __align__(16) unsigned char lds[];
+    const long long t_start = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m = lane & 15, kg = lane >> 4;
@@ -244,16 +274,16 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     const int chunks = C / kTK, steps = taps * chunks;
     unsigned char *s_halo = lds, *s_b = lds + kHaloBytes;
     unsigned short *s_slot = reinterpret_cast<unsigned short *>(lds + kHaloLds);  // [tap][wm][m][t]
-    for (int i = tid; i < taps * kTM; i += kT3) {
-        const int tap = i / kTM, r = i - tap * kTM;
-        const int dy = tap / ksize - pad, dx = tap % ksize - pad;
-        const int row = m0 + r;
-        int slot = kHaloSlots;
-        if (row < rows) {
-            const int w = row % W, h = (row / W) % H;
-            if (h + dy >= 0 && h + dy < H && w + dx >= 0 && w + dx < W) slot = r + reach + dy * W + dx;
-        }
-        s_slot[((tap * 4 + (r >> 6)) * 16 + (r & 15)) * 4 + ((r >> 4) & 3)] = (unsigned short)slot;
+    if (tid < kTM) {  // one row per thread: its image coordinates once, then the taps
+        const int r = tid, row = m0 + r;
+        const int w = row % W, h = (row / W) % H;
+        unsigned short *dst = s_slot + ((r >> 6) * 16 + (r & 15)) * 4 + ((r >> 4) & 3);
+        int tap = 0;
+        for (int dy = -pad; dy <= pad; ++dy)
+            for (int dx = -pad; dx <= pad; ++dx, ++tap) {
+                const bool in = row < rows && h + dy >= 0 && h + dy < H && w + dx >= 0 && w + dx < W;
+                dst[tap * (4 * 16 * 4)] = (unsigned short)(in ? r + reach + dy * W + dx : kHaloSlots);
+            }
     }
     if (tid < 12) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + kHaloSlots * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
 
@@ -262,7 +292,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     const int nslots = kTM + 2 * reach;
     const int P = H * W;
     // RAW: scale rows then shift rows [bn_games][C] of the games from the one holding the first staged pixel on
-    float *s_bn = reinterpret_cast<float *>(lds + kHaloLds + 16 * kTM * sizeof(unsigned short));
+    float *s_bn = reinterpret_cast<float *>(lds + kHaloLds + kSlotBytes);
     const int g_first = max(m0 - reach, 0) / P;
     int gl[3] = {0, 0, 0};
     if constexpr (RAW) {
@@ -353,45 +383,88 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     stash_halo(0);
     stash_b(0);
     __syncthreads();
+    // Operand reads and matrix instructions of a step are issued in three waves so that the products of
+    // one pair of planes run while the next pair is still on its way from LDS (the fences keep the
+    // compiler from gathering all 24 reads in front of the first product): smallest terms first.
+    const long long t_loop = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto slots_of = [&](int tap) { return *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4); };
+    uint2 sl = slots_of(0);
     int s = 0;
     for (int chunk = 0; chunk < chunks; ++chunk) {
         const bool next_chunk = chunk + 1 < chunks;
-        if (next_chunk) fetch_halo(chunk + 1);  // in flight behind the taps of this chunk
+        if (next_chunk && !(MZ_CONV3_SKIP & 16)) fetch_halo(chunk + 1);  // in flight behind the taps of this chunk
         for (int tap = 0; tap < taps; ++tap, ++s) {
             const int stage = s & 1;
             const bool more = s + 1 < steps;
-            if (more) fetch_b(s + 1);
+            if (more && !(MZ_CONV3_SKIP & 8)) fetch_b(s + 1);
             const unsigned char *sb = s_b + stage * kBStage;
-            const uint2 sl = *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4);
-            const int slot[4] = {(int)(sl.x & 0xffff), (int)(sl.x >> 16), (int)(sl.y & 0xffff), (int)(sl.y >> 16)};
-            bf16x8 a[3][4], b[3][4];
+            int ao[4], bo[4];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int t = 0; t < 4; ++t) {
+                const int slot = (int)((t < 2 ? sl.x : sl.y) >> (16 * (t & 1))) & 0xffff;
+                ao[t] = lds_off(slot, kg);
+                bo[t] = lds_off(wn * 64 + t * 16 + m, kg);
+            }
+            sl = slots_of(tap + 1 < taps ? tap + 1 : 0);  // the next step's slots, a step ahead of their use
+            bf16x8 a[3][4], b[3][4];
+            auto read_a = [&](int p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    a[p][t] = *reinterpret_cast<const bf16x8 *>(s_halo + p * kHaloPlane + lds_off(slot[t], kg));
-                    b[p][t] = *reinterpret_cast<const bf16x8 *>(sb + p * (kTN * kARow) + lds_off(wn * 64 + t * 16 + m, kg));
+                    if (!(MZ_CONV3_SKIP & 2)) a[p][t] = *reinterpret_cast<const bf16x8 *>(s_halo + p * kHaloPlane + ao[t]);
+                    else a[p][t] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)ao[t], 1u, 2u, 3u});
                 }
+            };
+            auto read_b = [&](int p) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (!(MZ_CONV3_SKIP & 4)) b[p][t] = *reinterpret_cast<const bf16x8 *>(sb + p * (kTN * kARow) + bo[t]);
+                    else b[p][t] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)(s + t), 1u, 2u, 3u});
+                }
+            };
 #define MZ_TERM(P, Q)                                                                                        \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0);
+        if (!(MZ_CONV3_SKIP & 1)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0); \
+        else asm volatile("" ::"v"(a[P][mt]), "v"(b[Q][nt]));
+            read_a(2);
+            read_b(0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(1);
+            read_b(1);
+            __builtin_amdgcn_sched_barrier(0);
             MZ_TERM(2, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(0);
+            read_b(2);
+            __builtin_amdgcn_sched_barrier(0);
             MZ_TERM(1, 1)
+            __builtin_amdgcn_sched_barrier(0);
             MZ_TERM(0, 2)
             MZ_TERM(1, 0)
             MZ_TERM(0, 1)
             MZ_TERM(0, 0)
 #undef MZ_TERM
-            if (more) stash_b(stage ^ 1);
+            if (more && !(MZ_CONV3_SKIP & 8)) stash_b(stage ^ 1);
             __syncthreads();
         }
-        if (next_chunk) {  // every wave has left the old halo behind the barrier above
+        if (next_chunk && !(MZ_CONV3_SKIP & 16)) {  // every wave has left the old range behind the barrier above
             stash_halo(chunk + 1);
             __syncthreads();
         }
     }
 
-    conv3_epilogue(acc, m0 + wm * 64, n0 + wn * 64, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
+    const long long t_epi = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    conv3_epilogue(acc, lds, m0, n0, wm, wn, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
+    if ((MZ_CONV3_SKIP & 32) && y) {  // diagnostic: cycles of the three parts, per wave, over the first outputs of the tile
+        __builtin_amdgcn_s_waitcnt(0);
+        const long long t_end = (long long)__builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            float *dst = y + (long long)m0 * N + n0 + wave * 4;
+            dst[0] = (float)(t_loop - t_start);
+            dst[1] = (float)(t_epi - t_loop);
+            dst[2] = (float)(t_end - t_epi);
+            dst[3] = (float)(t_start & 0xffffff);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -535,7 +608,8 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
     const long long K = (long long)taps * C;
     if (w_plane < K * N || x_plane <= 0 || (y3 && y_plane < (long long)rows * N) || K > 0x7fffffffLL)
         return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: plane strides too small");
-    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) || (w_plane & 7))
+    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3) | reinterpret_cast<uintptr_t>(y) |
+         reinterpret_cast<uintptr_t>(y3)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
         return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: operands must be 16-byte aligned");
     if (taps > 16) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: at most 16 taps (kernel size up to 4)");
     if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: block sums need a multiple of 64 rows");
@@ -574,8 +648,8 @@ static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plan
     if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "%s: block sums need a multiple of 64 rows", who);
     if (w_plane < K * N || (!raw && x_plane < rows * C) || (y3 && y_plane < rows * N))
         return mz::fail(MZ_ERR_ARG, "%s: plane strides too small", who);
-    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(w3)) & 15 || (x_plane & 7) ||
-        (w_plane & 7))
+    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(w3) |
+         reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y3)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
         return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
     // games a staged range can touch: it holds 256 + 2 * reach consecutive pixels
     int bn_games = 0;
@@ -583,7 +657,7 @@ static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plan
         if (!in_scale || !in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input scale / shift are NULL", who);
         bn_games = std::min<long long>(G, (kTM + 2 * reach - 2) / ((long long)H * W) + 2);
     }
-    const size_t lds = (size_t)kHaloLds + 16 * kTM * sizeof(unsigned short) + (size_t)2 * bn_games * C * sizeof(float);
+    const size_t lds = std::max<size_t>((size_t)kHaloLds + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float), kOutLds);
     if (lds > 160 * 1024)
         return mz::fail(MZ_ERR_ARG, "%s: the scale / shift rows of %d games x %d channels do not fit beside the staged range "
                         "(apply the BatchNorm with mz_bn_apply3 first)", who, bn_games, C);
