@@ -360,7 +360,8 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  *       convolution with that layer's per-game BatchNorm scale / shift f32[G][C] and activation: the operand
  *       in_activation(x * in_scale + in_shift) is formed and split while it is staged (conv2(relu(bn1(.))) of
  *       a ResBlock, network_builder.py:131-136), bit-identical to mz_bn_apply3 followed by
- *       mz_conv3_same_forward;
+ *       mz_conv3_same_forward.  in_scale = in_shift = NULL: the operand is x itself, split while staged (a
+ *       float32 activation needs no split copy in memory);
  *   block_sums (all three convolutions, optional): f64[rows / 64][N][2] receives the sum and the sum of squares
  *       of every output column over each block of 64 consecutive rows (rows must be a multiple of 64);
  *       mz_bn_stats_from_sums turns them into the per-game BatchNorm scale / shift (and mean / variance) of

@@ -280,6 +280,8 @@ class ConvRepresentation:
         n_out = rows * cv.cout
         out = self._Act(n=n_out)
         if cv.fast:
+            if pre is None and a.s is None and self._staged(cv, W):
+                pre = (None, None, 0)   # a float32 activation is split while it is staged
             x3 = self._s3(a, name + "_in") if pre is None else None
             if split_out:
                 out.s = self._buf(name + "_s", (3, n_out), torch.int16)
@@ -366,11 +368,10 @@ class ConvRepresentation:
         if si + 1 >= len(self.steps):
             return False
         nxt = self.steps[si + 1]
-        if nxt[0] == "conv":
-            return nxt[1].fast
-        if nxt[0] == "block":
-            return nxt[1].fast
-        return False
+        first = nxt[1] if nxt[0] in ("conv", "block") else None
+        # the staged-range kernel splits a float32 activation on the fly; the gathering one reads planes
+        return first is not None and first.fast and not (self.staged_range and first.stride == 1 and first.k in (1, 3)
+                                                         and first.pad == (first.k - 1) // 2)
 
     def __call__(self, history: torch.Tensor) -> torch.Tensor:
         """history f32[G, C*K+K, H, W] (the tensor of mz_history_push_assemble) -> latent f32[G, c, h, w]."""

@@ -297,7 +297,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     int gl[3] = {0, 0, 0};
     if constexpr (RAW) {
         const int G = rows / P;
-        for (int i = tid; i < bn_games * C; i += kT3) {
+        for (int i = tid; in_scale && i < bn_games * C; i += kT3) {
             const int g = min(g_first + i / C, G - 1), c = i % C;
             s_bn[i] = in_scale[(long long)g * C + c];
             s_bn[bn_games * C + i] = in_shift[(long long)g * C + c];
@@ -338,12 +338,17 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 x4 = __builtin_bit_cast(f32x4, gh[j * 2 + q]);
-                    const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
+                    f32x4 v4 = x4;
+                    if (in_scale) {  // uniform
+                        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v4[e] = act3(fmaf(x4[e], sc4[e], sh4[e]), in_act);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
                         unsigned short lo[3], hi[3];
-                        split3(act3(fmaf(x4[e], sc4[e], sh4[e]), in_act), lo[0], lo[1], lo[2]);
-                        split3(act3(fmaf(x4[e + 1], sc4[e + 1], sh4[e + 1]), in_act), hi[0], hi[1], hi[2]);
+                        split3(v4[e], lo[0], lo[1], lo[2]);
+                        split3(v4[e + 1], hi[0], hi[1], hi[2]);
 #pragma unroll
                         for (int p = 0; p < 3; ++p) pl[p][q * 2 + (e >> 1)] = ok ? ((unsigned int)lo[p] | ((unsigned int)hi[p] << 16)) : 0u;
                     }
@@ -653,8 +658,8 @@ static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plan
         return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
     // games a staged range can touch: it holds 256 + 2 * reach consecutive pixels
     int bn_games = 0;
-    if (raw) {
-        if (!in_scale || !in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input scale / shift are NULL", who);
+    if (raw && in_scale) {
+        if (!in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input shift is NULL", who);
         bn_games = std::min<long long>(G, (kTM + 2 * reach - 2) / ((long long)H * W) + 2);
     }
     const size_t lds = std::max<size_t>((size_t)kHaloLds + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float), kOutLds);
