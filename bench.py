@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 A, D = 7, 168
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
 
@@ -268,9 +269,13 @@ def representation_time(G, dev, iters=3):
     s = time_kernel(lambda: run(x), iters=iters)
     del run, x
     torch.cuda.empty_cache()
-    return {"games": G, "ms_per_move": s * 1e3, "tflops": flops_per_game() * G / s / 1e12,
-            "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-            "kernel": "convolutions as gathered fp32 MFMA products (k_wide, segmented gather), per-game BatchNorm"}
+    tf = flops_per_game() * G / s / 1e12
+    return {"games": G, "ms_per_move": s * 1e3, "tflops": tf, "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            # every float32 product is six bf16 products on the matrix cores (whole network, small layers included)
+            "bf16_executed_tflops": 6 * tf, "bf16_mfma_peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+            "bf16_executed_frac": 6 * tf / BF16_MFMA_PEAK_TFLOPS,
+            "kernel": "convolutions as split-bf16 matrix products with float32 accuracy (k_conv3_same / k_conv3), "
+                      "per-game BatchNorm statistics from the convolution epilogue"}
 
 
 def main():
