@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int kRT = 256;
+constexpr int kChunk = 2048;  // doubles staged per pass of the sequential sums
 
 // One workgroup.  priority f64[n]; probs / cdf f64[n] are outputs that double as scratch.
 // u f64[B] -> draw i32[B], weight f64[B] = (n P(draw))^-beta / max over the draw.
@@ -32,25 +33,49 @@ k_per_sample(const double *__restrict__ priority, int n, double alpha, double be
     __shared__ int s_idx[kRT];
     __shared__ double s_total;
     __shared__ int s_longest;
+    // The two left-to-right sums (Python's sum() and numpy's cumsum) are chains of dependent additions:
+    // one lane runs them, over chunks that all lanes stage in LDS first, so that the chain waits for
+    // the adder only and never for global memory.
+    __shared__ double s_chunk[kChunk];
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += kRT) probs[i] = pow(priority[i], alpha);
     __syncthreads();
-    if (tid == 0) {
+    {
         double total = 0.0;
-        for (int i = 0; i < n; ++i) total = total + probs[i];
-        s_total = total;
+        for (int c0 = 0; c0 < n; c0 += kChunk) {
+            const int len = min(kChunk, n - c0);
+            for (int i = tid; i < len; i += kRT) s_chunk[i] = probs[c0 + i];
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll 8
+                for (int i = 0; i < len; ++i) total = total + s_chunk[i];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_total = total;
     }
     __syncthreads();
     const double total = s_total;
     for (int i = tid; i < n; i += kRT) probs[i] = total < 1e-8 ? 1.0 / (double)n : probs[i] / total;
     __syncthreads();
-    if (tid == 0) {
+    {
         double run = 0.0;
-        for (int i = 0; i < n; ++i) {
-            run = run + probs[i];
-            cdf[i] = run;
+        for (int c0 = 0; c0 < n; c0 += kChunk) {
+            const int len = min(kChunk, n - c0);
+            for (int i = tid; i < len; i += kRT) s_chunk[i] = probs[c0 + i];
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll 8
+                for (int i = 0; i < len; ++i) {
+                    run = run + s_chunk[i];
+                    s_chunk[i] = run;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < len; i += kRT) cdf[c0 + i] = s_chunk[i];
+            __syncthreads();
         }
-        s_total = run;
+        if (tid == 0) s_total = run;
     }
     __syncthreads();
     const double last = s_total;
