@@ -572,7 +572,8 @@ typedef struct mz_tower {
  * with the mean and biased variance of ONE network call (src/search/expansion.py:25-28 calls g
  * with the A children of a node as one batch; every other call has batch size 1).  Here
  * consecutive groups of `group` rows form one such call (B must be a multiple of `group`);
- * running statistics are not updated (nothing on the search path reads them).
+ * running statistics are not updated (nothing on the search path reads them; mz_tower_forward_stats exports
+ * what an update needs).
  * Input: x_r = x[x_rows[r]] (gather optional); with row_add != NULL the fc_merge split is
  * applied while loading, x_r = relu(x[x_rows[r]] + row_add[row_sel[r]]) (row_sel NULL: r % group).
  * y_rows NULL: row r; negative entries are skipped.
@@ -585,6 +586,20 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
                      const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
                      int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B,
                      int32_t group, void *stream);
+
+/* mz_tower_forward that also exports every BatchNorm2d's batch statistics, so that a caller can apply
+ * the side effect the reference's train-mode calls have on running_mean / running_var
+ * (network_builder.py:94,104,118): bn_stats receives, for block b in order and for each of its three
+ * BatchNorm layers (bn1, bn2, the skip path's; the last left untouched for an identity skip),
+ * mean f32[calls][out_channels] followed by the biased variance f32[calls][out_channels], calls = B / group
+ * in row order -- mz_tower_stats_floats(tower, calls) floats in all.  mz_bn_running_update on a layer's two
+ * arrays (G = calls, P = group * H * W) advances its buffers as `calls` consecutive reference calls would.
+ * bn_stats NULL: mz_tower_forward. */
+int64_t mz_tower_stats_floats(const mz_tower *h_tower, int32_t calls);
+int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
+                           const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
+                           int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B,
+                           int32_t group, float *bn_stats, void *stream);
 
 /* table[a][:] = fc_merge.weight[:, D:] @ action_embedding[a] + fc_merge.bias for a < A
  * (f32[A][D]): the per-action half of fc_merge, neural_network.py:168-172. */

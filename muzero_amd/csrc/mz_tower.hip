@@ -375,14 +375,17 @@ __device__ __forceinline__ double wave_total(double v) {
 // variance, accumulated in double as torch's CPU kernels do), then the activation.  One wave per
 // channel; a second buffer (the skip path), if given, is normalised by other waves at the same
 // time.  gamma/beta come from LDS (lg/lb, fetched earlier) when given, else from global memory.
+// `stat` (optional): the layer's batch statistics go to global memory, mean f32[calls][C] then
+// biased variance f32[calls][C], call = call0 + segment -- what a running-statistics update needs.
 struct BnJob {
     lds_f *buf;
     const float *gamma, *beta;
     const lds_f *lg, *lb;
     float eps;
     int act;
+    float *stat;
 };
-__device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P, int seg) {
+__device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P, int seg, int call0 = 0, int calls = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg = P / seg, per_buf = C * nseg;  // a workgroup may hold several calls: one segment each
     const int jobs = j1.buf ? 2 * per_buf : per_buf;
@@ -410,6 +413,10 @@ __device__ void bn_act(const BnJob &j0, const BnJob &j1, int C, int P, int seg) 
         const double be = J.lb ? (double)J.lb[c] : (double)as_constant(J.beta)[c];
         const float scale = (float)(ga * invstd);
         const float shift = (float)(be - mean * ga * invstd);
+        if (J.stat != nullptr && lane == 0) {
+            J.stat[(long long)(call0 + sg) * C + c] = (float)mean;
+            J.stat[(long long)(calls + call0 + sg) * C + c] = (float)var;
+        }
         for (int p = lane; p < seg; p += 64) v[p] = activate(v[p] * scale + shift, J.act);
     }
 }
@@ -548,7 +555,8 @@ __device__ __forceinline__ void
 tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, long long ldx,
            const int32_t *__restrict__ x_rows, const float *__restrict__ row_add, long long ld_add,
            const int32_t *__restrict__ row_sel, float *__restrict__ y, long long ldy,
-           const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group) {
+           const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group,
+           float *__restrict__ stats, int calls) {
     extern __shared__ __align__(16) float smem[];
     lds_f *S = to_lds(smem);
     lds_f *cur = S + G.off_a, *mid = S + G.off_b, *aux = S + G.off_c, *red = S + G.off_red, *stage = S + G.off_stage;
@@ -674,6 +682,7 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
     };
 
     MZ_TT(0)
+    long long stat_off = 0;
     for (int b = 0; b < T.n_blocks; ++b) {
         const mz_resblock &R = T.block[b];
         const int Cin = R.in_channels, Cout = R.out_channels, k = R.kernel_size;
@@ -880,9 +889,14 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
         if (small && tid < npar) par[tid] = pv;
         __syncthreads();
         MZ_TT(4)
-        bn_act(BnJob{mid, R.bn1_w, R.bn1_b, pg, pg ? pg + Cout : nullptr, R.eps1, R.activation},
+        // statistics of block b: bn1, bn2, the skip path's BatchNorm -- 2 * calls * Cout floats each
+        float *st1 = stats ? stats + stat_off : nullptr;
+        float *st2 = stats ? st1 + 2LL * calls * Cout : nullptr, *std_ = stats ? st1 + 4LL * calls * Cout : nullptr;
+        const int call0 = blockIdx.x * (P / G.seg);
+        stat_off += 6LL * calls * Cout;
+        bn_act(BnJob{mid, R.bn1_w, R.bn1_b, pg, pg ? pg + Cout : nullptr, R.eps1, R.activation, st1},
                BnJob{down ? aux : nullptr, R.dbn_w, R.dbn_b, pg ? pg + 4 * Cout : nullptr,
-                     pg ? pg + 5 * Cout : nullptr, R.epsd, MZ_ACT_NONE}, Cout, P, G.seg);
+                     pg ? pg + 5 * Cout : nullptr, R.epsd, MZ_ACT_NONE, std_}, Cout, P, G.seg, call0, calls);
         __syncthreads();
         MZ_TT(5)
         // ---- conv2: mid -> dst.  `cur` is free unless it still holds the identity skip.
@@ -925,8 +939,8 @@ tower_body(const mz_tower &T, const TowerGeom &G, const float *__restrict__ x, l
         __syncthreads();
         MZ_TT(6)
         bn_act(BnJob{dst, R.bn2_w, R.bn2_b, pg ? pg + 2 * Cout : nullptr, pg ? pg + 3 * Cout : nullptr, R.eps2,
-                     MZ_ACT_NONE},
-               BnJob{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, MZ_ACT_NONE}, Cout, P, G.seg);
+                     MZ_ACT_NONE, st2},
+               BnJob{nullptr, nullptr, nullptr, nullptr, nullptr, 0.0f, MZ_ACT_NONE, nullptr}, Cout, P, G.seg, call0, calls);
         __syncthreads();
         MZ_TT(7)
         // ---- skip connection + activation -> cur (input of the next block)
@@ -1014,15 +1028,16 @@ __global__ void __launch_bounds__(kTT)
 k_tower(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
         const float *__restrict__ row_add, long long ld_add, const int32_t *__restrict__ row_sel,
         float *__restrict__ y, long long ldy, const int32_t *__restrict__ y_rows, float *__restrict__ t_out,
-        long long ld_t, int group) {
-    tower_body<4>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
+        long long ld_t, int group, float *__restrict__ stats, int calls) {
+    tower_body<4>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group, stats, calls);
 }
 __global__ void __launch_bounds__(kTT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long ldx,
                const int32_t *__restrict__ x_rows, const float *__restrict__ row_add, long long ld_add,
                const int32_t *__restrict__ row_sel, float *__restrict__ y, long long ldy,
-               const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group) {
-    tower_body<2>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group);
+               const int32_t *__restrict__ y_rows, float *__restrict__ t_out, long long ld_t, int group,
+               float *__restrict__ stats, int calls) {
+    tower_body<2>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group, stats, calls);
 }
 
 int tower_geometry(const mz_tower *T, int group, int ng, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
@@ -1277,10 +1292,25 @@ int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, con
     return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, scratch, need, stream);
 }
 
+int64_t mz_tower_stats_floats(const mz_tower *h_tower, int32_t calls) {
+    if (!h_tower || calls <= 0 || h_tower->n_blocks < 0 || h_tower->n_blocks > MZ_MAX_BLOCKS) return 0;
+    int64_t n = 0;
+    for (int b = 0; b < h_tower->n_blocks; ++b) n += 6LL * calls * h_tower->block[b].out_channels;
+    return n;
+}
+
 int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
                      const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
                      int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B, int32_t group,
                      void *stream) {
+    return mz_tower_forward_stats(h_tower, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, B, group,
+                                  nullptr, stream);
+}
+
+int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx, const int32_t *x_rows,
+                           const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
+                           int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B, int32_t group,
+                           float *bn_stats, void *stream) {
     TowerGeom g;
     size_t lds = 0;
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -1326,7 +1356,7 @@ int mz_tower_forward(const mz_tower *h_tower, const float *x, int64_t ldx, const
         MZ_TRY(allow_lds(kernel, lds, name));
         hipLaunchKernelGGL(kernel, dim3(wgs), dim3(kTT), lds, (hipStream_t)stream, *h_tower, g, x,
                            (long long)ldx, x_rows, row_add, (long long)ld_add, row_sel, y, (long long)ldy, y_rows,
-                           t_out, (long long)ld_t, rows_per_wg);
+                           t_out, (long long)ld_t, rows_per_wg, bn_stats, B / group);
         return mz::check_launch(name);
     };
     return packed ? launch(k_tower_packed, "k_tower_packed") : launch(k_tower, "k_tower");

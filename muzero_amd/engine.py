@@ -209,16 +209,17 @@ class PackedNetworks:
             ptr(value), ptr(argmax), B, _stream()), "mz_prediction_forward")
 
 
-def make_networks(dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda"):
+def make_networks(dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", track_running_stats: bool = False):
     """Device evaluator for a (g, f) pair: `PackedNetworks` (fused kernels, single-launch search)
     for `res_net: []` configurations, `muzero_amd.towers.TowerNetworks` when either network has
-    residual blocks or a res_final convolution."""
+    residual blocks or a res_final convolution (`track_running_stats`: its BatchNorm layers' running
+    statistics advance with every call as in the reference; the MLP networks have none)."""
     plain = (len(dynamics.res_blocks) == 0 and len(prediction.res_blocks) == 0 and
              isinstance(dynamics.res_final, torch.nn.Identity) and isinstance(prediction.res_final, torch.nn.Identity))
     if plain:
         return PackedNetworks(dynamics, prediction, device=device)
     from muzero_amd.towers import TowerNetworks
-    return TowerNetworks(dynamics, prediction, device=device)
+    return TowerNetworks(dynamics, prediction, device=device, track_running_stats=track_running_stats)
 
 
 @dataclass

@@ -120,7 +120,7 @@ def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_act
 
 class SelfPlayEngine:
     def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0,
-                 device_rng: bool = False, env=None):
+                 device_rng: bool = False, env=None, track_running_stats: bool = False):
         """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps).
         `env`: a batched environment (`observe`, `step`, `reset(mask)`, `num_actions`,
         `observation_space`); default: G Connect-Four games on the GPU.  Host-side simulators go
@@ -129,7 +129,11 @@ class SelfPlayEngine:
         The search consumes no random numbers itself: the Dirichlet noise, the child draws and the
         exploration decisions of a move are inputs.  By default they come from a numpy generator on
         the host (reproducible against a CPU replay); `device_rng=True` draws them on the GPU with
-        torch's generator instead, which keeps the whole move on the device."""
+        torch's generator instead, which keeps the whole move on the device.
+
+        `track_running_stats`: the BatchNorm running statistics of h, g and f advance with every network
+        call as the reference's train-mode calls make them (no output depends on them);
+        `sync_running_stats()` writes them back into the three modules."""
         self.G, self.cfg = G, config
         self.device = torch.device(device)
         m = config.mcts
@@ -138,8 +142,8 @@ class SelfPlayEngine:
         self.env = env if env is not None else BatchedConnectFour(G, device=device)
         assert getattr(self.env, "G", G) == G, "the environment batch must hold G games"
         self.A = self.env.num_actions
-        self.h = RepresentationRunner(repr_net, device=device)
-        self.nets = make_networks(dyn_net, pred_net, device=device)
+        self.h = RepresentationRunner(repr_net, device=device, track_running_stats=track_running_stats)
+        self.nets = make_networks(dyn_net, pred_net, device=device, track_running_stats=track_running_stats)
         self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
                                 device=device, keep_latents=False)  # nothing here reads the children's latents
         self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
@@ -157,6 +161,12 @@ class SelfPlayEngine:
         self.step_in_episode = torch.zeros(G, dtype=torch.int32, device=dev)
         self.action = torch.zeros(G, dtype=torch.int32, device=dev)
         self.env.reset()
+
+    def sync_running_stats(self) -> None:
+        """With track_running_stats: the advanced BatchNorm buffers of h, g and f go back into the modules."""
+        self.h.sync_running_stats()
+        if hasattr(self.nets, "sync_running_stats"):
+            self.nets.sync_running_stats()
 
     def epsilon(self, training_steps: int) -> float:
         c = self.cfg

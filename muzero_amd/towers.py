@@ -68,8 +68,18 @@ class TowerNetworks:
     concurrent = True   # f and the fc_merge product of g may run on two streams (scratch is per stream)
     strided_outputs = True  # reward / value may be 1-D views with a stride (a column of a [G, n] buffer)
 
-    def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096):
+    def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096,
+                 track_running_stats: bool = False):
+        """track_running_stats: every tower call also advances the BatchNorm running statistics of its
+        blocks as the reference's train-mode calls do (network_builder.py:94,104,118), one update per
+        reference call, the calls of one launch in row order (with one tree that is the reference's
+        order; with G trees in lock step the trees' calls interleave).  `sync_running_stats()` writes
+        the buffers and num_batches_tracked back into the modules.  No output depends on them."""
         self.device = torch.device(device)
+        self.track_running_stats = track_running_stats
+        self._running: dict = {}   # id(tower struct) -> [(bn module, running_mean, running_var)] per block x 3
+        self._calls: dict = {}     # id(tower struct) -> device counter of reference calls since the last sync
+        self._mean_shift: dict = {}  # id(tower struct) -> {layer: constant missing from the exported batch mean}
         self.dynamics_net, self.prediction_net = dynamics, prediction
         c, h, w = dynamics.latent_shape
         self.shape = (c, h, w)
@@ -133,6 +143,10 @@ class TowerNetworks:
 
     def refresh(self) -> None:
         """Re-reads the modules' weights (call after a weight update)."""
+        if self.track_running_stats and self._running:
+            # the modules' buffers are the one copy self-play and training share: hand ours over, re-read theirs
+            self.sync_running_stats()
+            self._running, self._calls, self._mean_shift = {}, {}, {}
         self._keep = []
         self.version = getattr(self, "version", 0) + 1  # captured launch graphs hold the old buffers' addresses
         lib = _hip.lib()
@@ -140,6 +154,8 @@ class TowerNetworks:
         D, A = self.D, self.A
         self.tower_g = self._tower(list(g.res_blocks), g.res_final)
         self.tower_f = self._tower(list(f.res_blocks), f.res_final)
+        self._track(self.tower_g, list(g.res_blocks))
+        self._track(self.tower_f, list(f.res_blocks))
         # plan every packed piece into one blob
         plans = []  # (kind, dense-or-mlp, plan)
         off = 0
@@ -255,6 +271,11 @@ class TowerNetworks:
             b0.conv1_bias = ptr(self._dev(bias_map.to(torch.float32)))
             b0.down_w = ptr(self._dev(wd.to(torch.float32)))
             self.tower_f_t = t
+            self._running[id(t)] = self._running.get(id(self.tower_f))  # the same blocks, pre-multiplied weights
+            self._calls[id(t)] = self._calls.get(id(self.tower_f))
+            # ... but it is part of that layer's batch mean (layer 2 of block 0: the skip path's BatchNorm)
+            wdf = blk0.downsample[0].weight.detach().to(self.device, torch.float64).reshape(-1, c)
+            self._mean_shift[id(t)] = {2: (wdf @ bf).to(torch.float32).contiguous()}
         if self.blob is None or self.blob.numel() != off:
             self.blob = torch.empty(off, dtype=torch.float32, device=self.device)
         for kind, src, pl in plans:
@@ -314,11 +335,77 @@ class TowerNetworks:
                        "mz_policy_post")
         return out
 
+    def _track(self, tower, blocks) -> None:
+        """Device copies of the running statistics of a tower's BatchNorm layers (bn1, bn2, skip)."""
+        if not self.track_running_stats:
+            return
+        layers = []
+        for blk in blocks:
+            for bn in (blk.bn1, blk.bn2, blk.downsample[1] if blk.downsample is not None else None):
+                if bn is None or not bn.track_running_stats or bn.running_mean is None:
+                    layers.append(None)
+                    continue
+                layers.append((bn, bn.running_mean.detach().to(self.device, torch.float32).clone(),
+                               bn.running_var.detach().to(self.device, torch.float32).clone()))
+        self._running[id(tower)] = layers
+        # counted on the device, so that launches replayed from a recorded graph count as well
+        self._calls[id(tower)] = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def sync_running_stats(self) -> None:
+        """Writes the advanced running statistics and call counts back into the torch modules."""
+        seen, counters = set(), {}
+        for key, layers in self._running.items():
+            cnt = self._calls.get(key)
+            for e in layers or ():
+                if e is None:
+                    continue
+                counters.setdefault(id(e[0]), {})[id(cnt)] = cnt  # towers sharing blocks share the counter
+                if id(e[0]) in seen:
+                    continue
+                seen.add(id(e[0]))
+                bn, rm, rv = e
+                with torch.no_grad():
+                    bn.running_mean.copy_(rm.to(bn.running_mean.device))
+                    bn.running_var.copy_(rv.to(bn.running_var.device))
+        for key, layers in self._running.items():
+            for e in layers or ():
+                if e is not None and id(e[0]) in counters:
+                    n = sum(int(c.item()) for c in counters.pop(id(e[0])).values())
+                    if e[0].num_batches_tracked is not None:
+                        with torch.no_grad():
+                            e[0].num_batches_tracked += n
+        for c in {id(c): c for c in self._calls.values() if c is not None}.values():
+            c.zero_()
+
     def _tower_call(self, tower, x, ldx, x_rows, row_add, row_sel, y, ldy, y_rows, B, group, t_out=None) -> None:
-        _hip.check(_hip.lib().mz_tower_forward(C.byref(tower), ptr(x), ldx, ptr(x_rows), ptr(row_add), self.D,
-                                               ptr(row_sel), ptr(y), ldy, ptr(y_rows), ptr(t_out),
-                                               t_out.shape[-1] if t_out is not None else 0, B, group, _stream()),
+        lib = _hip.lib()
+        layers = self._running.get(id(tower)) if self.track_running_stats else None
+        stats = None
+        if layers and B > 0:
+            calls = B // group
+            stats = self._buf(("bn_stats", id(tower), torch.cuda.current_stream().cuda_stream),
+                              (lib.mz_tower_stats_floats(C.byref(tower), calls),))
+        _hip.check(lib.mz_tower_forward_stats(C.byref(tower), ptr(x), ldx, ptr(x_rows), ptr(row_add), self.D,
+                                              ptr(row_sel), ptr(y), ldy, ptr(y_rows), ptr(t_out),
+                                              t_out.shape[-1] if t_out is not None else 0, B, group, ptr(stats), _stream()),
                    "mz_tower_forward")
+        if stats is None:
+            return
+        off, hw = 0, self.shape[1] * self.shape[2]
+        for b in range(tower.n_blocks):
+            c = tower.block[b].out_channels
+            for j in range(3):
+                e = layers[3 * b + j]
+                if e is not None:
+                    bn, rm, rv = e
+                    mean, var = stats[off:off + calls * c], stats[off + calls * c:off + 2 * calls * c]
+                    shift = self._mean_shift.get(id(tower), {}).get(3 * b + j)
+                    if shift is not None:
+                        mean.view(calls, c).add_(shift)
+                    _hip.check(lib.mz_bn_running_update(ptr(mean), ptr(var), calls, c, group * hw, float(bn.momentum),
+                                                        ptr(rm), ptr(rv), _stream()), "mz_bn_running_update")
+                off += 2 * calls * c
+        self._calls[id(tower)].add_(calls)
 
     def _mlp_on(self, plan, name: str, x, ldx, x_rows, B, out=None):
         """Head on bottleneck values.  `out`: one-output heads may write straight into the caller's

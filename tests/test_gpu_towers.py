@@ -668,3 +668,52 @@ def test_tower_search_at_benchmarked_size():
                 close(P["rollout"][gi, s], torch.stack([r[0, 0], v[0, 0]]), f"rollout tree {gi} sim {s}")
     assert near_ties <= 2
     g.cpu(), f.cpu()
+
+
+@pytest.mark.parametrize("ni,ti", TREES[:2])
+def test_tower_running_statistics_follow_the_reference_calls(ni, ti):
+    """track_running_stats: after a search the BatchNorm buffers of g and f equal those the
+    reference's train-mode calls leave in the torch modules (network_builder.py:94,104,118) -- the
+    per-node CPU port makes the same calls at the same batch sizes (3 x f at batch 1, g at batch A, g
+    at batch 1 per simulation), torch updates its buffers as a side effect; here the tower kernels
+    export each call's statistics and the momentum chain runs on the device.  Same recorded search
+    (root, eta, child draws) on both sides, one tree; then again through the HIP graph replay."""
+    import copy
+    from oracle import pyref
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    k = f"net{ni}_t{ti}_"
+    g, f, A, shape = load_tower_nets(ni)
+    D = int(np.prod(shape))
+    S, depth = int(Z[k + "S"]), int(Z[k + "depth"])
+    noise, disc, tp = float(Z[k + "noise_frac"]), float(Z[k + "discount"]), int(Z[k + "to_play"])
+    lat = Z[k + "root_latent"].reshape(1, D).astype(np.float32)
+    eta, rand = Z[k + "eta"].astype(np.float32), Z[k + "rand"].astype(np.int32)
+    g_ref, f_ref = copy.deepcopy(g).train(), copy.deepcopy(f).train()
+    nets = TowerNetworks(g, f, track_running_stats=True)
+    mcts = BatchedMCTS(nets, 1, S, depth, discount=disc, noise_frac=noise)
+    searches = 3  # the second warms the launch graph up, the third replays it
+    for _ in range(searches):
+        mcts.run(torch.from_numpy(lat).cuda(), torch.tensor([tp], dtype=torch.int8).cuda(), torch.from_numpy(eta[None]).cuda(),
+                 torch.from_numpy(rand[None]).cuda())
+        draws = iter(rand.tolist())
+        with torch.no_grad():
+            ev = pyref.TorchEvaluator(g_ref, f_ref, torch.arange(A).long(), depth)
+            _, _, nodes = pyref.run_mcts(torch.from_numpy(lat).reshape(1, *shape), tp, ev, A, S, discount=disc, noise_frac=noise,
+                                         eta=eta, rand_index=lambda n: next(draws))
+    torch.cuda.synchronize()
+    assert mcts.replays >= 1
+    assert np.array_equal(mcts.pool.visit.cpu().numpy()[0, :len(nodes)], [nd.visit for nd in nodes])  # the same tree
+    nets.sync_running_stats()
+    checked = 0
+    for mine, ref in ((g, g_ref), (f, f_ref)):
+        for (name, a), (_, b) in zip(mine.named_buffers(), ref.named_buffers()):
+            if name.endswith("num_batches_tracked"):
+                assert int(a) == int(b) > 0, name
+            else:
+                np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-6, err_msg=name)
+                checked += 1
+    assert checked >= 8
+    # the parameters were not touched
+    assert all(torch.equal(p, q) for p, q in zip(list(g.parameters()) + list(f.parameters()),
+                                                 list(g_ref.parameters()) + list(f_ref.parameters())))
