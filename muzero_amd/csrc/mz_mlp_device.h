@@ -46,6 +46,10 @@ namespace mzd {
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kPrefetch = 4;  // k-steps of weights held in registers ahead of the MFMAs
+#ifndef MZ_WEIGHT_SETS
+#define MZ_WEIGHT_SETS 2
+#endif
+constexpr int kWeightSets = MZ_WEIGHT_SETS;  // register sets of such batches a wave rotates through (short row tiles)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) float lds_f;
@@ -423,22 +427,29 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
             }
         }
     };
-    f32x4 wa[NTW][KP], wb[NTW][KP];
+    // NS register sets rotate: NS - 1 batches are in flight while one is consumed.  Two is the measured
+    // optimum: a third set for the short row tiles (-DMZ_WEIGHT_SETS=3) left the search 1.4 % slower --
+    // the weight stream is bound by what a compute unit gets from L2, not by the latency one wave sees.
+    constexpr int NS = MT >= 4 ? 2 : kWeightSets;
+    f32x4 w[NS][NTW][KP];
     MZ_TL(1)
-    fetch(wa);  // the weights have the longest way: requested before the operand pipeline is primed
+    // the weights have the longest way: requested before the operand pipeline is primed
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < total) fetch(w[u]);
     MZ_TL(2)
     {
         const f32x4 sh = rows.shared(m, 4 * kq);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xc[mt] = Rows::form(sh, rows.raw(mt, m, 4 * kq));
     }
-    for (int i = 0; i < total; i += 2) {
-        if (i + 1 < total) fetch(wb);
-        compute(wa);
+    for (int i = 0; i < total; i += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (i + u + NS - 1 < total) fetch(w[(u + NS - 1) % NS]);
+            if (i + u < total) compute(w[u]);
+        }
         if (i == 0) { MZ_TL(3) }
-        if (i + 2 < total) fetch(wa);
-        if (i + 1 < total) compute(wb);
-        if (i == 0) { MZ_TL(4) }
     }
     MZ_TL(5)
 }
