@@ -175,7 +175,8 @@ def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
     from muzero_amd._hip import ptr
     lib = _hip.lib()
     gen = torch.Generator(device="cuda").manual_seed(11)
-    for (G, H, W, Cin, N, k) in [(3, 7, 9, 64, 128, 3), (2, 24, 24, 128, 256, 3), (5, 6, 63, 64, 128, 3), (2, 5, 100, 64, 128, 1)]:
+    for (G, H, W, Cin, N, k) in [(3, 7, 9, 64, 128, 3), (2, 24, 24, 128, 256, 3), (5, 6, 63, 64, 128, 3), (2, 5, 100, 64, 128, 1),
+                                 (3, 5, 7, 192, 384, 3), (1, 1, 1, 64, 128, 3), (40, 3, 3, 64, 128, 3)]:
         rows, taps = G * H * W, k * k
         x = torch.randn(rows * Cin, device="cuda", generator=gen)
         w = torch.randn(N * taps * Cin, device="cuda", generator=gen) * 0.05
@@ -274,3 +275,39 @@ def test_fused_forms_reproduce_the_separate_kernels_bit_for_bit():
     assert torch.equal(full, no_bn)
     assert torch.equal(no_bn, no_range)
     np.testing.assert_allclose(full.cpu().numpy(), no_sums.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(full.abs().max()))
+
+
+def test_staged_convolution_applies_the_previous_batchnorm_bit_for_bit():
+    """mz_conv3_same_bn_forward(x, scale, shift, relu) against mz_bn_apply3 (to split planes) followed by
+    mz_conv3_same_forward: identical bits, for ranges that span several small games and for a NULL scale
+    (the float32 input split on the fly) against mz_split3 + mz_conv3_same_forward."""
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    for (G, H, W, Cin, N) in [(4, 24, 24, 128, 128), (37, 4, 5, 64, 256), (3, 9, 8, 192, 128)]:
+        rows, P, k = G * H * W, H * W, 3
+        x = torch.randn(rows * Cin, device="cuda", generator=gen) * 2.0
+        scale = torch.rand((G, Cin), device="cuda", generator=gen) + 0.5
+        shift = torch.randn((G, Cin), device="cuda", generator=gen)
+        w = torch.randn(N * 9 * Cin, device="cuda", generator=gen) * 0.05
+        w3 = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
+        a3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
+        _hip.check(lib.mz_bn_apply3(ptr(x), ptr(scale), ptr(shift), None, None, None, None, 0, 1, None, ptr(a3), a3.shape[1], G, P, Cin,
+                                    None), "mz_bn_apply3")
+        want, got = torch.empty(rows * N, device="cuda"), torch.empty(rows * N, device="cuda")
+        _hip.check(lib.mz_conv3_same_forward(ptr(a3), a3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], None, 0, ptr(want), None, 0, N,
+                                             None, None), "mz_conv3_same_forward")
+        _hip.check(lib.mz_conv3_same_bn_forward(ptr(x), ptr(scale), ptr(shift), 1, Cin, G, H, W, k, ptr(w3), w3.shape[1], None, 0,
+                                                ptr(got), None, 0, N, None, None), "mz_conv3_same_bn_forward")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (G, H, W, Cin, N)
+        x3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
+        _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
+        _hip.check(lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], None, 0, ptr(want), None, 0, N,
+                                             None, None), "mz_conv3_same_forward")
+        _hip.check(lib.mz_conv3_same_bn_forward(ptr(x), None, None, 0, Cin, G, H, W, k, ptr(w3), w3.shape[1], None, 0, ptr(got), None, 0,
+                                                N, None, None), "mz_conv3_same_bn_forward")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (G, H, W, Cin, N)
