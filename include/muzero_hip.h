@@ -601,6 +601,24 @@ int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx,
                            int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B,
                            int32_t group, float *bn_stats, void *stream);
 
+/* g on the bottleneck values t of its input latent, up to the first matrix product of its tower, without
+ * the C*H*W-wide intermediate in memory (neural_network.py:168-182: fc_merge, reshape, the first
+ * ResBlock's conv1 and skip convolution).  h_merge: the latent half of fc_merge composed with the previous
+ * res_final (K = values per row of t, N = H*W*C) with its output rows permuted position-major
+ * (row p*C + c = latent index c*H*W + p), packed by mz_wide_pack; table f32[A][H*W][C]: the per-action
+ * half plus bias in the same order; h_conv: the [C] -> 32 column product (columns co*9 + tap of conv1, then
+ * the skip convolution's channels), packed likewise.  action i32[B] (one call per row) or NULL (every row
+ * with all A actions, rows of Y then in (row, action) order).  Y f32[rows][H*W][32].
+ * mz_tower_tail_forward finishes the block from Y (the tap sum, bn1, conv2, bn2, the skip path's
+ * BatchNorm, sum, activation; batch statistics per `group` rows, as mz_tower_forward) into the block
+ * output t_out (row scatter y_rows); bn_stats as in mz_tower_forward_stats. */
+int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer *h_conv, const float *blob,
+                          const float *t, int64_t ld_t, const int32_t *t_rows, const float *table,
+                          const int32_t *action, int32_t A, int32_t B, int32_t C, int32_t HW, float *Y,
+                          void *stream);
+int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, int32_t group, float *t_out,
+                          int64_t ld_t, const int32_t *y_rows, float *bn_stats, void *stream);
+
 /* table[a][:] = fc_merge.weight[:, D:] @ action_embedding[a] + fc_merge.bias for a < A
  * (f32[A][D]): the per-action half of fc_merge, neural_network.py:168-172. */
 int mz_action_table(const float *embedding, const float *merge_weight, const float *merge_bias,

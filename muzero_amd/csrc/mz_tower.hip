@@ -1040,6 +1040,355 @@ k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long l
     tower_body<2>(T, G, x, ldx, x_rows, row_add, ld_add, row_sel, y, ldy, y_rows, t_out, ld_t, group, stats, calls);
 }
 
+// ------------------------------------------------------------------ thin towers
+// One residual block on at most 4 channels (f evaluated on the bottleneck values of g's last block:
+// 3 -> 3 channels with pre-multiplied weights; the tail of g once its 256 -> 3 convolution has been
+// taken as a matrix product): a few thousand multiply-adds per call.  The general kernel spends a
+// workgroup and a dozen barriers on that; here ONE WAVE owns a call -- its positions sit in the lanes
+// (up to 4 per lane), every reduction is a wave reduction, the activations go through a private
+// slice of LDS only for the neighbour reads of the 3 x 3 windows, and weights are wave-uniform scalar
+// loads.  Four calls per 256-thread workgroup, no workgroup barrier.
+//
+// FROM_Y: the input rows are not the block's input but the products
+//   Y[position][column] = sum_ci W[ci][column] x[ci][position],  column = (output channel, tap) pairs
+// of conv1 followed by the skip convolution's channels (32 floats per position): conv1's output is
+// the sum over taps of Y shifted by the tap's offset.
+constexpr int kThinMaxC = 4, kThinMaxPos = 4;   // channels; positions per lane (P <= 256)
+constexpr int kThinT = 256;
+constexpr int kYCols = 32;
+
+constexpr int kThinW = 2 * kThinMaxC * kThinMaxC * 9 + kThinMaxC * kThinMaxC + 6 * kThinMaxC;  // staged: conv1, conv2, skip, BatchNorm
+
+template <bool FROM_Y, int K>
+__global__ void __launch_bounds__(kThinT)
+k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
+             float *__restrict__ t_out, long long ld_t, const int32_t *__restrict__ y_rows, int group, int calls,
+             float *__restrict__ stats) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int KK = K * K, PAD = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const mz_resblock &R = T.block[0];
+    const int H = T.H, W = T.W, HW = H * W, P = group * HW;
+    const int Cin = R.in_channels, Cout = R.out_channels;
+    const bool down = R.down_w != nullptr;
+    // the block's weights: staged once per workgroup, read as LDS broadcasts
+    lds_f *w1 = to_lds(smem), *w2 = w1 + kThinMaxC * kThinMaxC * 9, *wd = w2 + kThinMaxC * kThinMaxC * 9;
+    for (int i = threadIdx.x; i < Cout * Cin * KK; i += kThinT) w1[i] = FROM_Y ? 0.0f : R.conv1_w[i];
+    for (int i = threadIdx.x; i < Cout * Cout * KK; i += kThinT) w2[i] = R.conv2_w[i];
+    for (int i = threadIdx.x; i < Cout * Cin; i += kThinT) wd[i] = (down && !FROM_Y) ? R.down_w[i] : 0.0f;
+    lds_f *bnp = wd + kThinMaxC * kThinMaxC;  // [bn1_w, bn1_b, bn2_w, bn2_b, dbn_w, dbn_b][kThinMaxC]
+    if ((int)threadIdx.x < 6 * kThinMaxC) {
+        const int j = threadIdx.x / kThinMaxC, c = threadIdx.x % kThinMaxC;
+        const float *src = j == 0 ? R.bn1_w : j == 1 ? R.bn1_b : j == 2 ? R.bn2_w : j == 3 ? R.bn2_b : j == 4 ? R.dbn_w : R.dbn_b;
+        bnp[threadIdx.x] = (src && c < Cout) ? src[c] : 0.0f;
+    }
+    __syncthreads();
+    const int call = blockIdx.x * (kThinT / 64) + wave;
+    if (call >= calls) return;  // no workgroup barrier below
+    lds_f *buf = to_lds(smem) + kThinW + wave * (2 * kThinMaxC * kThinMaxPos * 64);
+    lds_f *a_in = buf, *a_mid = buf + kThinMaxC * kThinMaxPos * 64;  // [channel][P]
+    const int r0 = call * group;
+    const int npos = (P + 63) >> 6;
+
+    // this lane's positions: row of the call, position in the image, which taps stay inside the image
+    int prow[kThinMaxPos], psp[kThinMaxPos];
+    unsigned inside[kThinMaxPos];
+#pragma unroll
+    for (int u = 0; u < kThinMaxPos; ++u) {
+        const int p = min(lane + 64 * u, P - 1);
+        prow[u] = p / HW;
+        psp[u] = p - prow[u] * HW;
+        const int py = psp[u] / W, px = psp[u] - py * W;
+        inside[u] = 0;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int yy = py + tap / K - PAD, xx = px + tap % K - PAD;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) inside[u] |= 1u << tap;
+        }
+    }
+    auto live = [&](int u) { return u < npos && lane + 64 * u < P; };
+    auto row_ptr = [&](int r) -> const float * {
+        const long long s = x_rows ? (long long)x_rows[r0 + r] : (long long)(r0 + r);
+        return s < 0 ? nullptr : x + s * ldx;
+    };
+    // sum over the taps and input channels of a K x K window: src[ci][P] in LDS, weights w[(co * n_ci + ci) * KK + tap]
+    auto window = [&](const lds_f *src, const lds_f *w, int n_ci, int co, int u, float v) {
+        const int centre = prow[u] * HW + psp[u];
+        for (int ci = 0; ci < n_ci; ++ci) {
+            const lds_f *sp = src + ci * P + centre, *wr = w + (co * n_ci + ci) * KK;
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int off = (tap / K - PAD) * W + (tap % K - PAD);
+                const bool ok = (inside[u] >> tap) & 1;
+                v = fmaf(wr[tap], ok ? sp[ok ? off : 0] : 0.0f, v);
+            }
+        }
+        return v;
+    };
+
+    float c1[kThinMaxC][kThinMaxPos], sk[kThinMaxC][kThinMaxPos];
+#pragma unroll
+    for (int c = 0; c < kThinMaxC; ++c)
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) c1[c][u] = sk[c][u] = 0.0f;
+
+    if constexpr (FROM_Y) {
+        // conv1[co][p] = sum_tap Y[p + offset(tap)][co * KK + tap]; skip[co][p] = Y[p][Cout * KK + co].
+        // The call's rows of Y are contiguous (P x 32 floats): copied to LDS as whole 16-byte pieces, then
+        // every lane picks its windows from there.
+        lds_f *ys = to_lds(smem) + kThinW + (kThinT / 64) * (2 * kThinMaxC * kThinMaxPos * 64) + wave * (P * kYCols);
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(x + (long long)r0 * ldx);
+            for (int i = lane; i < P * (kYCols / 4); i += 64) *reinterpret_cast<lds_f4 *>(ys + 4 * i) = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) {
+            if (!live(u)) continue;
+            const lds_f *yr = ys + (prow[u] * HW + psp[u]) * kYCols;
+            for (int co = 0; co < Cout; ++co) {
+                float v = 0.0f;
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int off = (tap / K - PAD) * W + (tap % K - PAD);
+                    const bool ok = (inside[u] >> tap) & 1;
+                    v += ok ? yr[(ok ? off : 0) * kYCols + co * KK + tap] : 0.0f;
+                }
+                c1[co][u] = v;
+                sk[co][u] = yr[Cout * KK + co];
+            }
+        }
+    } else {
+        // the block's input -> LDS, then conv1 and the skip path from it
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u)
+            if (live(u)) {
+                const float *xr = row_ptr(prow[u]);
+                for (int ci = 0; ci < Cin; ++ci) a_in[ci * P + lane + 64 * u] = xr ? xr[ci * HW + psp[u]] : 0.0f;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (R.conv1_bias)  // requested together, before the windows
+#pragma unroll
+            for (int co = 0; co < kThinMaxC; ++co)
+#pragma unroll
+                for (int u = 0; u < kThinMaxPos; ++u)
+                    if (co < Cout && live(u)) c1[co][u] = R.conv1_bias[co * HW + psp[u]];
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) {
+            if (!live(u)) continue;
+            for (int co = 0; co < Cout; ++co) {
+                c1[co][u] = window(a_in, w1, Cin, co, u, c1[co][u]);
+                float sv = 0.0f;
+                if (down)
+                    for (int ci = 0; ci < Cin; ++ci) sv = fmaf(wd[co * Cin + ci], a_in[ci * P + lane + 64 * u], sv);
+                else
+                    sv = a_in[co * P + lane + 64 * u];  // identity skip (Cin == Cout)
+                sk[co][u] = sv;
+            }
+        }
+    }
+
+    // BatchNorm2d over the call's P values of a channel held in v[.] (mean / biased variance in float64
+    // around a pivot, as the general kernel), optional statistics export, then the activation
+    auto batchnorm = [&](float (&v)[kThinMaxPos], int which, float eps, int act, float *st, int c) {
+        const double pivot = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint((double)v[0])),
+                                              __builtin_amdgcn_readfirstlane(__double2loint((double)v[0])));
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u)
+            if (live(u)) {
+                const double d = (double)v[u] - pivot;
+                s += d;
+                q += d * d;
+            }
+        s = wave_total(s);
+        q = wave_total(q);
+        const double ds = s / P, mean = pivot + ds;
+        const double var = fmax(q / P - ds * ds, 0.0);
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double ga = (double)bnp[(2 * which) * kThinMaxC + c], be = (double)bnp[(2 * which + 1) * kThinMaxC + c];
+        const float scale = (float)(ga * invstd), shift = (float)(be - mean * ga * invstd);
+        if (st != nullptr && lane == 0) {
+            st[(long long)call * Cout + c] = (float)mean;
+            st[(long long)(calls + call) * Cout + c] = (float)var;
+        }
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) v[u] = activate(v[u] * scale + shift, act);
+    };
+    float *st1 = stats, *st2 = stats ? stats + 2LL * calls * Cout : nullptr, *st3 = stats ? stats + 4LL * calls * Cout : nullptr;
+    for (int co = 0; co < Cout; ++co) {
+        batchnorm(c1[co], 0, R.eps1, R.activation, st1, co);
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u)
+            if (live(u)) a_mid[co * P + lane + 64 * u] = c1[co][u];
+        if (down) batchnorm(sk[co], 2, R.epsd, MZ_ACT_NONE, st3, co);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // conv2 (Cout -> Cout), its BatchNorm, the skip sum and the activation
+    for (int co = 0; co < Cout; ++co) {
+        float c2[kThinMaxPos];
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) c2[u] = live(u) ? window(a_mid, w2, Cout, co, u, 0.0f) : 0.0f;
+        batchnorm(c2, 1, R.eps2, MZ_ACT_NONE, st2, co);
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) {
+            if (!live(u)) continue;
+            const long long dr = y_rows ? (long long)y_rows[r0 + prow[u]] : (long long)(r0 + prow[u]);
+            if (dr >= 0) t_out[dr * ld_t + co * HW + psp[u]] = activate(c2[u] + sk[co][u], R.activation);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fc_merge + first convolution of g in one pass
+// g on the bottleneck values t of its input latent (towers.py): z = Wm t is the fc_merge product (C*H*W
+// values per row), x = relu(z + table[action]) the tower's input, and the tower's first block starts with
+//   Y[position][column] = sum_c Wg[c][column] x[c][position]   (conv1's (channel, tap) pairs + the skip
+// convolution: 32 columns).  Writing z to memory and reading it back is most of the traffic of that
+// path; here a workgroup owns 64 rows and ONE position: it forms z for that position's C = 256 channels
+// (rows of Wm permuted position-major on the host), turns it into x in LDS and multiplies by Wg at
+// once -- only Y, 32 floats per position, leaves the chip.  With `action` NULL every row is expanded
+// with all A actions (the expansion: z is formed once, x and Y per action).
+// Both products on v_mfma_f32_16x16x4_f32 with the packed tiles of mz_wide_pack.
+constexpr int kMcT = 512, kMcRows = 64, kMcC = 256, kMcLdX = kMcC + 4;
+
+constexpr int kMcMaxKT = 8;   // merge product: at most 128 bottleneck values per row
+
+// Two workgroups share a compute unit (128 registers, 67 KB of LDS each): the phases of one -- staging,
+// the merge product, forming x, the convolution product -- are separated by barriers, and the other
+// workgroup's waves fill the matrix pipe meanwhile.  Weights stream from L2 two k-tiles ahead.
+__global__ void __launch_bounds__(kMcT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, long long wg_off,
+             const float *__restrict__ t, long long ld_t, const int32_t *__restrict__ t_rows, int B,
+             const float *__restrict__ table, const int32_t *__restrict__ action, int A, int nA, int HW,
+             float *__restrict__ Y) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int pos = blockIdx.y, r0 = blockIdx.x * kMcRows;
+    const int ldT = KTm * 16 + 4;
+    // x takes the place of the bottleneck rows once z is formed
+    lds_f *Ts = to_lds(smem), *Xs = Ts;
+    lds_i *s_act = to_lds_i(smem + (size_t)kMcRows * kMcLdX);
+    const int ymt = wave >> 1, yn = wave & 1;
+    const f32x4 *wm = reinterpret_cast<const f32x4 *>(blob + wm_off) + ((long long)(pos * (kMcC / 16) + 2 * wave) * KTm) * 64 + lane;
+    const f32x4 *wg = reinterpret_cast<const f32x4 *>(blob + wg_off) + ((long long)yn * (kMcC / 16)) * 64 + lane;
+    // the first two k-tiles of this wave's merge weights are on their way while the rows are staged
+    f32x4 b0[2] = {wm[0], wm[(long long)KTm * 64]}, b1[2] = {b0[0], b0[1]};
+    if (KTm > 1) {
+        b1[0] = wm[64];
+        b1[1] = wm[(long long)(KTm + 1) * 64];
+    }
+    {
+        // eight threads per row: the row index is fetched once, then the row's values are requested together
+        const int r = tid >> 3, k0 = tid & 7;
+        long long row = -1;
+        if (r0 + r < B) row = t_rows ? (long long)t_rows[r0 + r] : (long long)(r0 + r);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[kMcMaxKT];
+#pragma unroll
+            for (int j = 0; j < kMcMaxKT; ++j) {
+                const int k = k0 + 8 * (h * kMcMaxKT + j);
+                v[j] = (row >= 0 && k < Kt) ? t[row * ld_t + k] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < kMcMaxKT; ++j) {
+                const int k = k0 + 8 * (h * kMcMaxKT + j);
+                if (k < KTm * 16) Ts[r * ldT + k] = v[j];
+            }
+        }
+    }
+    if (tid < kMcRows) {
+        int a = 0;
+        if (action && r0 + tid < B) a = min(max(action[r0 + tid], 0), A - 1);
+        s_act[tid] = a;
+    }
+    __syncthreads();
+
+    // ---- z for this position: wave w owns channels 32 w .. 32 w + 31 (two column tiles), all four row tiles
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[mt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KTm; ++kt) {
+        const f32x4 bc[2] = {b0[0], b0[1]};
+        b0[0] = b1[0];
+        b0[1] = b1[1];
+        if (kt + 2 < KTm) {
+            b1[0] = wm[(long long)(kt + 2) * 64];
+            b1[1] = wm[(long long)(KTm + kt + 2) * 64];
+        }
+        f32x4 a4[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a4[mt] = *reinterpret_cast<const lds_f4 *>(Ts + (mt * 16 + m) * ldT + kt * 16 + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][j], bc[n][j], acc[mt][n], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has read its rows of t
+    // ---- per action: x = relu(z + table[action]) -> LDS, Y = x Wg; wave w owns Y tile (row tile w / 2, columns 16 (w & 1) ..)
+    for (int ai = 0; ai < nA; ++ai) {
+        f32x4 g0 = wg[0], g1 = wg[64];  // on their way while x is formed
+        if (action) {
+            // a row's action picks its table row: sixteen values of this lane at a time, requested together
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float tv[4][4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        tv[mt][i] = table[((long long)s_act[mt * 16 + 4 * kq + i] * HW + pos) * kMcC + 32 * wave + 16 * n + m];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        Xs[(mt * 16 + 4 * kq + i) * kMcLdX + 32 * wave + 16 * n + m] = fmaxf(acc[mt][n][i] + tv[mt][i], 0.0f);
+            }
+        } else {
+            const float *trow = table + ((long long)ai * HW + pos) * kMcC + 32 * wave + m;
+            const float tv0 = trow[0], tv1 = trow[16];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lds_f *dst = Xs + (mt * 16 + 4 * kq + i) * kMcLdX + 32 * wave + m;
+                    dst[0] = fmaxf(acc[mt][0][i] + tv0, 0.0f);
+                    dst[16] = fmaxf(acc[mt][1][i] + tv1, 0.0f);
+                }
+        }
+        __syncthreads();
+        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < kMcC / 16; ++kt) {
+            const f32x4 gc = g0;
+            g0 = g1;
+            if (kt + 2 < kMcC / 16) g1 = wg[(long long)(kt + 2) * 64];
+            const f32x4 a4 = *reinterpret_cast<const lds_f4 *>(Xs + (ymt * 16 + m) * kMcLdX + kt * 16 + 4 * kq);
+            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], gc[0], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], gc[1], y1, 0, 0, 0);
+            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], gc[2], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], gc[3], y1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rg = r0 + ymt * 16 + 4 * kq + i;
+            if (rg < B) Y[(((long long)rg * nA + ai) * HW + pos) * kYCols + 16 * yn + m] = y0[i] + y1[i];
+        }
+        __syncthreads();
+    }
+}
+
 int tower_geometry(const mz_tower *T, int group, int ng, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
     if (!T || T->n_blocks < 0 || T->n_blocks > MZ_MAX_BLOCKS || T->C <= 0 || T->H <= 0 || T->W <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: bad tower (n_blocks 0..%d, positive C, H, W)", MZ_MAX_BLOCKS);
@@ -1292,6 +1641,62 @@ int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, con
     return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, scratch, need, stream);
 }
 
+int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer *h_conv, const float *blob, const float *t,
+                          int64_t ld_t, const int32_t *t_rows, const float *table, const int32_t *action, int32_t A, int32_t B,
+                          int32_t C, int32_t HW, float *Y, void *stream) {
+    if (!h_merge || !h_conv || !blob || !t || !table || !Y || A <= 0 || B <= 0 || HW <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: NULL argument or non-positive size");
+    if (C != kMcC) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: %d channels (the kernel is built for %d)", C, kMcC);
+    if (h_merge->N != HW * C || h_merge->K <= 0 || h_merge->Kp > 16 * kMcMaxKT || ld_t < h_merge->K)
+        return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: the merge layer must map at most 128 values to H*W*C = %d (position-major rows)",
+                        HW * C);
+    if (h_conv->K != C || h_conv->N > kYCols || h_conv->Np != kYCols)
+        return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: the convolution product must map %d channels to at most %d columns", C, kYCols);
+    if (HW > 65535) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: more than 65535 positions");
+    const int KTm = h_merge->Kp >> 4;
+    const size_t lds = ((size_t)kMcRows * kMcLdX + kMcRows) * sizeof(float);  // KTm * 16 + 4 <= kMcLdX: the rows of t fit the same area
+    MZ_TRY(allow_lds(k_merge_conv, lds, "k_merge_conv"));
+    hipLaunchKernelGGL(k_merge_conv, dim3((B + kMcRows - 1) / kMcRows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
+                       (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B, table,
+                       action, A, action ? 1 : A, HW, Y);
+    return mz::check_launch("k_merge_conv");
+}
+
+int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, int32_t group, float *t_out, int64_t ld_t,
+                          const int32_t *y_rows, float *bn_stats, void *stream) {
+    if (!h_tower || !Y || !t_out || B <= 0 || group <= 0 || B % group)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: NULL argument, or B is not a positive multiple of group");
+    if (h_tower->n_blocks != 1) return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: one block expected");
+    const mz_resblock &R = h_tower->block[0];
+    const int hw = h_tower->H * h_tower->W, kk = R.kernel_size * R.kernel_size;
+    if (R.kernel_size != 3 || !R.down_w || R.out_channels > kThinMaxC || R.out_channels * kk + R.out_channels > kYCols)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: a 3x3 block with a skip convolution and at most 3 output channels expected");
+    if (!R.bn1_w || !R.bn1_b || !R.conv2_w || !R.bn2_w || !R.bn2_b || !R.dbn_w || !R.dbn_b)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: block 0 has a NULL weight");
+    if (R.activation < MZ_ACT_NONE || R.activation > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: unsupported activation %d", R.activation);
+    if ((long long)group * hw > 64 * kThinMaxPos || group * hw < 2)
+        return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: %d positions per call (2 .. %d)", group * hw, 64 * kThinMaxPos);
+    if (ld_t < (long long)R.out_channels * hw) return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: ld_t below the block's values per row");
+    const int calls = B / group, per_wg = kThinT / 64;
+    const size_t lds = ((size_t)per_wg * 2 * kThinMaxC * kThinMaxPos * 64 + kThinW + (size_t)per_wg * group * hw * kYCols) * sizeof(float);
+    MZ_TRY(allow_lds(k_tower_thin<true, 3>, lds, "k_tower_thin"));
+    hipLaunchKernelGGL((k_tower_thin<true, 3>), dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds, (hipStream_t)stream, *h_tower, Y,
+                       (long long)hw * kYCols, nullptr, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
+    return mz::check_launch("k_tower_thin");
+}
+
+// Calls from which the one-wave-per-call kernel takes over thin towers: with few calls the general
+// kernel's workgroup per call has the shorter chain (11-14 us against 18-27 us at 256 calls), with
+// thousands the thin kernel's throughput wins (28 us against 38-147 us at 4096 calls).
+static int thin_min_calls() {
+    static const int n = [] {
+        const char *e = getenv("MZ_TOWER_THIN_MIN_CALLS");  // tuning aid
+        return e ? atoi(e) : 1024;
+    }();
+    return n;
+}
+
 int64_t mz_tower_stats_floats(const mz_tower *h_tower, int32_t calls) {
     if (!h_tower || calls <= 0 || h_tower->n_blocks < 0 || h_tower->n_blocks > MZ_MAX_BLOCKS) return 0;
     int64_t n = 0;
@@ -1311,6 +1716,30 @@ int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx,
                            const float *row_add, int64_t ld_add, const int32_t *row_sel, float *y,
                            int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B, int32_t group,
                            float *bn_stats, void *stream) {
+    // A single block on a handful of channels whose caller wants the block output only: one wave per call
+    if (h_tower && h_tower->n_blocks == 1 && h_tower->C <= kThinMaxC && h_tower->block[0].in_channels == h_tower->C &&
+        h_tower->block[0].out_channels <= kThinMaxC && (h_tower->block[0].kernel_size == 1 || h_tower->block[0].kernel_size == 3) &&
+        (h_tower->block[0].down_w || h_tower->block[0].in_channels == h_tower->block[0].out_channels) && !y && t_out && !row_add &&
+        x && group > 0 && B > 0 && B % group == 0 && h_tower->H > 0 && h_tower->W > 0 &&
+        (long long)group * h_tower->H * h_tower->W <= 64 * kThinMaxPos && B / group >= thin_min_calls()) {
+        const mz_resblock &R = h_tower->block[0];
+        const int hw = h_tower->H * h_tower->W;
+        if (ldx < (long long)h_tower->C * hw || ld_t < (long long)R.out_channels * hw)
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: a row stride is below the row's %d values", h_tower->C * hw);
+        if (!R.conv1_w || !R.bn1_w || !R.bn1_b || !R.conv2_w || !R.bn2_w || !R.bn2_b || (R.down_w && (!R.dbn_w || !R.dbn_b)))
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block 0 has a NULL weight");
+        if (R.activation < MZ_ACT_NONE || R.activation > MZ_ACT_SIGMOID)
+            return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block 0 has unsupported activation %d", R.activation);
+        if (group * hw < 2) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: batch statistics need more than 1 value per channel");
+        const int calls = B / group, per_wg = kThinT / 64;
+        const size_t lds_thin = ((size_t)per_wg * 2 * kThinMaxC * kThinMaxPos * 64 + kThinW) * sizeof(float);
+        auto launch_thin = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds_thin, (hipStream_t)stream, *h_tower, x,
+                               (long long)ldx, x_rows, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
+            return mz::check_launch("k_tower_thin");
+        };
+        return R.kernel_size == 3 ? launch_thin(k_tower_thin<false, 3>) : launch_thin(k_tower_thin<false, 1>);
+    }
     TowerGeom g;
     size_t lds = 0;
     auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

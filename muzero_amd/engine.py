@@ -316,7 +316,10 @@ class BatchedMCTS:
             extra = dict(t_in=t_in, t_out=self.tmp_t[d & 1], want_latent=self.keep_latents) \
                 if self.t_pool is not None else {}
             f_extra = {"t_in": t_in} if t_in is not None else {}
-            if self.side is not None:  # fc_merge's latent half needs no action: it runs next to f
+            # (with fc_merge fused into the tower's first product there is nothing to run beside f)
+            fused_g = (getattr(nets, "fused_g", False) and t_in is not None and not self.keep_latents
+                       and G >= getattr(nets, "fuse_min_rows", 0))
+            if self.side is not None and not fused_g:  # fc_merge's latent half needs no action: it runs next to f
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
                     nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)

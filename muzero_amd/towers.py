@@ -29,6 +29,7 @@ There is no CPU fallback: every call goes through libmuzero_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -69,13 +70,16 @@ class TowerNetworks:
     strided_outputs = True  # reward / value may be 1-D views with a stride (a column of a [G, n] buffer)
 
     def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096,
-                 track_running_stats: bool = False):
+                 track_running_stats: bool = False, fuse_merge_conv: bool = True):
         """track_running_stats: every tower call also advances the BatchNorm running statistics of its
         blocks as the reference's train-mode calls do (network_builder.py:94,104,118), one update per
         reference call, the calls of one launch in row order (with one tree that is the reference's
         order; with G trees in lock step the trees' calls interleave).  `sync_running_stats()` writes
         the buffers and num_batches_tracked back into the modules.  No output depends on them."""
         self.device = torch.device(device)
+        self.fuse_merge_conv = fuse_merge_conv  # False keeps fc_merge and the tower of g as separate kernels
+        # source rows from which the fused form is used: below, the separate kernels have the shorter chain
+        self.fuse_min_rows = int(os.environ.get("MZ_FUSE_MIN_ROWS", "1024"))
         self.track_running_stats = track_running_stats
         self._running: dict = {}   # id(tower struct) -> [(bn module, running_mean, running_var)] per block x 3
         self._calls: dict = {}     # id(tower struct) -> device counter of reference calls since the last sync
@@ -242,10 +246,27 @@ class TowerNetworks:
         self.bottleneck_f = bn_f[0] * self.shape[1] * self.shape[2] if bn_f else 0
         self.merge_t = self.reward_t = self.value_t = self.policy_t = None
         merge_const = None
+        self.fused_g = False     # fc_merge + the tower's first convolution in one pass (mz_merge_conv_forward)
+        self.merge_t_perm = self.conv_g = self.table_t_perm = None
         if bn_g:
             wt, merge_const = through(g.fc_merge.weight[:, :D], None, bn_g)
             self.merge_t = plan_wide(_hip.Dense(ptr(wt), None, wt.shape[1], D, _hip.ACT["none"], 0))
             self.reward_t = head_on_t(g.reward_mlp, bn_g)
+            blk = g.res_blocks[0] if len(g.res_blocks) == 1 else None
+            c, hgt, wid = self.shape
+            if (self.fuse_merge_conv and blk is not None and c == 256 and blk.downsample is not None and blk.conv1.kernel_size == (3, 3)
+                    and blk.conv1.out_channels <= 3 and wt.shape[1] <= 128):
+                co = blk.conv1.out_channels
+                hw = hgt * wid
+                # rows of the merge product position-major: row p * C + ch <- latent index ch * HW + p
+                wperm = self._dev(wt.view(c, hw, wt.shape[1]).permute(1, 0, 2).reshape(D, wt.shape[1]))
+                self.merge_t_perm = plan_wide(_hip.Dense(ptr(wperm), None, wt.shape[1], D, _hip.ACT["none"], 0))
+                # columns of the first block's product: (output channel, tap) pairs of conv1, then the skip convolution
+                wg = torch.zeros((32, c), dtype=torch.float32, device=self.device)
+                wg[:co * 9] = blk.conv1.weight.detach().to(self.device, torch.float32).permute(0, 2, 3, 1).reshape(co * 9, c)
+                wg[co * 9:co * 10] = blk.downsample[0].weight.detach().to(self.device, torch.float32).reshape(co, c)
+                self.conv_g = plan_wide(_hip.Dense(ptr(self._dev(wg)), None, c, 32, _hip.ACT["none"], 0))
+                self.fused_g = True
         if bn_f:
             self.value_t = head_on_t(f.value_mlp, bn_f)
             self.policy_t = head_on_t(f.policy_mlp, bn_f)
@@ -289,6 +310,9 @@ class TowerNetworks:
                                        D, A, ptr(self.table), _stream()), "mz_action_table")
         # per-action table of the bottleneck form: the constant part W b of the folded res_final included
         self.table_t = (self.table + merge_const[None, :]).contiguous() if merge_const is not None else None
+        if self.fused_g:
+            c, hgt, wid = self.shape
+            self.table_t_perm = self.table_t.view(A, c, hgt * wid).permute(0, 2, 1).contiguous()  # [A][HW][C]
 
     # ---- scratch ----------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
@@ -389,8 +413,12 @@ class TowerNetworks:
                                               ptr(row_sel), ptr(y), ldy, ptr(y_rows), ptr(t_out),
                                               t_out.shape[-1] if t_out is not None else 0, B, group, ptr(stats), _stream()),
                    "mz_tower_forward")
-        if stats is None:
-            return
+        if stats is not None:
+            self._advance_running(tower, layers, stats, calls, group)
+
+    def _advance_running(self, tower, layers, stats, calls, group) -> None:
+        """The momentum chain of every tracked BatchNorm layer over the statistics one launch exported."""
+        lib = _hip.lib()
         off, hw = 0, self.shape[1] * self.shape[2]
         for b in range(tower.n_blocks):
             c = tower.block[b].out_channels
@@ -453,6 +481,34 @@ class TowerNetworks:
         D, A = self.D, self.A
         ld = ld or D
         use_t = t_in is not None and self.merge_t is not None
+        if (use_t and self.fused_g and base is None and not want_latent and t_out is not None and self.reward_t is not None
+                and (action is not None or B % A == 0) and (B if action is not None else B // A) >= self.fuse_min_rows):
+            # fc_merge, the action term and the first block's big product in one kernel, the rest of the block in a second
+            lib = _hip.lib()
+            t, t_rows = t_in
+            c, hgt, wid = self.shape
+            if action is None:
+                U = B // A
+                if t_rows is not None and t_rows.numel() != U:
+                    t_rows = t_rows[::A].contiguous()
+                n_src, group = U, A
+            else:
+                n_src, group = B, 1
+            Y = self._buf("g_Y", (B, hgt * wid, 32))
+            _hip.check(lib.mz_merge_conv_forward(C.byref(self.merge_t_perm), C.byref(self.conv_g), ptr(self.blob), ptr(t), t.shape[-1],
+                                                 ptr(t_rows), ptr(self.table_t_perm), ptr(action), A, n_src, c, hgt * wid, ptr(Y),
+                                                 _stream()), "mz_merge_conv_forward")
+            layers = self._running.get(id(self.tower_g)) if self.track_running_stats else None
+            stats, calls = None, B // group
+            if layers:
+                stats = self._buf(("bn_stats", id(self.tower_g)), (lib.mz_tower_stats_floats(C.byref(self.tower_g), calls),))
+            _hip.check(lib.mz_tower_tail_forward(C.byref(self.tower_g), ptr(Y), B, group, ptr(t_out), t_out.shape[-1], ptr(next_rows),
+                                                 ptr(stats), _stream()), "mz_tower_tail_forward")
+            if stats is not None:
+                self._advance_running(self.tower_g, layers, stats, calls, group)
+            if reward is not None:
+                self._mlp_on(self.reward_t, "reward_t", t_out, t_out.shape[-1], next_rows, B, out=reward)
+            return
         if action is None:
             assert B % A == 0, "expansion rows come in groups of A"
             U = B // A

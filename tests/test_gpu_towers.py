@@ -585,7 +585,9 @@ def test_tower_search_at_benchmarked_size():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.weight.uniform_(0.5, 1.5)
                 m.bias.uniform_(-0.3, 0.3)
-    nets = TowerNetworks(g, f)
+    nets = TowerNetworks(g, f, fuse_merge_conv=False)
+    fused = TowerNetworks(g, f)   # fc_merge + the first convolution of g's tower in one kernel (searches without stored latents)
+    assert fused.fused_g and not nets.fused_g
     rng = np.random.default_rng(17)
     lat = rng.standard_normal((G, D)).astype(np.float32)
     eta = rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)
@@ -593,9 +595,11 @@ def test_tower_search_at_benchmarked_size():
     to_play = np.zeros(G, np.int8)   # single-player simulators (CarRacing): to_play 0
     dev = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
     pools = {}
-    for keep in (True, False):
-        mcts = BatchedMCTS(nets, G, S, depth, discount=0.998, noise_frac=0.25, keep_latents=keep)
-        assert mcts.t_pool is not None and mcts.keep_latents == keep, "the bottleneck form is not in use"
+    for keep in (True, False, "fused"):
+        mcts = BatchedMCTS(fused if keep == "fused" else nets, G, S, depth, discount=0.998, noise_frac=0.25,
+                           keep_latents=keep is True)
+        keep_flag = keep is True
+        assert mcts.t_pool is not None and mcts.keep_latents == keep_flag, "the bottleneck form is not in use"
         trace = {}
         res = mcts.run(*dev, trace=trace)          # launch by launch (tracing)
         torch.cuda.synchronize()
@@ -606,7 +610,7 @@ def test_tower_search_at_benchmarked_size():
         child = np.stack([x.cpu().numpy() for x in trace["child"]], axis=1)
         reward_nodes = pool.reward.cpu().numpy()
         root_prior = torch.empty(G, A, device="cuda")
-        nets.prediction(dev[0], G, softmax_times=1, policy=root_prior)
+        mcts.nets.prediction(dev[0], G, softmax_times=1, policy=root_prior)
         prior_stream = np.concatenate([root_prior.cpu().numpy()[:, None], prior_s], axis=1)
         reward_stream = np.stack([reward_nodes[:, 1 + e * A:1 + (e + 1) * A] for e in range(S + 1)], axis=1)
         ref = otree.run_batch(A, S, depth, to_play, prior_stream, reward_stream, rand, rollout, eta, 0.25, 0.998)
@@ -625,13 +629,27 @@ def test_tower_search_at_benchmarked_size():
             assert torch.equal(res2.policy32, res.policy32) and torch.equal(res2.value, res.value)
         assert mcts.replays == 2, "the recorded graph was not used"
         pools[keep] = dict(prior=prior_stream, reward=reward_stream, rollout=rollout, leaf=leaf, child=child,
-                           latent=pool.latent if keep else None, t_pool=mcts.t_pool.clone())
-        if keep:
+                           latent=pool.latent if keep_flag else None, t_pool=mcts.t_pool.clone())
+        if keep_flag:
             keep_mcts = mcts   # keeps pool.latent alive for (ii)
     # storing the latents or not changes nothing the search computes
     for n in ("prior", "reward", "rollout", "leaf", "child"):
         assert np.array_equal(pools[True][n], pools[False][n]), n
     assert torch.equal(pools[True]["t_pool"], pools[False]["t_pool"])
+    # the fused form of g computes the same numbers in another order: wherever a tree's descents agree,
+    # its streams do to 1e-5 of their scale, and a tree's first disagreeing descent is a near-tie
+    same = np.array([np.array_equal(pools["fused"]["leaf"][gi], pools[False]["leaf"][gi]) and
+                     np.array_equal(pools["fused"]["child"][gi], pools[False]["child"][gi]) for gi in range(G)])
+    assert same.mean() >= 0.9, f"only {int(same.sum())} of {G} trees took the same descents"
+    for n in ("prior", "reward", "rollout"):
+        a, b = pools["fused"][n][same], pools[False][n][same]
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=max(1e-5 * float(np.abs(b).max()), TOL["atol"]), err_msg=n)
+    for gi in np.flatnonzero(~same):
+        first = int(np.flatnonzero((pools["fused"]["leaf"][gi] != pools[False]["leaf"][gi]) |
+                                   (pools["fused"]["child"][gi] != pools[False]["child"][gi]))[0])
+        for n in ("prior", "reward"):   # everything computed before the first differing descent agrees
+            a, b = pools["fused"][n][gi, :first + 1], pools[False][n][gi, :first + 1]
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=max(1e-5 * float(np.abs(b).max()), TOL["atol"]), err_msg=f"{n} tree {gi}")
 
     # ---- (ii) the torch modules, one reference call at a time, on the GPU (rocBLAS / MIOpen fp32)
     gt, ft = g.cuda(), f.cuda()
