@@ -1059,28 +1059,48 @@ constexpr int kYCols = 32;
 
 constexpr int kThinW = 2 * kThinMaxC * kThinMaxC * 9 + kThinMaxC * kThinMaxC + 6 * kThinMaxC;  // staged: conv1, conv2, skip, BatchNorm
 
-template <bool FROM_Y, int K>
+// What the thin kernel needs of a block: a handful of pointers and numbers (passing the whole mz_tower
+// would make every field a separate load from the argument segment, each with its own wait).
+struct ThinBlock {
+    const float *conv1_w, *conv2_w, *down_w, *conv1_bias;
+    const float *bn[6];  // bn1 weight, bias, bn2 weight, bias, skip BatchNorm weight, bias
+    float eps1, eps2, epsd;
+    int cin, cout, act, H, W;
+};
+
+// CI / CO: compile-time bounds of the channel counts (the shipped towers: exactly 3 -> 3, EXACT; other
+// shapes run with CI = CO = 4 and guards), so that the per-channel values live in registers and every
+// loop unrolls.
+template <bool FROM_Y, int K, int CI, int CO, bool EXACT>
 __global__ void __launch_bounds__(kThinT)
-k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
+k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
              float *__restrict__ t_out, long long ld_t, const int32_t *__restrict__ y_rows, int group, int calls,
              float *__restrict__ stats) {
     extern __shared__ __align__(16) float smem[];
     constexpr int KK = K * K, PAD = (K - 1) / 2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const mz_resblock &R = T.block[0];
-    const int H = T.H, W = T.W, HW = H * W, P = group * HW;
-    const int Cin = R.in_channels, Cout = R.out_channels;
+    const int H = R.H, W = R.W, HW = H * W, P = group * HW;
+    const int Cin = EXACT ? CI : R.cin, Cout = EXACT ? CO : R.cout;
     const bool down = R.down_w != nullptr;
     // the block's weights: staged once per workgroup, read as LDS broadcasts
     lds_f *w1 = to_lds(smem), *w2 = w1 + kThinMaxC * kThinMaxC * 9, *wd = w2 + kThinMaxC * kThinMaxC * 9;
-    for (int i = threadIdx.x; i < Cout * Cin * KK; i += kThinT) w1[i] = FROM_Y ? 0.0f : R.conv1_w[i];
-    for (int i = threadIdx.x; i < Cout * Cout * KK; i += kThinT) w2[i] = R.conv2_w[i];
-    for (int i = threadIdx.x; i < Cout * Cin; i += kThinT) wd[i] = (down && !FROM_Y) ? R.down_w[i] : 0.0f;
     lds_f *bnp = wd + kThinMaxC * kThinMaxC;  // [bn1_w, bn1_b, bn2_w, bn2_b, dbn_w, dbn_b][kThinMaxC]
-    if ((int)threadIdx.x < 6 * kThinMaxC) {
-        const int j = threadIdx.x / kThinMaxC, c = threadIdx.x % kThinMaxC;
-        const float *src = j == 0 ? R.bn1_w : j == 1 ? R.bn1_b : j == 2 ? R.bn2_w : j == 3 ? R.bn2_b : j == 4 ? R.dbn_w : R.dbn_b;
-        bnp[threadIdx.x] = (src && c < Cout) ? src[c] : 0.0f;
+    {
+        const int i = threadIdx.x;
+        float v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
+        if (!FROM_Y && i < Cout * Cin * KK) v1 = R.conv1_w[i];
+        if (i < Cout * Cout * KK) v2 = R.conv2_w[i];
+        if (!FROM_Y && down && i < Cout * Cin) v3 = R.down_w[i];
+        if (i < 6 * kThinMaxC) {
+            const float *src = R.bn[i / kThinMaxC];
+            if (src && i % kThinMaxC < Cout) v4 = src[i % kThinMaxC];
+        }
+        if (i < kThinMaxC * kThinMaxC * 9) {
+            w1[i] = v1;
+            w2[i] = v2;
+        }
+        if (i < kThinMaxC * kThinMaxC) wd[i] = v3;
+        if (i < 6 * kThinMaxC) bnp[i] = v4;
     }
     __syncthreads();
     const int call = blockIdx.x * (kThinT / 64) + wave;
@@ -1093,8 +1113,10 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
     // this lane's positions: row of the call, position in the image, which taps stay inside the image
     int prow[kThinMaxPos], psp[kThinMaxPos];
     unsigned inside[kThinMaxPos];
+    bool live[kThinMaxPos];
 #pragma unroll
     for (int u = 0; u < kThinMaxPos; ++u) {
+        live[u] = u < npos && lane + 64 * u < P;
         const int p = min(lane + 64 * u, P - 1);
         prow[u] = p / HW;
         psp[u] = p - prow[u] * HW;
@@ -1106,15 +1128,12 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
             if (yy >= 0 && yy < H && xx >= 0 && xx < W) inside[u] |= 1u << tap;
         }
     }
-    auto live = [&](int u) { return u < npos && lane + 64 * u < P; };
-    auto row_ptr = [&](int r) -> const float * {
-        const long long s = x_rows ? (long long)x_rows[r0 + r] : (long long)(r0 + r);
-        return s < 0 ? nullptr : x + s * ldx;
-    };
     // sum over the taps and input channels of a K x K window: src[ci][P] in LDS, weights w[(co * n_ci + ci) * KK + tap]
-    auto window = [&](const lds_f *src, const lds_f *w, int n_ci, int co, int u, float v) {
+    auto window = [&](const lds_f *src, const lds_f *w, int n_ci, int n_ci_max, int co, int u, float v) {
         const int centre = prow[u] * HW + psp[u];
-        for (int ci = 0; ci < n_ci; ++ci) {
+#pragma unroll
+        for (int ci = 0; ci < kThinMaxC; ++ci) {
+            if (ci >= n_ci_max || ci >= n_ci) break;
             const lds_f *sp = src + ci * P + centre, *wr = w + (co * n_ci + ci) * KK;
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
@@ -1126,11 +1145,16 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
         return v;
     };
 
-    float c1[kThinMaxC][kThinMaxPos], sk[kThinMaxC][kThinMaxPos];
+    float c1[CO][kThinMaxPos], sk[CO][kThinMaxPos];
 #pragma unroll
-    for (int c = 0; c < kThinMaxC; ++c)
+    for (int c = 0; c < CO; ++c)
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u) c1[c][u] = sk[c][u] = 0.0f;
+    // destination rows of the result, requested now
+    long long drow[kThinMaxPos];
+#pragma unroll
+    for (int u = 0; u < kThinMaxPos; ++u)
+        drow[u] = live[u] ? (y_rows ? (long long)y_rows[r0 + prow[u]] : (long long)(r0 + prow[u])) : -1;
 
     if constexpr (FROM_Y) {
         // conv1[co][p] = sum_tap Y[p + offset(tap)][co * KK + tap]; skip[co][p] = Y[p][Cout * KK + co].
@@ -1139,16 +1163,27 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
         lds_f *ys = to_lds(smem) + kThinW + (kThinT / 64) * (2 * kThinMaxC * kThinMaxPos * 64) + wave * (P * kYCols);
         {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(x + (long long)r0 * ldx);
-            for (int i = lane; i < P * (kYCols / 4); i += 64) *reinterpret_cast<lds_f4 *>(ys + 4 * i) = src[i];
+            const int n4 = P * (kYCols / 4);
+            for (int i0 = lane; i0 < n4; i0 += 64 * 8) {  // eight pieces per lane in flight
+                f32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + 64 * j < n4) v[j] = src[i0 + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + 64 * j < n4) *reinterpret_cast<lds_f4 *>(ys + 4 * (i0 + 64 * j)) = v[j];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u) {
-            if (!live(u)) continue;
+            if (!live[u]) continue;
             const lds_f *yr = ys + (prow[u] * HW + psp[u]) * kYCols;
-            for (int co = 0; co < Cout; ++co) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                if (!EXACT && co >= Cout) break;
                 float v = 0.0f;
 #pragma unroll
                 for (int tap = 0; tap < KK; ++tap) {
@@ -1161,32 +1196,50 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
             }
         }
     } else {
-        // the block's input -> LDS, then conv1 and the skip path from it
+        // the block's input -> LDS (every value requested before the first is used), then conv1 and the skip path
+        float xin[CI][kThinMaxPos];
+        const float *xr[kThinMaxPos];
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u) {
+            xr[u] = nullptr;
+            if (live[u]) {
+                const long long s = x_rows ? (long long)x_rows[r0 + prow[u]] : (long long)(r0 + prow[u]);
+                if (s >= 0) xr[u] = x + s * ldx + psp[u];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u)
-            if (live(u)) {
-                const float *xr = row_ptr(prow[u]);
-                for (int ci = 0; ci < Cin; ++ci) a_in[ci * P + lane + 64 * u] = xr ? xr[ci * HW + psp[u]] : 0.0f;
-            }
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) xin[ci][u] = (xr[u] && (EXACT || ci < Cin)) ? xr[u][ci * HW] : 0.0f;
+        if (R.conv1_bias)
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+#pragma unroll
+                for (int u = 0; u < kThinMaxPos; ++u)
+                    if ((EXACT || co < Cout) && live[u]) c1[co][u] = R.conv1_bias[co * HW + psp[u]];
+#pragma unroll
+        for (int u = 0; u < kThinMaxPos; ++u)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+                if (live[u] && (EXACT || ci < Cin)) a_in[ci * P + lane + 64 * u] = xin[ci][u];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (R.conv1_bias)  // requested together, before the windows
-#pragma unroll
-            for (int co = 0; co < kThinMaxC; ++co)
-#pragma unroll
-                for (int u = 0; u < kThinMaxPos; ++u)
-                    if (co < Cout && live(u)) c1[co][u] = R.conv1_bias[co * HW + psp[u]];
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u) {
-            if (!live(u)) continue;
-            for (int co = 0; co < Cout; ++co) {
-                c1[co][u] = window(a_in, w1, Cin, co, u, c1[co][u]);
+            if (!live[u]) continue;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                if (!EXACT && co >= Cout) break;
+                c1[co][u] = window(a_in, w1, Cin, CI, co, u, c1[co][u]);
                 float sv = 0.0f;
-                if (down)
-                    for (int ci = 0; ci < Cin; ++ci) sv = fmaf(wd[co * Cin + ci], a_in[ci * P + lane + 64 * u], sv);
-                else
+                if (down) {
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci)
+                        if (EXACT || ci < Cin) sv = fmaf(wd[co * Cin + ci], xin[ci][u], sv);
+                } else {
                     sv = a_in[co * P + lane + 64 * u];  // identity skip (Cin == Cout)
+                }
                 sk[co][u] = sv;
             }
         }
@@ -1200,7 +1253,7 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
         double s = 0.0, q = 0.0;
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u)
-            if (live(u)) {
+            if (live[u]) {
                 const double d = (double)v[u] - pivot;
                 s += d;
                 q += d * d;
@@ -1220,29 +1273,54 @@ k_tower_thin(mz_tower T, const float *__restrict__ x, long long ldx, const int32
         for (int u = 0; u < kThinMaxPos; ++u) v[u] = activate(v[u] * scale + shift, act);
     };
     float *st1 = stats, *st2 = stats ? stats + 2LL * calls * Cout : nullptr, *st3 = stats ? stats + 4LL * calls * Cout : nullptr;
-    for (int co = 0; co < Cout; ++co) {
-        batchnorm(c1[co], 0, R.eps1, R.activation, st1, co);
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (!EXACT && co >= Cout) break;
+        batchnorm(c1[co], 0, R.eps1, R.act, st1, co);
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u)
-            if (live(u)) a_mid[co * P + lane + 64 * u] = c1[co][u];
+            if (live[u]) a_mid[co * P + lane + 64 * u] = c1[co][u];
         if (down) batchnorm(sk[co], 2, R.epsd, MZ_ACT_NONE, st3, co);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // conv2 (Cout -> Cout), its BatchNorm, the skip sum and the activation
-    for (int co = 0; co < Cout; ++co) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (!EXACT && co >= Cout) break;
         float c2[kThinMaxPos];
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) c2[u] = live(u) ? window(a_mid, w2, Cout, co, u, 0.0f) : 0.0f;
+        for (int u = 0; u < kThinMaxPos; ++u) c2[u] = live[u] ? window(a_mid, w2, Cout, CO, co, u, 0.0f) : 0.0f;
         batchnorm(c2, 1, R.eps2, MZ_ACT_NONE, st2, co);
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) {
-            if (!live(u)) continue;
-            const long long dr = y_rows ? (long long)y_rows[r0 + prow[u]] : (long long)(r0 + prow[u]);
-            if (dr >= 0) t_out[dr * ld_t + co * HW + psp[u]] = activate(c2[u] + sk[co][u], R.activation);
-        }
+        for (int u = 0; u < kThinMaxPos; ++u)
+            if (live[u] && drow[u] >= 0) t_out[drow[u] * ld_t + co * HW + psp[u]] = activate(c2[u] + sk[co][u], R.act);
     }
+}
+
+inline ThinBlock thin_block(const mz_tower *T) {
+    const mz_resblock &R = T->block[0];
+    ThinBlock b;
+    b.conv1_w = R.conv1_w;
+    b.conv2_w = R.conv2_w;
+    b.down_w = R.down_w;
+    b.conv1_bias = R.conv1_bias;
+    b.bn[0] = R.bn1_w;
+    b.bn[1] = R.bn1_b;
+    b.bn[2] = R.bn2_w;
+    b.bn[3] = R.bn2_b;
+    b.bn[4] = R.dbn_w;
+    b.bn[5] = R.dbn_b;
+    b.eps1 = R.eps1;
+    b.eps2 = R.eps2;
+    b.epsd = R.epsd;
+    b.cin = R.in_channels;
+    b.cout = R.out_channels;
+    b.act = R.activation;
+    b.H = T->H;
+    b.W = T->W;
+    return b;
 }
 
 // ------------------------------------------------------------------ fc_merge + first convolution of g in one pass
@@ -1680,10 +1758,14 @@ int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, in
     if (ld_t < (long long)R.out_channels * hw) return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: ld_t below the block's values per row");
     const int calls = B / group, per_wg = kThinT / 64;
     const size_t lds = ((size_t)per_wg * 2 * kThinMaxC * kThinMaxPos * 64 + kThinW + (size_t)per_wg * group * hw * kYCols) * sizeof(float);
-    MZ_TRY(allow_lds(k_tower_thin<true, 3>, lds, "k_tower_thin"));
-    hipLaunchKernelGGL((k_tower_thin<true, 3>), dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds, (hipStream_t)stream, *h_tower, Y,
-                       (long long)hw * kYCols, nullptr, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
-    return mz::check_launch("k_tower_thin");
+    const ThinBlock tb = thin_block(h_tower);
+    auto launch = [&](auto kernel) {
+        MZ_TRY(allow_lds(kernel, lds, "k_tower_thin"));
+        hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds, (hipStream_t)stream, tb, Y,
+                           (long long)hw * kYCols, nullptr, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
+        return mz::check_launch("k_tower_thin");
+    };
+    return R.out_channels == 3 ? launch(k_tower_thin<true, 3, 3, 3, true>) : launch(k_tower_thin<true, 3, 4, 4, false>);
 }
 
 // Calls from which the one-wave-per-call kernel takes over thin towers: with few calls the general
@@ -1733,12 +1815,14 @@ int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx,
         if (group * hw < 2) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: batch statistics need more than 1 value per channel");
         const int calls = B / group, per_wg = kThinT / 64;
         const size_t lds_thin = ((size_t)per_wg * 2 * kThinMaxC * kThinMaxPos * 64 + kThinW) * sizeof(float);
+        const ThinBlock tb = thin_block(h_tower);
         auto launch_thin = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds_thin, (hipStream_t)stream, *h_tower, x,
+            hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds_thin, (hipStream_t)stream, tb, x,
                                (long long)ldx, x_rows, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
             return mz::check_launch("k_tower_thin");
         };
-        return R.kernel_size == 3 ? launch_thin(k_tower_thin<false, 3>) : launch_thin(k_tower_thin<false, 1>);
+        if (R.kernel_size == 3 && R.in_channels == 3 && R.out_channels == 3) return launch_thin(k_tower_thin<false, 3, 3, 3, true>);
+        return R.kernel_size == 3 ? launch_thin(k_tower_thin<false, 3, 4, 4, false>) : launch_thin(k_tower_thin<false, 1, 4, 4, false>);
     }
     TowerGeom g;
     size_t lds = 0;
