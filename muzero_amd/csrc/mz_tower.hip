@@ -1329,33 +1329,37 @@ inline ThinBlock thin_block(const mz_tower *T) {
 //   Y[position][column] = sum_c Wg[c][column] x[c][position]   (conv1's (channel, tap) pairs + the skip
 // convolution: 32 columns).  Writing z to memory and reading it back is most of the traffic of that
 // path; here a workgroup owns 64 rows and ONE position: it forms z for that position's C = 256 channels
-// (rows of Wm permuted position-major on the host), turns it into x in LDS and multiplies by Wg at
-// once -- only Y, 32 floats per position, leaves the chip.  With `action` NULL every row is expanded
-// with all A actions (the expansion: z is formed once, x and Y per action).
-// Both products on v_mfma_f32_16x16x4_f32 with the packed tiles of mz_wide_pack.
-constexpr int kMcT = 512, kMcRows = 64, kMcC = 256, kMcLdX = kMcC + 4;
+// (rows of Wm permuted position-major on the host), turns it into x and multiplies by Wg at once -- only
+// Y, 32 floats per position, leaves the chip.  With `action` NULL every row is expanded with all A actions
+// (the expansion: z is formed once, x and Y per action).
+// Both products on v_mfma_f32_16x16x4_f32 with the packed tiles of mz_wide_pack.  The merge product is
+// formed TRANSPOSED (weights as the A operand, the rows of t as B): lane l then holds
+// z[row l & 15][channel 4 (l >> 4) + i], which is exactly the A-operand layout of the convolution product
+// over those channels -- x never leaves the registers.  A wave owns 32 channels: its convolution product is
+// a partial sum over them for all 64 rows x 32 columns; the eight partials meet in LDS and are added in
+// wave order.
+constexpr int kMcT = 512, kMcRows = 64, kMcC = 256;
+constexpr int kMcLdP = kYCols + 4;  // row stride of a partial product in LDS: four rows apart land 16 banks apart
+constexpr int kMcMaxKT = 8;         // merge product: at most 128 bottleneck values per row
+constexpr size_t kMcLds = ((size_t)(kMcT / 64) * kMcRows * kMcLdP + kMcRows) * sizeof(float);
 
-constexpr int kMcMaxKT = 8;   // merge product: at most 128 bottleneck values per row
-
-// Two workgroups share a compute unit (128 registers, 67 KB of LDS each): the phases of one -- staging,
-// the merge product, forming x, the convolution product -- are separated by barriers, and the other
-// workgroup's waves fill the matrix pipe meanwhile.  Weights stream from L2 two k-tiles ahead.
+// Two workgroups share a compute unit (128 registers, 74 KB of LDS each): while one waits at a barrier or
+// for its rows, the other's waves fill the matrix pipe.
 __global__ void __launch_bounds__(kMcT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, long long wg_off,
              const float *__restrict__ t, long long ld_t, const int32_t *__restrict__ t_rows, int B,
              const float *__restrict__ table, const int32_t *__restrict__ action, int A, int nA, int HW,
-             float *__restrict__ Y) {
+             float *__restrict__ Y, int skip) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
     const int pos = blockIdx.y, r0 = blockIdx.x * kMcRows;
     const int ldT = KTm * 16 + 4;
-    // x takes the place of the bottleneck rows once z is formed
-    lds_f *Ts = to_lds(smem), *Xs = Ts;
-    lds_i *s_act = to_lds_i(smem + (size_t)kMcRows * kMcLdX);
-    const int ymt = wave >> 1, yn = wave & 1;
+    // the partial products take the place of the bottleneck rows once z is formed
+    lds_f *Ts = to_lds(smem), *Ps = Ts;
+    lds_i *s_act = to_lds_i(smem + (size_t)(kMcT / 64) * kMcRows * kMcLdP);
     const f32x4 *wm = reinterpret_cast<const f32x4 *>(blob + wm_off) + ((long long)(pos * (kMcC / 16) + 2 * wave) * KTm) * 64 + lane;
-    const f32x4 *wg = reinterpret_cast<const f32x4 *>(blob + wg_off) + ((long long)yn * (kMcC / 16)) * 64 + lane;
+    const f32x4 *wg = reinterpret_cast<const f32x4 *>(blob + wg_off) + (long long)(2 * wave) * 64 + lane;
     // the first two k-tiles of this wave's merge weights are on their way while the rows are staged
     f32x4 b0[2] = {wm[0], wm[(long long)KTm * 64]}, b1[2] = {b0[0], b0[1]};
     if (KTm > 1) {
@@ -1373,7 +1377,7 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
 #pragma unroll
             for (int j = 0; j < kMcMaxKT; ++j) {
                 const int k = k0 + 8 * (h * kMcMaxKT + j);
-                v[j] = (row >= 0 && k < Kt) ? t[row * ld_t + k] : 0.0f;
+                v[j] = (row >= 0 && k < Kt && !(skip & 8)) ? t[row * ld_t + k] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < kMcMaxKT; ++j) {
@@ -1387,9 +1391,16 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
         if (action && r0 + tid < B) a = min(max(action[r0 + tid], 0), A - 1);
         s_act[tid] = a;
     }
+    // this wave's convolution weights: channels 32 w .. 32 w + 31 (k-tiles 2 w, 2 w + 1) x both column tiles
+    f32x4 g[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) g[n][c2] = wg[(long long)(c2 * (kMcC / 16) + n) * 64];
     __syncthreads();
 
-    // ---- z for this position: wave w owns channels 32 w .. 32 w + 31 (two column tiles), all four row tiles
+    // ---- z for this position, transposed: wave w owns channels 32 w .. 32 w + 31 (two tiles), all four row tiles;
+    //      acc[mt][n][i] = z[row 16 mt + m][channel 32 w + 16 n + 4 kq + i]
     f32x4 acc[4][2];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -1406,64 +1417,77 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
         f32x4 a4[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) a4[mt] = *reinterpret_cast<const lds_f4 *>(Ts + (mt * 16 + m) * ldT + kt * 16 + 4 * kq);
+        if (!(skip & 1))
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][j], bc[n][j], acc[mt][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n)
+                        acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[n][j], a4[mt][j], acc[mt][n], 0, 0, 0);
     }
+    int act_m[4] = {0, 0, 0, 0};
+    if (action)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) act_m[mt] = s_act[mt * 16 + m];
     __syncthreads();  // every wave has read its rows of t
-    // ---- per action: x = relu(z + table[action]) -> LDS, Y = x Wg; wave w owns Y tile (row tile w / 2, columns 16 (w & 1) ..)
+    // ---- per action: x = relu(z + table[action]) in registers, this wave's part of Y = x Wg, partials added through LDS
+    const int rrow = tid >> 3, rc4 = tid & 7;  // the output piece this thread adds up: row, four columns
     for (int ai = 0; ai < nA; ++ai) {
-        f32x4 g0 = wg[0], g1 = wg[64];  // on their way while x is formed
-        if (action) {
-            // a row's action picks its table row: sixteen values of this lane at a time, requested together
+        f32x4 y[4][2];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float tv[4][4];
+        for (int mt = 0; mt < 4; ++mt) y[mt][0] = y[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 *trow = reinterpret_cast<const f32x4 *>(table + ((long long)ai * HW + pos) * kMcC + 32 * wave + 4 * kq);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        tv[mt][i] = table[((long long)s_act[mt * 16 + 4 * kq + i] * HW + pos) * kMcC + 32 * wave + 16 * n + m];
+        for (int n = 0; n < 2; ++n) {
+            // the table values of this lane's four channels: per row tile where rows carry their own action
+            f32x4 tv[4];
+            if (action) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
+                    tv[mt] = *reinterpret_cast<const f32x4 *>(table + ((long long)act_m[mt] * HW + pos) * kMcC + 32 * wave + 16 * n + 4 * kq);
+            } else {
+                tv[0] = trow[4 * n];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        Xs[(mt * 16 + 4 * kq + i) * kMcLdX + 32 * wave + 16 * n + m] = fmaxf(acc[mt][n][i] + tv[mt][i], 0.0f);
+                for (int mt = 1; mt < 4; ++mt) tv[mt] = tv[0];
             }
-        } else {
-            const float *trow = table + ((long long)ai * HW + pos) * kMcC + 32 * wave + m;
-            const float tv0 = trow[0], tv1 = trow[16];
+            f32x4 x[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lds_f *dst = Xs + (mt * 16 + 4 * kq + i) * kMcLdX + 32 * wave + m;
-                    dst[0] = fmaxf(acc[mt][0][i] + tv0, 0.0f);
-                    dst[16] = fmaxf(acc[mt][1][i] + tv1, 0.0f);
-                }
-        }
-        __syncthreads();
-        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < kMcC / 16; ++kt) {
-            const f32x4 gc = g0;
-            g0 = g1;
-            if (kt + 2 < kMcC / 16) g1 = wg[(long long)(kt + 2) * 64];
-            const f32x4 a4 = *reinterpret_cast<const lds_f4 *>(Xs + (ymt * 16 + m) * kMcLdX + kt * 16 + 4 * kq);
-            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], gc[0], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], gc[1], y1, 0, 0, 0);
-            y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], gc[2], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], gc[3], y1, 0, 0, 0);
-        }
+                for (int i = 0; i < 4; ++i) x[mt][i] = fmaxf(acc[mt][n][i] + tv[mt][i], 0.0f);
+            if (!(skip & 2))
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rg = r0 + ymt * 16 + 4 * kq + i;
-            if (rg < B) Y[(((long long)rg * nA + ai) * HW + pos) * kYCols + 16 * yn + m] = y0[i] + y1[i];
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; ++c2)
+                            y[mt][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][j], g[n][c2][j], y[mt][c2], 0, 0, 0);
         }
+        // y[mt][c2][i] = partial Y[row 16 mt + 4 kq + i][column 16 c2 + m]
+        lds_f *pw = Ps + (size_t)wave * kMcRows * kMcLdP;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[(mt * 16 + 4 * kq + i) * kMcLdP + 16 * c2 + m] = y[mt][c2][i];
         __syncthreads();
+        {
+            f32x4 sum = *reinterpret_cast<const lds_f4 *>(Ps + rrow * kMcLdP + 4 * rc4);
+#pragma unroll
+            for (int w = 1; w < kMcT / 64; ++w) {
+                const f32x4 v = *reinterpret_cast<const lds_f4 *>(Ps + ((size_t)w * kMcRows + rrow) * kMcLdP + 4 * rc4);
+                sum.x += v.x;
+                sum.y += v.y;
+                sum.z += v.z;
+                sum.w += v.w;
+            }
+            const int rg = r0 + rrow;
+            if (rg < B) *reinterpret_cast<f32x4 *>(Y + (((long long)rg * nA + ai) * HW + pos) * kYCols + 4 * rc4) = sum;
+        }
+        if (ai + 1 < nA) __syncthreads();
     }
 }
 
@@ -1732,11 +1756,15 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
         return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: the convolution product must map %d channels to at most %d columns", C, kYCols);
     if (HW > 65535) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: more than 65535 positions");
     const int KTm = h_merge->Kp >> 4;
-    const size_t lds = ((size_t)kMcRows * kMcLdX + kMcRows) * sizeof(float);  // KTm * 16 + 4 <= kMcLdX: the rows of t fit the same area
+    const size_t lds = kMcLds;  // the rows of t (64 x at most 132 floats) fit the area of the partial products
     MZ_TRY(allow_lds(k_merge_conv, lds, "k_merge_conv"));
+    static const int skip = [] {
+        const char *e = getenv("MZ_MC_SKIP");  // timing aid: leaves out parts of the kernel (results are then meaningless)
+        return e ? atoi(e) : 0;
+    }();
     hipLaunchKernelGGL(k_merge_conv, dim3((B + kMcRows - 1) / kMcRows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
                        (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B, table,
-                       action, A, action ? 1 : A, HW, Y);
+                       action, A, action ? 1 : A, HW, Y, skip);
     return mz::check_launch("k_merge_conv");
 }
 
