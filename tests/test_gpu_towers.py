@@ -588,17 +588,14 @@ def test_tower_search_at_benchmarked_size():
     nets = TowerNetworks(g, f, fuse_merge_conv=False)
     fused = TowerNetworks(g, f)   # fc_merge + the first convolution of g's tower in one kernel (searches without stored latents)
     assert fused.fused_g and not nets.fused_g
-    rng = np.random.default_rng(17)
-    lat = rng.standard_normal((G, D)).astype(np.float32)
-    eta = rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)
-    rand = rng.integers(0, A, size=(G, S + 1)).astype(np.int32)
-    to_play = np.zeros(G, np.int8)   # single-player simulators (CarRacing): to_play 0
-    dev = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
-    pools = {}
-    for keep in (True, False, "fused"):
-        mcts = BatchedMCTS(fused if keep == "fused" else nets, G, S, depth, discount=0.998, noise_frac=0.25,
-                           keep_latents=keep is True)
-        keep_flag = keep is True
+    def searched(networks, G, keep_flag, seed):
+        rng = np.random.default_rng(seed)
+        lat = rng.standard_normal((G, D)).astype(np.float32)
+        eta = rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)
+        rand = rng.integers(0, A, size=(G, S + 1)).astype(np.int32)
+        to_play = np.zeros(G, np.int8)   # single-player simulators (CarRacing): to_play 0
+        dev = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
+        mcts = BatchedMCTS(networks, G, S, depth, discount=0.998, noise_frac=0.25, keep_latents=keep_flag)
         assert mcts.t_pool is not None and mcts.keep_latents == keep_flag, "the bottleneck form is not in use"
         trace = {}
         res = mcts.run(*dev, trace=trace)          # launch by launch (tracing)
@@ -628,28 +625,39 @@ def test_tower_search_at_benchmarked_size():
                 assert torch.equal(getattr(pool, n), want), f"graph replay: {n}"
             assert torch.equal(res2.policy32, res.policy32) and torch.equal(res2.value, res.value)
         assert mcts.replays == 2, "the recorded graph was not used"
-        pools[keep] = dict(prior=prior_stream, reward=reward_stream, rollout=rollout, leaf=leaf, child=child,
-                           latent=pool.latent if keep_flag else None, t_pool=mcts.t_pool.clone())
-        if keep_flag:
-            keep_mcts = mcts   # keeps pool.latent alive for (ii)
+        return dict(prior=prior_stream, reward=reward_stream, rollout=rollout, leaf=leaf, child=child,
+                    latent=pool.latent if keep_flag else None, t_pool=mcts.t_pool.clone(), mcts=mcts)
+
+    pools = {keep: searched(nets, G, keep, 17) for keep in (True, False)}
+    keep_mcts = pools[True]["mcts"]   # keeps pool.latent alive for (ii)
+    pools[False].pop("mcts")
     # storing the latents or not changes nothing the search computes
     for n in ("prior", "reward", "rollout", "leaf", "child"):
         assert np.array_equal(pools[True][n], pools[False][n]), n
     assert torch.equal(pools[True]["t_pool"], pools[False]["t_pool"])
-    # the fused form of g computes the same numbers in another order: wherever a tree's descents agree,
-    # its streams do to 1e-5 of their scale, and a tree's first disagreeing descent is a near-tie
-    same = np.array([np.array_equal(pools["fused"]["leaf"][gi], pools[False]["leaf"][gi]) and
-                     np.array_equal(pools["fused"]["child"][gi], pools[False]["child"][gi]) for gi in range(G)])
-    assert same.mean() >= 0.9, f"only {int(same.sum())} of {G} trees took the same descents"
+
+    # The kernels used from a thousand reference calls per launch on (one wave per call for the small blocks;
+    # fc_merge + the first convolution of g in one kernel) compute the same numbers in another order: at that
+    # size, once with the separate kernels and once fused, each run checked as above; wherever a tree's descents
+    # agree its streams do to 1e-5 of their scale, and a tree's first disagreeing descent is a near-tie.
+    G2 = 1024
+    assert fused.fuse_min_rows <= G2
+    plain_big = searched(nets, G2, False, 18)
+    fused_big = searched(fused, G2, False, 18)
+    same = np.array([np.array_equal(fused_big["leaf"][gi], plain_big["leaf"][gi]) and
+                     np.array_equal(fused_big["child"][gi], plain_big["child"][gi]) for gi in range(G2)])
+    assert same.mean() >= 0.9, f"only {int(same.sum())} of {G2} trees took the same descents"
     for n in ("prior", "reward", "rollout"):
-        a, b = pools["fused"][n][same], pools[False][n][same]
+        a, b = fused_big[n][same], plain_big[n][same]
+        assert not np.array_equal(a, b), "the fused kernels were not used"
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=max(1e-5 * float(np.abs(b).max()), TOL["atol"]), err_msg=n)
     for gi in np.flatnonzero(~same):
-        first = int(np.flatnonzero((pools["fused"]["leaf"][gi] != pools[False]["leaf"][gi]) |
-                                   (pools["fused"]["child"][gi] != pools[False]["child"][gi]))[0])
+        first = int(np.flatnonzero((fused_big["leaf"][gi] != plain_big["leaf"][gi]) |
+                                   (fused_big["child"][gi] != plain_big["child"][gi]))[0])
         for n in ("prior", "reward"):   # everything computed before the first differing descent agrees
-            a, b = pools["fused"][n][gi, :first + 1], pools[False][n][gi, :first + 1]
+            a, b = fused_big[n][gi, :first + 1], plain_big[n][gi, :first + 1]
             np.testing.assert_allclose(a, b, rtol=1e-5, atol=max(1e-5 * float(np.abs(b).max()), TOL["atol"]), err_msg=f"{n} tree {gi}")
+    del plain_big, fused_big
 
     # ---- (ii) the torch modules, one reference call at a time, on the GPU (rocBLAS / MIOpen fp32)
     gt, ft = g.cuda(), f.cuda()
@@ -686,6 +694,109 @@ def test_tower_search_at_benchmarked_size():
                 close(P["rollout"][gi, s], torch.stack([r[0, 0], v[0, 0]]), f"rollout tree {gi} sim {s}")
     assert near_ties <= 2
     g.cpu(), f.cpu()
+
+
+def test_one_wave_per_call_kernel_matches_the_general_kernel():
+    """Small blocks (f's tower on the bottleneck values: 3 -> 3 channels on 6 x 6) run on a one-wave-per-call kernel
+    from 1024 reference calls per launch on; below, on the general tower kernel.  Same rows through both (one launch
+    of 2048 calls against four launches of 512): outputs and exported batch statistics agree to 1e-6 of scale (the
+    two kernels add the window in different orders), for batch-size-1 calls and for calls of 5 rows."""
+    import ctypes as C
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    g, f = build_nets((256, 6, 6), 5)
+    with torch.no_grad():
+        for m in f.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    nets = TowerNetworks(g, f)
+    tower = nets.tower_f_t
+    assert tower is not None and tower.n_blocks == 1
+    lib = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for group, calls in ((1, 2048), (5, 1024)):
+        B = calls * group
+        src = torch.randn(B + 7, 108, device="cuda", generator=gen)
+        rows = torch.randperm(B + 7, device="cuda", generator=gen)[:B].to(torch.int32)
+        if group > 1:   # the rows of a call share one source latent in the expansion; here they simply differ
+            rows = rows.contiguous()
+        out_rows = torch.randperm(B, device="cuda", generator=gen).to(torch.int32)
+        n_stats = lib.mz_tower_stats_floats(C.byref(tower), calls)
+
+        def run(chunk_calls):
+            out = torch.zeros(B, 108, device="cuda")
+            stats = []
+            for c0 in range(0, calls, chunk_calls):
+                r0, nb = c0 * group, chunk_calls * group
+                st_c = torch.zeros(lib.mz_tower_stats_floats(C.byref(tower), chunk_calls), device="cuda")
+                _hip.check(lib.mz_tower_forward_stats(C.byref(tower), ptr(src), 108, ptr(rows[r0:r0 + nb].contiguous()), None, 0, None,
+                                                      None, 0, ptr(out_rows[r0:r0 + nb].contiguous()), ptr(out), 108, nb, group,
+                                                      ptr(st_c), st), "mz_tower_forward_stats")
+                stats.append(st_c.view(-1, 2, chunk_calls, 3))   # [layer][mean | variance][call][channel]
+            torch.cuda.synchronize()
+            return out, torch.cat(stats, dim=2)
+
+        thin, thin_stats = run(calls)
+        general, general_stats = run(512 // (2 if group > 1 else 1))
+        assert thin_stats.numel() == n_stats
+        scale = float(general.abs().max())
+        assert float((thin - general).abs().max()) <= 1e-6 * scale, (group, float((thin - general).abs().max()), scale)
+        np.testing.assert_allclose(thin_stats.cpu().numpy(), general_stats.cpu().numpy(), rtol=1e-5, atol=1e-7)
+        assert not torch.equal(thin, torch.zeros_like(thin))
+
+
+def test_running_statistics_through_the_fused_form():
+    """track_running_stats with fc_merge + the first convolution of g in one kernel: after an expansion launch
+    (1024 calls of 5 rows) and a rollout-step launch (1024 calls of 1 row) the BatchNorm buffers written back into
+    the torch modules equal those the separate kernels leave, to 1e-5 (both export every call's statistics and run
+    the same momentum chain in call order)."""
+    import copy
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    A, calls = 5, 1024
+    g1, f1 = build_nets((256, 6, 6), A)
+    with torch.no_grad():
+        for m in g1.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    g2, f2 = copy.deepcopy(g1), copy.deepcopy(f1)
+    plain = TowerNetworks(g1, f1, track_running_stats=True, fuse_merge_conv=False)
+    fused = TowerNetworks(g2, f2, track_running_stats=True)
+    assert fused.fused_g and fused.fuse_min_rows <= calls
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    t_src = torch.randn(calls + 3, 108, device="cuda", generator=gen)
+    rows = torch.randperm(calls + 3, device="cuda", generator=gen)[:calls].to(torch.int32)
+    act = torch.randint(0, A, (calls,), device="cuda", generator=gen).to(torch.int32)
+    outs = []
+    for nets in (plain, fused):
+        t_out = torch.zeros(calls * A, 108, device="cuda")
+        reward = torch.zeros(calls * A, device="cuda")
+        rows_rep = rows.repeat_interleave(A).contiguous()
+        nets.dynamics(None, calls * A, rows=rows_rep, action=None, t_in=(t_src, rows_rep), t_out=t_out, reward=reward,
+                      want_latent=False)
+        t_step = torch.zeros(calls, 108, device="cuda")
+        r_step = torch.zeros(calls, device="cuda")
+        nets.dynamics(None, calls, rows=rows, action=act, t_in=(t_src, rows), t_out=t_step, reward=r_step, want_latent=False)
+        nets.sync_running_stats()
+        torch.cuda.synchronize()
+        outs.append((t_out, reward, t_step, r_step))
+    for a, b, what in zip(outs[0], outs[1], ("expansion t", "expansion reward", "step t", "step reward")):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * scale, what
+        assert not torch.equal(a, b) or "reward" in what, "the fused kernels were not used"
+    checked = 0
+    for (n1, m1), (_, m2) in zip(g1.named_modules(), g2.named_modules()):
+        if isinstance(m1, torch.nn.BatchNorm2d):
+            assert int(m1.num_batches_tracked) == int(m2.num_batches_tracked) == 2 * calls, n1
+            np.testing.assert_allclose(m2.running_mean.cpu().numpy(), m1.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n1)
+            np.testing.assert_allclose(m2.running_var.cpu().numpy(), m1.running_var.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=n1)
+            checked += 1
+    assert checked >= 3
 
 
 @pytest.mark.parametrize("ni,ti", TREES[:2])
