@@ -58,8 +58,12 @@ def test_recorded_step_equals_eager_step(opt_name):
         torch.cuda.synchronize()
         assert abs(float(loss_r) - loss_e) <= 1e-6 * abs(loss_e)
         torch.testing.assert_close(per_r.cpu(), per_e, rtol=1e-6, atol=1e-7)
+    # Adam divides by sqrt(v): an element whose gradient is small beside its summands carries the
+    # BLAS summation-order difference between capture and eager execution at the scale of a step
+    # (lr = 1e-3), so its bound is 1e-3 of one step; SGD keeps the tight bound
+    atol = 1e-6 if opt_name == "adam" else 1e-8
     for p, q in zip(pa, pb):
-        torch.testing.assert_close(p, q, rtol=1e-6, atol=1e-8)
+        torch.testing.assert_close(p, q, rtol=1e-6, atol=atol)
     assert not torch.equal(pb[0], before[0])
     # a batch of zero-weight windows only (every draw was an episode too short for a window): the
     # recorded step leaves finite, unchanged weights, as the eager step (which skips the update) does
