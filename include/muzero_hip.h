@@ -601,6 +601,14 @@ int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx,
                            int64_t ldy, const int32_t *y_rows, float *t_out, int64_t ld_t, int32_t B,
                            int32_t group, float *bn_stats, void *stream);
 
+/* Kernel choice of mz_tower_forward(_stats) for a tower of one block on at most 4 channels whose caller
+ * wants the block output only (f on the bottleneck values, neural_network.py:234-262 through the folded
+ * res_final): from `calls` reference calls per launch on, one wavefront evaluates a call instead of one
+ * workgroup.  Default 1 (always).  Sets the threshold unless new_value < 0; returns the previous one.  Both
+ * kernels compute the same block (results agree to 1e-6 of scale: the window sums run in another order);
+ * no counterpart in the reference, a tuning and cross-checking knob only. */
+int mz_tower_thin_min_calls(int32_t new_value);
+
 /* g on the bottleneck values t of its input latent, up to the first matrix product of its tower, without
  * the C*H*W-wide intermediate in memory (neural_network.py:168-182: fc_merge, reshape, the first
  * ResBlock's conv1 and skip convolution).  h_merge: the latent half of fc_merge composed with the previous

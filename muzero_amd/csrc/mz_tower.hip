@@ -1045,9 +1045,18 @@ k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long l
 // 3 -> 3 channels with pre-multiplied weights; the tail of g once its 256 -> 3 convolution has been
 // taken as a matrix product): a few thousand multiply-adds per call.  The general kernel spends a
 // workgroup and a dozen barriers on that; here ONE WAVE owns a call -- its positions sit in the lanes
-// (up to 4 per lane), every reduction is a wave reduction, the activations go through a private
-// slice of LDS only for the neighbour reads of the 3 x 3 windows, and weights are wave-uniform scalar
-// loads.  Four calls per 256-thread workgroup, no workgroup barrier.
+// (up to 4 per lane), every reduction is a wave reduction, and there is no workgroup barrier at all.
+// The kernel is bound by the instructions a wave issues, so it is written to issue few:
+//   * activations go through a private slice of LDS position-major, the (at most 4) channels of a
+//     position in one 16-byte cell, followed by one cell of zeros: a tap that falls outside the image
+//     names the zero cell, so the nine reads of a 3 x 3 window are unconditional 16-byte reads that
+//     serve every channel (no per-tap exec masking, 9 reads instead of 27-36 per window);
+//   * weights and BatchNorm parameters are wave-uniform: read through the scalar cache straight into
+//     scalar operands of the multiply-adds (nothing staged in LDS);
+//   * the float64 tail of a BatchNorm (two divisions, a square root, a reciprocal) is evaluated once
+//     for all channels of a layer pair, channel c in lane c, instead of once per channel in every
+//     lane; the results return to scalar registers by lane reads.
+// Four calls per 256-thread workgroup.
 //
 // FROM_Y: the input rows are not the block's input but the products
 //   Y[position][column] = sum_ci W[ci][column] x[ci][position],  column = (output channel, tap) pairs
@@ -1056,8 +1065,16 @@ k_tower_packed(mz_tower T, TowerGeom G, const float *__restrict__ x, long long l
 constexpr int kThinMaxC = 4, kThinMaxPos = 4;   // channels; positions per lane (P <= 256)
 constexpr int kThinT = 256;
 constexpr int kYCols = 32;
-
-constexpr int kThinW = 2 * kThinMaxC * kThinMaxC * 9 + kThinMaxC * kThinMaxC + 6 * kThinMaxC;  // staged: conv1, conv2, skip, BatchNorm
+// LDS floats of one wave (= one call): one activation buffer of P + 1 four-channel cells for conv2's input, a
+// second one for the block's input unless the rows are products (FROM_Y), which take (P + 1) x 32 floats instead.
+inline size_t thin_wave_floats(bool from_y, int P) {
+    const size_t cells = (size_t)(P + 1) * kThinMaxC;
+    return from_y ? cells + (size_t)(P + 1) * kYCols : 2 * cells;
+}
+// Workgroups of four waves while four calls' LDS lets four workgroups share a compute unit, else one wave
+// per workgroup (no workgroup barrier anywhere, so the size is free): the expansion's 180 positions x 32
+// products are 26 KB per call.
+inline int thin_threads(size_t wave_floats) { return 4 * wave_floats * sizeof(float) <= 40 * 1024 ? kThinT : 64; }
 
 // What the thin kernel needs of a block: a handful of pointers and numbers (passing the whole mz_tower
 // would make every field a separate load from the argument segment, each with its own wait).
@@ -1067,6 +1084,42 @@ struct ThinBlock {
     float eps1, eps2, epsd;
     int cin, cout, act, H, W;
 };
+
+// The float64 tail of N BatchNorm channels at once: lane c < N evaluates channel c (the same operations
+// in the same order as one channel at a time), scale / shift come back as wave-uniform values.
+// s, q: sums of the deviations from `pivot` and of their squares over the call's P values; lane c < N
+// also stores the channel's mean and biased variance to mean_dst / var_dst (per-lane addresses; NULL: no export).
+template <int N>
+__device__ __forceinline__ void thin_bn_tail(const double (&s)[N], const double (&q)[N], const float (&pivot)[N],
+                                             const float (&gamma)[N], const float (&beta)[N], const float (&eps)[N], int P,
+                                             float *mean_dst, float *var_dst, float (&scale)[N], float (&shift)[N]) {
+    const int lane = threadIdx.x & 63;
+    double S = s[0], Q = q[0];
+    float pv = pivot[0], ga = gamma[0], be = beta[0], ep = eps[0];
+#pragma unroll
+    for (int c = 1; c < N; ++c) {
+        const bool me = lane == c;
+        S = me ? s[c] : S;
+        Q = me ? q[c] : Q;
+        pv = me ? pivot[c] : pv;
+        ga = me ? gamma[c] : ga;
+        be = me ? beta[c] : be;
+        ep = me ? eps[c] : ep;
+    }
+    const double ds = S / P, mean = (double)pv + ds;
+    const double var = fmax(Q / P - ds * ds, 0.0);
+    const double invstd = 1.0 / sqrt(var + (double)ep);
+    const float sc = (float)((double)ga * invstd), sh = (float)((double)be - mean * (double)ga * invstd);
+    if (mean_dst != nullptr && lane < N) {
+        *mean_dst = (float)mean;
+        *var_dst = (float)var;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        scale[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), c));
+        shift[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sh), c));
+    }
+}
 
 // CI / CO: compile-time bounds of the channel counts (the shipped towers: exactly 3 -> 3, EXACT; other
 // shapes run with CI = CO = 4 and guards), so that the per-channel values live in registers and every
@@ -1082,37 +1135,16 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
     const int H = R.H, W = R.W, HW = H * W, P = group * HW;
     const int Cin = EXACT ? CI : R.cin, Cout = EXACT ? CO : R.cout;
     const bool down = R.down_w != nullptr;
-    // the block's weights: staged once per workgroup, read as LDS broadcasts
-    lds_f *w1 = to_lds(smem), *w2 = w1 + kThinMaxC * kThinMaxC * 9, *wd = w2 + kThinMaxC * kThinMaxC * 9;
-    lds_f *bnp = wd + kThinMaxC * kThinMaxC;  // [bn1_w, bn1_b, bn2_w, bn2_b, dbn_w, dbn_b][kThinMaxC]
-    {
-        const int i = threadIdx.x;
-        float v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
-        if (!FROM_Y && i < Cout * Cin * KK) v1 = R.conv1_w[i];
-        if (i < Cout * Cout * KK) v2 = R.conv2_w[i];
-        if (!FROM_Y && down && i < Cout * Cin) v3 = R.down_w[i];
-        if (i < 6 * kThinMaxC) {
-            const float *src = R.bn[i / kThinMaxC];
-            if (src && i % kThinMaxC < Cout) v4 = src[i % kThinMaxC];
-        }
-        if (i < kThinMaxC * kThinMaxC * 9) {
-            w1[i] = v1;
-            w2[i] = v2;
-        }
-        if (i < kThinMaxC * kThinMaxC) wd[i] = v3;
-        if (i < 6 * kThinMaxC) bnp[i] = v4;
-    }
-    __syncthreads();
-    const int call = blockIdx.x * (kThinT / 64) + wave;
-    if (call >= calls) return;  // no workgroup barrier below
-    lds_f *buf = to_lds(smem) + kThinW + wave * (2 * kThinMaxC * kThinMaxPos * 64);
-    lds_f *a_in = buf, *a_mid = buf + kThinMaxC * kThinMaxPos * 64;  // [channel][P]
+    const int call = blockIdx.x * ((int)blockDim.x >> 6) + wave;
+    if (call >= calls) return;  // no workgroup barrier anywhere
+    const int cells = (P + 1) * kThinMaxC;
+    lds_f *a_mid = to_lds(smem) + wave * (FROM_Y ? cells + (P + 1) * kYCols : 2 * cells), *a_in = a_mid + cells;  // [P + 1][4] each
     const int r0 = call * group;
-    const int npos = (P + 63) >> 6;
+    const int npos = (P + 63) >> 6;  // position slots in use (wave-uniform)
+    cst_f *w1 = as_constant(R.conv1_w), *w2 = as_constant(R.conv2_w), *wd = as_constant(R.down_w);
 
-    // this lane's positions: row of the call, position in the image, which taps stay inside the image
-    int prow[kThinMaxPos], psp[kThinMaxPos];
-    unsigned inside[kThinMaxPos];
+    // this lane's positions: row of the call, position in the image, the cell each tap reads (P: the zero cell)
+    int prow[kThinMaxPos], psp[kThinMaxPos], cell[kThinMaxPos][KK];
     bool live[kThinMaxPos];
 #pragma unroll
     for (int u = 0; u < kThinMaxPos; ++u) {
@@ -1121,28 +1153,32 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
         prow[u] = p / HW;
         psp[u] = p - prow[u] * HW;
         const int py = psp[u] / W, px = psp[u] - py * W;
-        inside[u] = 0;
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int yy = py + tap / K - PAD, xx = px + tap % K - PAD;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) inside[u] |= 1u << tap;
+            cell[u][tap] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? p + (tap / K - PAD) * W + (tap % K - PAD) : P;
         }
     }
-    // sum over the taps and input channels of a K x K window: src[ci][P] in LDS, weights w[(co * n_ci + ci) * KK + tap]
-    auto window = [&](const lds_f *src, const lds_f *w, int n_ci, int n_ci_max, int co, int u, float v) {
-        const int centre = prow[u] * HW + psp[u];
+    // K x K windows of one position slot for every output channel: src holds 4-channel cells, weights
+    // w[(co * n_ci + ci) * KK + tap]; acc[co] continues the sum (input channels outermost, taps innermost)
+    auto windows = [&](const lds_f *src, cst_f *w, int n_ci, int u, float (&acc)[CO]) {
+        f32x4 a[KK];
 #pragma unroll
-        for (int ci = 0; ci < kThinMaxC; ++ci) {
-            if (ci >= n_ci_max || ci >= n_ci) break;
-            const lds_f *sp = src + ci * P + centre, *wr = w + (co * n_ci + ci) * KK;
+        for (int tap = 0; tap < KK; ++tap) a[tap] = *reinterpret_cast<const lds_f4 *>(src + 4 * cell[u][tap]);
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int off = (tap / K - PAD) * W + (tap % K - PAD);
-                const bool ok = (inside[u] >> tap) & 1;
-                v = fmaf(wr[tap], ok ? sp[ok ? off : 0] : 0.0f, v);
+        for (int co = 0; co < CO; ++co) {
+            if (!EXACT && co >= Cout) break;
+            // one output channel's weights at a time in scalar registers (81 at once would spill them)
+            __builtin_amdgcn_sched_barrier(0);
+            float v = acc[co];
+#pragma unroll
+            for (int ci = 0; ci < kThinMaxC; ++ci) {
+                if (ci >= n_ci) break;
+#pragma unroll
+                for (int tap = 0; tap < KK; ++tap) v = fmaf(w[(co * n_ci + ci) * KK + tap], a[tap][ci], v);
             }
+            acc[co] = v;
         }
-        return v;
     };
 
     float c1[CO][kThinMaxPos], sk[CO][kThinMaxPos];
@@ -1155,12 +1191,13 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
 #pragma unroll
     for (int u = 0; u < kThinMaxPos; ++u)
         drow[u] = live[u] ? (y_rows ? (long long)y_rows[r0 + prow[u]] : (long long)(r0 + prow[u])) : -1;
+    if (lane < (FROM_Y ? 1 : 2) * kThinMaxC) a_mid[(lane < kThinMaxC ? 0 : cells - kThinMaxC) + P * kThinMaxC + lane] = 0.0f;  // the zero cells
 
     if constexpr (FROM_Y) {
         // conv1[co][p] = sum_tap Y[p + offset(tap)][co * KK + tap]; skip[co][p] = Y[p][Cout * KK + co].
-        // The call's rows of Y are contiguous (P x 32 floats): copied to LDS as whole 16-byte pieces, then
-        // every lane picks its windows from there.
-        lds_f *ys = to_lds(smem) + kThinW + (kThinT / 64) * (2 * kThinMaxC * kThinMaxPos * 64) + wave * (P * kYCols);
+        // The call's rows of Y are contiguous (P x 32 floats): copied to LDS as whole 16-byte pieces and
+        // followed by a row of zeros, then every lane picks its windows from there.
+        lds_f *ys = a_mid + cells;
         {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(x + (long long)r0 * ldx);
             const int n4 = P * (kYCols / 4);
@@ -1173,31 +1210,31 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
                 for (int j = 0; j < 8; ++j)
                     if (i0 + 64 * j < n4) *reinterpret_cast<lds_f4 *>(ys + 4 * (i0 + 64 * j)) = v[j];
             }
+            if (lane < kYCols) ys[P * kYCols + lane] = 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u) {
-            if (!live[u]) continue;
-            const lds_f *yr = ys + (prow[u] * HW + psp[u]) * kYCols;
+            if (u >= npos) break;
+            const lds_f *yc = ys + (prow[u] * HW + psp[u]) * kYCols;
+            const lds_f *yt[KK];
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) yt[tap] = ys + cell[u][tap] * kYCols;
 #pragma unroll
             for (int co = 0; co < CO; ++co) {
                 if (!EXACT && co >= Cout) break;
                 float v = 0.0f;
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) {
-                    const int off = (tap / K - PAD) * W + (tap % K - PAD);
-                    const bool ok = (inside[u] >> tap) & 1;
-                    v += ok ? yr[(ok ? off : 0) * kYCols + co * KK + tap] : 0.0f;
-                }
+                for (int tap = 0; tap < KK; ++tap) v += yt[tap][co * KK + tap];
                 c1[co][u] = v;
-                sk[co][u] = yr[Cout * KK + co];
+                sk[co][u] = yc[Cout * KK + co];
             }
         }
     } else {
-        // the block's input -> LDS (every value requested before the first is used), then conv1 and the skip path
-        float xin[CI][kThinMaxPos];
+        // the block's input -> LDS cells (every value requested before the first is used), then conv1 and the skip path
+        float xin[kThinMaxC][kThinMaxPos];
         const float *xr[kThinMaxPos];
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u) {
@@ -1210,7 +1247,8 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u)
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) xin[ci][u] = (xr[u] && (EXACT || ci < Cin)) ? xr[u][ci * HW] : 0.0f;
+            for (int ci = 0; ci < kThinMaxC; ++ci)
+                xin[ci][u] = (ci < CI && xr[u] && (EXACT || ci < Cin)) ? xr[u][ci * HW] : 0.0f;
         if (R.conv1_bias)
 #pragma unroll
             for (int co = 0; co < CO; ++co)
@@ -1219,83 +1257,136 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
                     if ((EXACT || co < Cout) && live[u]) c1[co][u] = R.conv1_bias[co * HW + psp[u]];
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u)
-#pragma unroll
-            for (int ci = 0; ci < CI; ++ci)
-                if (live[u] && (EXACT || ci < Cin)) a_in[ci * P + lane + 64 * u] = xin[ci][u];
+            if (live[u])
+                *reinterpret_cast<lds_f4 *>(a_in + 4 * (lane + 64 * u)) = f32x4{xin[0][u], xin[1][u], xin[2][u], xin[3][u]};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int u = 0; u < kThinMaxPos; ++u) {
-            if (!live[u]) continue;
+            if (u >= npos) break;
+            float acc[CO];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] = c1[co][u];
+            windows(a_in, w1, Cin, u, acc);
 #pragma unroll
             for (int co = 0; co < CO; ++co) {
                 if (!EXACT && co >= Cout) break;
-                c1[co][u] = window(a_in, w1, Cin, CI, co, u, c1[co][u]);
+                c1[co][u] = acc[co];
                 float sv = 0.0f;
                 if (down) {
 #pragma unroll
                     for (int ci = 0; ci < CI; ++ci)
                         if (EXACT || ci < Cin) sv = fmaf(wd[co * Cin + ci], xin[ci][u], sv);
                 } else {
-                    sv = a_in[co * P + lane + 64 * u];  // identity skip (Cin == Cout)
+                    sv = xin[co < kThinMaxC ? co : 0][u];  // identity skip (Cin == Cout)
                 }
                 sk[co][u] = sv;
             }
         }
     }
 
-    // BatchNorm2d over the call's P values of a channel held in v[.] (mean / biased variance in float64
-    // around a pivot, as the general kernel), optional statistics export, then the activation
-    auto batchnorm = [&](float (&v)[kThinMaxPos], int which, float eps, int act, float *st, int c) {
-        const double pivot = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint((double)v[0])),
-                                              __builtin_amdgcn_readfirstlane(__double2loint((double)v[0])));
-        double s = 0.0, q = 0.0;
+    // BatchNorm2d over the call's P values of a channel (mean / biased variance in float64 around a
+    // pivot, as the general kernel): per channel the two wave sums, then thin_bn_tail for all channels at once
+    auto sums = [&](const float (&v)[kThinMaxPos], float &pivot, double &s, double &q) {
+        pivot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0])));
+        s = 0.0, q = 0.0;
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u)
-            if (live[u]) {
-                const double d = (double)v[u] - pivot;
-                s += d;
-                q += d * d;
-            }
+        for (int u = 0; u < kThinMaxPos; ++u) {
+            if (u >= npos) break;
+            const double d = live[u] ? (double)v[u] - (double)pivot : 0.0;
+            s += d;
+            q += d * d;
+        }
         s = wave_total(s);
         q = wave_total(q);
-        const double ds = s / P, mean = pivot + ds;
-        const double var = fmax(q / P - ds * ds, 0.0);
-        const double invstd = 1.0 / sqrt(var + (double)eps);
-        const double ga = (double)bnp[(2 * which) * kThinMaxC + c], be = (double)bnp[(2 * which + 1) * kThinMaxC + c];
-        const float scale = (float)(ga * invstd), shift = (float)(be - mean * ga * invstd);
-        if (st != nullptr && lane == 0) {
-            st[(long long)call * Cout + c] = (float)mean;
-            st[(long long)(calls + call) * Cout + c] = (float)var;
-        }
-#pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) v[u] = activate(v[u] * scale + shift, act);
     };
     float *st1 = stats, *st2 = stats ? stats + 2LL * calls * Cout : nullptr, *st3 = stats ? stats + 4LL * calls * Cout : nullptr;
+    {   // bn1 (+ activation) and the skip path's BatchNorm: 2 * CO channels in one tail
+        constexpr int N = 2 * CO;
+        double s[N], q[N];
+        float pivot[N], gamma[N], beta[N], eps[N], scale[N], shift[N];
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        if (!EXACT && co >= Cout) break;
-        batchnorm(c1[co], 0, R.eps1, R.act, st1, co);
+        for (int c = 0; c < N; ++c) {
+            s[c] = q[c] = 0.0;
+            pivot[c] = gamma[c] = beta[c] = 0.0f;
+            eps[c] = 1.0f;
+        }
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u)
-            if (live[u]) a_mid[co * P + lane + 64 * u] = c1[co][u];
-        if (down) batchnorm(sk[co], 2, R.epsd, MZ_ACT_NONE, st3, co);
+        for (int co = 0; co < CO; ++co) {
+            if (!EXACT && co >= Cout) break;
+            sums(c1[co], pivot[co], s[co], q[co]);
+            gamma[co] = as_constant(R.bn[0])[co], beta[co] = as_constant(R.bn[1])[co], eps[co] = R.eps1;
+            if (down) {
+                sums(sk[co], pivot[CO + co], s[CO + co], q[CO + co]);
+                gamma[CO + co] = as_constant(R.bn[4])[co], beta[CO + co] = as_constant(R.bn[5])[co], eps[CO + co] = R.epsd;
+            }
+        }
+        float *mean_dst = nullptr, *var_dst = nullptr;
+        if (stats != nullptr) {
+            const int c = lane < CO ? lane : lane - CO;
+            float *st = lane < CO ? st1 : st3;
+            if (c < Cout && (lane < CO || down)) {
+                mean_dst = st + (long long)call * Cout + c;
+                var_dst = st + (long long)(calls + call) * Cout + c;
+            }
+        }
+        thin_bn_tail<N>(s, q, pivot, gamma, beta, eps, P, mean_dst, var_dst, scale, shift);
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            if (!EXACT && co >= Cout) break;
+#pragma unroll
+            for (int u = 0; u < kThinMaxPos; ++u) {
+                c1[co][u] = activate(c1[co][u] * scale[co] + shift[co], R.act);
+                if (down) sk[co][u] = sk[co][u] * scale[CO + co] + shift[CO + co];
+            }
+        }
     }
+#pragma unroll
+    for (int u = 0; u < kThinMaxPos; ++u)
+        if (live[u])
+            *reinterpret_cast<lds_f4 *>(a_mid + 4 * (lane + 64 * u)) =
+                f32x4{c1[0][u], CO > 1 ? c1[CO > 1 ? 1 : 0][u] : 0.0f, CO > 2 ? c1[CO > 2 ? 2 : 0][u] : 0.0f, CO > 3 ? c1[CO > 3 ? 3 : 0][u] : 0.0f};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // conv2 (Cout -> Cout), its BatchNorm, the skip sum and the activation
+    float c2[CO][kThinMaxPos];
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        if (!EXACT && co >= Cout) break;
-        float c2[kThinMaxPos];
+    for (int u = 0; u < kThinMaxPos; ++u) {
+        float acc[CO];
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) c2[u] = live[u] ? window(a_mid, w2, Cout, CO, co, u, 0.0f) : 0.0f;
-        batchnorm(c2, 1, R.eps2, MZ_ACT_NONE, st2, co);
+        for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+        if (u < npos) windows(a_mid, w2, Cout, u, acc);
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u)
-            if (live[u] && drow[u] >= 0) t_out[drow[u] * ld_t + co * HW + psp[u]] = activate(c2[u] + sk[co][u], R.act);
+        for (int co = 0; co < CO; ++co) c2[co][u] = acc[co];
+    }
+    {
+        double s[CO], q[CO];
+        float pivot[CO], gamma[CO], beta[CO], eps[CO], scale[CO], shift[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            s[co] = q[co] = 0.0;
+            pivot[co] = gamma[co] = beta[co] = 0.0f;
+            eps[co] = 1.0f;
+            if (!EXACT && co >= Cout) continue;
+            sums(c2[co], pivot[co], s[co], q[co]);
+            gamma[co] = as_constant(R.bn[2])[co], beta[co] = as_constant(R.bn[3])[co], eps[co] = R.eps2;
+        }
+        float *mean_dst = nullptr, *var_dst = nullptr;
+        if (stats != nullptr && lane < Cout) {
+            mean_dst = st2 + (long long)call * Cout + lane;
+            var_dst = st2 + (long long)(calls + call) * Cout + lane;
+        }
+        thin_bn_tail<CO>(s, q, pivot, gamma, beta, eps, P, mean_dst, var_dst, scale, shift);
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            if (!EXACT && co >= Cout) break;
+#pragma unroll
+            for (int u = 0; u < kThinMaxPos; ++u)
+                if (live[u] && drow[u] >= 0)
+                    t_out[drow[u] * ld_t + co * HW + psp[u]] = activate((c2[co][u] * scale[co] + shift[co]) + sk[co][u], R.act);
+        }
     }
 }
 
@@ -1784,27 +1875,34 @@ int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, in
     if ((long long)group * hw > 64 * kThinMaxPos || group * hw < 2)
         return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: %d positions per call (2 .. %d)", group * hw, 64 * kThinMaxPos);
     if (ld_t < (long long)R.out_channels * hw) return mz::fail(MZ_ERR_ARG, "mz_tower_tail_forward: ld_t below the block's values per row");
-    const int calls = B / group, per_wg = kThinT / 64;
-    const size_t lds = ((size_t)per_wg * 2 * kThinMaxC * kThinMaxPos * 64 + kThinW + (size_t)per_wg * group * hw * kYCols) * sizeof(float);
+    const size_t wave_floats = thin_wave_floats(true, group * hw);
+    const int calls = B / group, threads = thin_threads(wave_floats), per_wg = threads / 64;
+    const size_t lds = per_wg * wave_floats * sizeof(float);
     const ThinBlock tb = thin_block(h_tower);
     auto launch = [&](auto kernel) {
         MZ_TRY(allow_lds(kernel, lds, "k_tower_thin"));
-        hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds, (hipStream_t)stream, tb, Y,
+        hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(threads), lds, (hipStream_t)stream, tb, Y,
                            (long long)hw * kYCols, nullptr, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
         return mz::check_launch("k_tower_thin");
     };
     return R.out_channels == 3 ? launch(k_tower_thin<true, 3, 3, 3, true>) : launch(k_tower_thin<true, 3, 4, 4, false>);
 }
 
-// Calls from which the one-wave-per-call kernel takes over thin towers: with few calls the general
-// kernel's workgroup per call has the shorter chain (11-14 us against 18-27 us at 256 calls), with
-// thousands the thin kernel's throughput wins (28 us against 38-147 us at 4096 calls).
-static int thin_min_calls() {
-    static const int n = [] {
-        const char *e = getenv("MZ_TOWER_THIN_MIN_CALLS");  // tuning aid
-        return e ? atoi(e) : 1024;
-    }();
-    return n;
+// Calls per launch from which the one-wave-per-call kernel takes over thin towers.  It is as fast as the
+// general kernel's workgroup per call at a few hundred calls (11-16 us against 12-14 us at 256) and several
+// times faster at thousands (25 us against 38-147 us at 4096), so the default is "always"; the threshold
+// remains as a knob (environment variable at load time, mz_tower_thin_min_calls at run time) so that the
+// general kernel can be run on the same rows.
+static int g_thin_min_calls = [] {
+    const char *e = getenv("MZ_TOWER_THIN_MIN_CALLS");
+    return e ? atoi(e) : 1;
+}();
+static int thin_min_calls() { return g_thin_min_calls; }
+
+int mz_tower_thin_min_calls(int32_t new_value) {
+    const int old = g_thin_min_calls;
+    if (new_value >= 0) g_thin_min_calls = new_value;
+    return old;
 }
 
 int64_t mz_tower_stats_floats(const mz_tower *h_tower, int32_t calls) {
@@ -1841,11 +1939,12 @@ int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx,
         if (R.activation < MZ_ACT_NONE || R.activation > MZ_ACT_SIGMOID)
             return mz::fail(MZ_ERR_ARG, "mz_tower_forward: block 0 has unsupported activation %d", R.activation);
         if (group * hw < 2) return mz::fail(MZ_ERR_ARG, "mz_tower_forward: batch statistics need more than 1 value per channel");
-        const int calls = B / group, per_wg = kThinT / 64;
-        const size_t lds_thin = ((size_t)per_wg * 2 * kThinMaxC * kThinMaxPos * 64 + kThinW) * sizeof(float);
+        const size_t wave_floats = thin_wave_floats(false, group * hw);
+        const int calls = B / group, threads = thin_threads(wave_floats), per_wg = threads / 64;
+        const size_t lds_thin = per_wg * wave_floats * sizeof(float);
         const ThinBlock tb = thin_block(h_tower);
         auto launch_thin = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(kThinT), lds_thin, (hipStream_t)stream, tb, x,
+            hipLaunchKernelGGL(kernel, dim3((calls + per_wg - 1) / per_wg), dim3(threads), lds_thin, (hipStream_t)stream, tb, x,
                                (long long)ldx, x_rows, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
             return mz::check_launch("k_tower_thin");
         };

@@ -697,10 +697,11 @@ def test_tower_search_at_benchmarked_size():
 
 
 def test_one_wave_per_call_kernel_matches_the_general_kernel():
-    """Small blocks (f's tower on the bottleneck values: 3 -> 3 channels on 6 x 6) run on a one-wave-per-call kernel
-    from 1024 reference calls per launch on; below, on the general tower kernel.  Same rows through both (one launch
-    of 2048 calls against four launches of 512): outputs and exported batch statistics agree to 1e-6 of scale (the
-    two kernels add the window in different orders), for batch-size-1 calls and for calls of 5 rows."""
+    """Small blocks (f's tower on the bottleneck values: 3 -> 3 channels on 6 x 6) run on a one-wave-per-call kernel;
+    mz_tower_thin_min_calls moves the call count from which it is used, so the general tower kernel can take the
+    same rows (one launch of 2048 calls against four launches of 512 with the threshold above them): outputs and
+    exported batch statistics agree to 1e-6 of scale (the two kernels add the window in different orders), for
+    batch-size-1 calls and for calls of 5 rows; a handful of calls (3, and 1) go through the one-wave kernel too."""
     import ctypes as C
     from muzero_amd import _hip
     from muzero_amd._hip import ptr
@@ -727,10 +728,10 @@ def test_one_wave_per_call_kernel_matches_the_general_kernel():
         out_rows = torch.randperm(B, device="cuda", generator=gen).to(torch.int32)
         n_stats = lib.mz_tower_stats_floats(C.byref(tower), calls)
 
-        def run(chunk_calls):
+        def run(chunk_calls, n_calls=calls):
             out = torch.zeros(B, 108, device="cuda")
             stats = []
-            for c0 in range(0, calls, chunk_calls):
+            for c0 in range(0, n_calls, chunk_calls):
                 r0, nb = c0 * group, chunk_calls * group
                 st_c = torch.zeros(lib.mz_tower_stats_floats(C.byref(tower), chunk_calls), device="cuda")
                 _hip.check(lib.mz_tower_forward_stats(C.byref(tower), ptr(src), 108, ptr(rows[r0:r0 + nb].contiguous()), None, 0, None,
@@ -740,13 +741,23 @@ def test_one_wave_per_call_kernel_matches_the_general_kernel():
             torch.cuda.synchronize()
             return out, torch.cat(stats, dim=2)
 
-        thin, thin_stats = run(calls)
-        general, general_stats = run(512 // (2 if group > 1 else 1))
+        old = lib.mz_tower_thin_min_calls(1)
+        try:
+            thin, thin_stats = run(calls)
+            few, few_stats = run(3, 6)     # two launches of three calls
+            one, _ = run(1, 1)
+            lib.mz_tower_thin_min_calls(1 << 30)
+            general, general_stats = run(512 // (2 if group > 1 else 1))
+        finally:
+            lib.mz_tower_thin_min_calls(old)
         assert thin_stats.numel() == n_stats
         scale = float(general.abs().max())
         assert float((thin - general).abs().max()) <= 1e-6 * scale, (group, float((thin - general).abs().max()), scale)
         np.testing.assert_allclose(thin_stats.cpu().numpy(), general_stats.cpu().numpy(), rtol=1e-5, atol=1e-7)
         assert not torch.equal(thin, torch.zeros_like(thin))
+        touched = out_rows[:6 * group].long()
+        assert torch.equal(few[touched], thin[touched]) and torch.equal(one[touched[:group]], thin[touched[:group]])
+        assert torch.equal(few_stats, thin_stats[:, :, :6])
 
 
 def test_running_statistics_through_the_fused_form():
