@@ -752,18 +752,39 @@ __device__ __forceinline__ lds_f *mlp_tile(const mz_packed_mlp &M, const float *
     return mlp_tile<MT>(tm, M, 0, packed, in_buf, in_ld, buf_a, buf_b, out_ld);
 }
 
-// Cooperative load of up to `rows` global rows (row r from src + row_index(r)*src_ld) into
-// an LDS tile [TM][ld], zero-filling columns [K, ld) and rows >= rows.
+// Cooperative load of up to `rows` global rows (row r from row_ptr(r), NULL: zeros) into an LDS tile
+// [TM][ld], zero-filling columns [K, ld) and rows >= rows.  Two round trips to memory, not one per
+// element: a wave takes whole rows, asks for the row's address once (wave-uniform, so it lives in scalar
+// registers) and requests all of the row's values before the first is stored.
 template <typename RowPtr>
 __device__ __forceinline__ void load_rows(lds_f *Xs, int ld, int TM, int rows, int K, RowPtr row_ptr) {
-    for (int i = threadIdx.x; i < TM * ld; i += kThreads) {
-        const int r = i / ld, c = i - r * ld;
-        float v = 0.0f;
-        if (r < rows && c < K) {
-            const float *p = row_ptr(r);
-            if (p) v = p[c];
+    const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
+    constexpr int kMaxPieces = 4;  // 64 * 4 values of a row in flight per pass
+    for (int r0 = wave; r0 < TM; r0 += 2 * kWaves) {
+        // two rows per pass: their address loads and their value loads overlap
+        const float *p[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + h * kWaves;
+            p[h] = (r < rows) ? row_ptr(r) : nullptr;
         }
-        Xs[i] = v;
+        for (int c0 = 0; c0 < ld; c0 += 64 * kMaxPieces) {
+            float v[2][kMaxPieces];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < kMaxPieces; ++j) {
+                    const int c = c0 + 64 * j + lane;
+                    v[h][j] = (p[h] != nullptr && c < K) ? p[h][c] : 0.0f;
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < kMaxPieces; ++j) {
+                    const int r = r0 + h * kWaves, c = c0 + 64 * j + lane;
+                    if (r < TM && c < ld) Xs[r * ld + c] = v[h][j];
+                }
+        }
     }
     __syncthreads();
 }
