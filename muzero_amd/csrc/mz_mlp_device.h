@@ -363,9 +363,14 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
 #pragma unroll
             for (int j = 0; j < KP; ++j) w[t][j] = base[j * 64 + lane];
         }
-        if (++fb == nb) {
+        // The cursor stops at the last batch: fetches past the end of the stream (issued unconditionally, so
+        // that every wait below counts an exact number of loads in flight) request that batch once more.
+        if (fb + 1 < nb) {
+            ++fb;
+        } else if (fg + 1 < ngroups) {
             fb = 0;
-            if (++fg < ngroups) fetch_bases();
+            ++fg;
+            fetch_bases();
         }
     };
     // compute cursor
@@ -435,8 +440,7 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     MZ_TL(1)
     // the weights have the longest way: requested before the operand pipeline is primed
 #pragma unroll
-    for (int u = 0; u < NS - 1; ++u)
-        if (u < total) fetch(w[u]);
+    for (int u = 0; u < NS - 1; ++u) fetch(w[u]);
     MZ_TL(2)
     {
         const f32x4 sh = rows.shared(m, 4 * kq);
@@ -446,7 +450,7 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     for (int i = 0; i < total; i += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            if (i + u + NS - 1 < total) fetch(w[(u + NS - 1) % NS]);
+            fetch(w[(u + NS - 1) % NS]);
             if (i + u < total) compute(w[u]);
         }
         if (i == 0) { MZ_TL(3) }
