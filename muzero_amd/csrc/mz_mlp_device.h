@@ -45,7 +45,10 @@ namespace mzd {
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-constexpr int kPrefetch = 4;  // k-steps of weights held in registers ahead of the MFMAs
+#ifndef MZ_PREFETCH
+#define MZ_PREFETCH 4
+#endif
+constexpr int kPrefetch = MZ_PREFETCH;  // k-steps of weights held in registers ahead of the MFMAs
 #ifndef MZ_WEIGHT_SETS
 #define MZ_WEIGHT_SETS 2
 #endif
