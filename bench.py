@@ -218,7 +218,7 @@ def tower_search(G, S, dev, steps, with_roofline):
     the tower kernel's rollout-step call against the HBM roofline."""
     from muzero_amd.engine import BatchedMCTS
     from muzero_amd.towers import TowerNetworks
-    from tools.bench_towers import build_nets, pmc_tower_traffic
+    from tools.bench_towers import build_nets
     shape, A = (256, 6, 6), 5
     D = shape[0] * shape[1] * shape[2]
     g, f = build_nets(shape, A)
@@ -240,19 +240,18 @@ def tower_search(G, S, dev, steps, with_roofline):
     assert int(res.visits.sum().item()) == G * S and mcts.replays >= steps
     out = {"workload": f"{G} trees x {S} sims, residual-tower g/f, latent {list(shape)}, {A} actions, lock-step search",
            "sims_per_sec": G * S / dt, "ms_per_search": dt * 1e3, "steps": steps}
-    if with_roofline and nets.tower_f_t is not None:
-        dt_ = nets.bottleneck_g
-        base = torch.randn(G, D, device=dev)
-        t_out = torch.empty(G, dt_, device=dev)
-        sel = torch.zeros(G, dtype=torch.int32, device=dev)
-        s = time_kernel(lambda: nets._tower_call(nets.tower_g, base, D, None, nets.table_t, sel, None, 0, None, G, 1,
-                                                 t_out=t_out), iters=20)
-        nbytes = 4.0 * G * (D + dt_)  # fc_merge's latent half read once + the block output written, per call
-        out["roofline_tower"] = {"bound": "hbm", "kernel": "k_tower / k_tower_packed [g rollout step, search form]",
-                                 "achieved": nbytes / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": nbytes / s / 1e9 / HBM_PEAK_GBS, "avg_launch_us": s * 1e6,
-                                 "bytes_per_launch": nbytes, "traffic": pmc_tower_traffic(G),
-                                 "traffic_source": "committed profile (profiles/r1_i_tower_pmc_traffic.json)"}
+    if with_roofline and getattr(nets, "fused_g", False):
+        # the kernel that takes most of a step: fc_merge on the bottleneck values + the first product of g's tower
+        # for an expansion (every tree's leaf with all A actions); fp32 matrix instructions
+        t = torch.randn(G, nets.bottleneck_g, device=dev)
+        s = time_kernel(lambda: nets.merge_conv(t, None, None, G), iters=20)
+        hw = shape[1] * shape[2]
+        flop = 2.0 * G * nets.merge_t_perm.Kp * D + 2.0 * G * A * hw * shape[0] * 32
+        out["roofline_tower"] = {"bound": "mfma", "kernel": "k_merge_conv [g expansion: fc_merge on the bottleneck values, "
+                                 "action term, first tower product; search form]",
+                                 "achieved": flop / s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": flop / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": s * 1e6,
+                                 "flop_per_launch": flop, "traffic": None}
     del mcts, nets
     torch.cuda.empty_cache()
     return out

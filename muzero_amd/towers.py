@@ -456,6 +456,18 @@ class TowerNetworks:
             return None
         return res
 
+    def merge_conv(self, t, t_rows, action, n_src) -> torch.Tensor:
+        """fc_merge on bottleneck values + the per-action term + the first product of g's tower in one launch
+        (only when `fused_g`): Y f32[rows][H*W][32] for rows = n_src (action i32[n_src]) or n_src * A (action None:
+        every source row with all A actions)."""
+        c, hgt, wid = self.shape
+        B = n_src if action is not None else n_src * self.A
+        Y = self._buf("g_Y", (B, hgt * wid, 32))
+        _hip.check(_hip.lib().mz_merge_conv_forward(C.byref(self.merge_t_perm), C.byref(self.conv_g), ptr(self.blob), ptr(t),
+                                                    t.shape[-1], ptr(t_rows), ptr(self.table_t_perm), ptr(action), self.A, n_src,
+                                                    c, hgt * wid, ptr(Y), _stream()), "mz_merge_conv_forward")
+        return Y
+
     # ---- batched g / f (same calls as PackedNetworks) -----------------------------------------
     def merge_rows(self, latent, B, *, ld=None, rows=None, t_in=None) -> torch.Tensor:
         """fc_merge's latent half for B rows (needs no action): pass the result to
@@ -495,10 +507,7 @@ class TowerNetworks:
                 n_src, group = U, A
             else:
                 n_src, group = B, 1
-            Y = self._buf("g_Y", (B, hgt * wid, 32))
-            _hip.check(lib.mz_merge_conv_forward(C.byref(self.merge_t_perm), C.byref(self.conv_g), ptr(self.blob), ptr(t), t.shape[-1],
-                                                 ptr(t_rows), ptr(self.table_t_perm), ptr(action), A, n_src, c, hgt * wid, ptr(Y),
-                                                 _stream()), "mz_merge_conv_forward")
+            Y = self.merge_conv(t, t_rows, action, n_src)
             layers = self._running.get(id(self.tower_g)) if self.track_running_stats else None
             stats, calls = None, B // group
             if layers:
