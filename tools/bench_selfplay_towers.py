@@ -113,7 +113,7 @@ def main() -> None:
         "config": {"workload": f"{G} games, {args.sims} simulations per move, history {args.history} x 3x96x96, "
                                f"shipped h/g/f shapes (latent {list(shape)}), {A} actions"},
         "simulations_per_sec": G * args.sims / dt,
-        "parts_ms": {"h (torch module, per-game batch statistics)": h_ms,
+        "parts_ms": {"h (HIP convolution path, per-game batch statistics)": h_ms,
                      "host step + observe + upload": env_ms,
                      "search and the rest": dt * 1e3 - h_ms - env_ms},
     }))

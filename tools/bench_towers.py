@@ -159,29 +159,29 @@ def main() -> None:
                                         next_latent=nxt, reward=rew))
     g1_ms = timed(lambda: nets.dynamics(mcts.pool.latent, G, rows=rows, action=arg.zero_(), next_latent=nxt[:G],
                                         reward=val))
-    # the tower kernel of the search form alone: g's rollout-step call (one reference call per tree; reads
-    # fc_merge's latent half, D floats per tree, adds the action's table row, which stays in L2, and
-    # writes the block output) and the expansion call (A children per tree; same input read once per tree)
+    # the kernels that take most of a step of the search form, each alone: fc_merge on the bottleneck values fused
+    # with the first product of g's tower (expansion: every leaf with all A actions; rollout step: one action per
+    # tree), against the fp32 matrix peak, and the one-wave tower kernel's calls
     tower_roofline = None
-    if nets.tower_f_t is not None:
+    if getattr(nets, "fused_g", False) and nets.tower_f_t is not None:
         dt_ = nets.bottleneck_g
-        base = torch.randn(G, D, device="cuda")
+        hw = shape[1] * shape[2]
+        t = torch.randn(G, dt_, device="cuda")
         t_out = torch.empty(G * A, dt_, device="cuda")
-        sel = torch.zeros(G, dtype=torch.int32, device="cuda")
-        gidx = (torch.arange(G * A, dtype=torch.int32, device="cuda") // A).contiguous()
-        step_ms = timed(lambda: nets._tower_call(nets.tower_g, base, D, None, nets.table_t, sel, None, 0, None, G, 1,
-                                                 t_out=t_out))
-        exp_ms = timed(lambda: nets._tower_call(nets.tower_g, base, D, gidx, nets.table_t, None, None, 0, None, G * A,
-                                                A, t_out=t_out))
-        step_bytes = 4.0 * G * (D + dt_)
-        exp_bytes = 4.0 * G * (D + A * dt_)
-        tower_roofline = {"bound": "hbm", "kernel": "k_tower / k_tower_packed [g rollout step, search form]",
-                          "achieved": step_bytes / step_ms / 1e6, "peak": 8000.0, "unit": "GB/s",
-                          "frac": step_bytes / step_ms / 1e6 / 8000.0, "avg_launch_us": step_ms * 1e3,
-                          "bytes_per_launch": step_bytes,
-                          "expansion_call": {"avg_launch_us": exp_ms * 1e3, "bytes_per_launch": exp_bytes,
-                                             "achieved": exp_bytes / exp_ms / 1e6},
-                          "traffic": pmc_tower_traffic(G)}
+        act = torch.zeros(G, dtype=torch.int32, device="cuda")
+        exp_ms = timed(lambda: nets.merge_conv(t, None, None, G))
+        step_ms = timed(lambda: nets.merge_conv(t, None, act, G))
+        exp_flop = 2.0 * G * nets.merge_t_perm.Kp * D + 2.0 * G * A * hw * shape[0] * 32
+        step_flop = 2.0 * G * nets.merge_t_perm.Kp * D + 2.0 * G * hw * shape[0] * 32
+        f_t = torch.empty(G, nets.bottleneck_f, device="cuda")
+        thin_f_ms = timed(lambda: nets._tower_call(nets.tower_f_t, t, dt_, None, None, None, None, 0, None, G, 1, t_out=f_t))
+        tower_roofline = {"bound": "mfma", "kernel": "k_merge_conv [g expansion, search form]",
+                          "achieved": exp_flop / exp_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": exp_flop / exp_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": exp_ms * 1e3,
+                          "flop_per_launch": exp_flop,
+                          "rollout_step_call": {"avg_launch_us": step_ms * 1e3, "flop_per_launch": step_flop,
+                                                "achieved": step_flop / step_ms / 1e9},
+                          "one_wave_tower_kernel_f_call_us": thin_f_ms * 1e3, "traffic": None}
     # reference arithmetic per simulation: 3 f calls and A+1 g calls, each g with the full 2D x D fc_merge
     F_heads = 2.0 * (D * 256 + 256 * 128 + 128 + D * 256 + 256 * 256 + 256 * A)
     F_tower = 2.0 * 36 * (shape[0] * 9 * 3 + 3 * 9 * 3 + shape[0] * 3 + 3 * shape[0])
