@@ -116,6 +116,15 @@ int mz_tree_expand_commit(const mz_pool *pool, const int32_t *leaf, const float 
 int mz_tree_select_rows(const mz_pool *pool, const double *sqrt_tab, const double *log_tab,
                         int32_t tab_len, int32_t flags, int32_t *out_leaf, int32_t *out_depth,
                         int32_t *out_row, int32_t *out_child_rows, void *stream);
+/* mz_tree_select_rows that also names the row of the child the simulation will start from
+ * (src/search/mcts.py:64-66 draws it right after the expansion): out_drawn_row i32[G] = row of child
+ * rand_child[g] among the rows of out_child_rows, -1 where mz_tree_expand_commit would give out_child = -1.
+ * Known before the expansion is committed, so the rollout's network calls need not wait for the child
+ * records (priors, rewards) to be written. */
+int mz_tree_select_rows_drawn(const mz_pool *pool, const double *sqrt_tab, const double *log_tab,
+                              int32_t tab_len, int32_t flags, int32_t *out_leaf, int32_t *out_depth,
+                              int32_t *out_row, int32_t *out_child_rows, const int32_t *rand_child,
+                              int32_t *out_drawn_row, void *stream);
 int mz_tree_expand_commit_rows(const mz_pool *pool, const int32_t *leaf, const float *prior,
                                const float *reward, const float *next_latent,
                                const int32_t *rand_child, int32_t *out_child,

@@ -64,7 +64,8 @@ __global__ void k_gather_latent(mz_pool p, const int32_t *__restrict__ idx, floa
 template <int LPT>
 __global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const double *__restrict__ log_tab,
                          int tab_len, int flags, int32_t *__restrict__ out_leaf, int32_t *__restrict__ out_depth,
-                         int32_t *__restrict__ out_row, int32_t *__restrict__ out_child_rows) {
+                         int32_t *__restrict__ out_row, int32_t *__restrict__ out_child_rows,
+                         const int32_t *__restrict__ rand_child, int32_t *__restrict__ out_drawn_row) {
     extern __shared__ double s_tab[];  // [tab_len] sqrt, then [tab_len] log term
     for (int i = threadIdx.x; i < tab_len; i += blockDim.x) {
         s_tab[i] = sqrt_tab[i];
@@ -81,6 +82,11 @@ __global__ void k_select(mz_pool p, const double *__restrict__ sqrt_tab, const d
         out_leaf[g] = leaf;
         if (out_depth) out_depth[g] = depth;
         if (out_row) out_row[g] = leaf >= 0 ? g * p.cap + leaf : -1;  // a failed descent names no row (read as zeros)
+        if (out_drawn_row) {  // the child the simulation will start from, as k_expand_commit will name it
+            const int rc = rand_child[g];
+            const bool ok = leaf >= 0 && p.n_nodes[g] + p.A <= p.cap && rc >= 0 && rc < p.A;
+            out_drawn_row[g] = ok ? g * p.cap + p.n_nodes[g] + rc : -1;
+        }
     }
     // pool rows an expansion of this leaf would give its children
     if (out_child_rows && a < p.A)
@@ -195,8 +201,15 @@ int mz_tree_init(const mz_pool *pool, const int8_t *root_to_play, const float *r
 int mz_tree_select_rows(const mz_pool *pool, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
                         int32_t flags, int32_t *out_leaf, int32_t *out_depth, int32_t *out_row,
                         int32_t *out_child_rows, void *stream) {
+    return mz_tree_select_rows_drawn(pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth, out_row, out_child_rows,
+                                     nullptr, nullptr, stream);
+}
+
+int mz_tree_select_rows_drawn(const mz_pool *pool, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
+                              int32_t flags, int32_t *out_leaf, int32_t *out_depth, int32_t *out_row,
+                              int32_t *out_child_rows, const int32_t *rand_child, int32_t *out_drawn_row, void *stream) {
     MZ_TRY(mz::check_pool(pool, false));
-    if (!sqrt_tab || !log_tab || tab_len <= 0 || !out_leaf)
+    if (!sqrt_tab || !log_tab || tab_len <= 0 || !out_leaf || (out_drawn_row && !rand_child))
         return mz::fail(MZ_ERR_ARG, "mz_tree_select: NULL table/output or tab_len <= 0");
     if ((long long)pool->G * pool->cap > INT32_MAX)
         return mz::fail(MZ_ERR_ARG, "mz_tree_select: G * cap exceeds the 32-bit row index");
@@ -206,7 +219,8 @@ int mz_tree_select_rows(const mz_pool *pool, const double *sqrt_tab, const doubl
     return dispatch_lpt(pool->A, [&](auto lpt) {
         constexpr int LPT = decltype(lpt)::value;
         hipLaunchKernelGGL(k_select<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), lds, st,
-                           *pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth, out_row, out_child_rows);
+                           *pool, sqrt_tab, log_tab, tab_len, flags, out_leaf, out_depth, out_row, out_child_rows, rand_child,
+                           out_drawn_row);
         return mz::check_launch("k_select");
     });
 }

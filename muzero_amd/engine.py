@@ -13,6 +13,7 @@ draw of the root expansion).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -94,15 +95,19 @@ class TreePool:
                    "mz_tree_init")
 
     def select(self, out_leaf: torch.Tensor, out_depth: torch.Tensor | None = None, root_f32: bool = True,
-               out_row: torch.Tensor | None = None, out_child_rows: torch.Tensor | None = None) -> None:
+               out_row: torch.Tensor | None = None, out_child_rows: torch.Tensor | None = None,
+               rand_child: torch.Tensor | None = None, out_drawn_row: torch.Tensor | None = None) -> None:
         """out_row i32[G] / out_child_rows i32[G, A] (optional): pool rows (tree * cap + node) of the
-        leaf and of the children an expansion would give it."""
+        leaf and of the children an expansion would give it; out_drawn_row i32[G] (with rand_child i32[G]):
+        the row of the child expand_commit will draw with the same rand_child."""
         assert out_leaf.dtype == torch.int32 and out_leaf.numel() == self.G
-        for t, n in ((out_row, self.G), (out_child_rows, self.G * self.A)):
+        for t, n in ((out_row, self.G), (out_child_rows, self.G * self.A), (rand_child, self.G), (out_drawn_row, self.G)):
             assert t is None or (t.dtype == torch.int32 and t.numel() == n and t.is_contiguous())
-        _hip.check(_hip.lib().mz_tree_select_rows(C.byref(self.c), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
-                                                  _hip.SELECT_ROOT_F32 if root_f32 else 0, ptr(out_leaf),
-                                                  ptr(out_depth), ptr(out_row), ptr(out_child_rows), _stream()),
+        assert out_drawn_row is None or rand_child is not None
+        _hip.check(_hip.lib().mz_tree_select_rows_drawn(C.byref(self.c), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
+                                                        _hip.SELECT_ROOT_F32 if root_f32 else 0, ptr(out_leaf),
+                                                        ptr(out_depth), ptr(out_row), ptr(out_child_rows), ptr(rand_child),
+                                                        ptr(out_drawn_row), _stream()),
                    "mz_tree_select")
 
     def expand_commit(self, leaf, prior, reward, rand_child, out_child, next_latent=None, out_child_row=None) -> None:
@@ -249,10 +254,14 @@ class BatchedMCTS:
         G, A, D = self.G, self.A, self.D
         self.leaf = torch.zeros(G, **i32)
         self.child = torch.zeros(G, **i32)
-        self.prior = torch.zeros((G, A), **f32)
+        # the leaf's priors are the first G rows of a [2G, A] buffer, the greedy actions of a rollout's first step
+        # the last G entries of a [2G] buffer: one f call can serve the leaf and the drawn child (_step_chain)
+        self.prior2 = torch.zeros((2 * G, A), **f32)
+        self.prior = self.prior2[:G]
         self.reward = torch.zeros((G, A), **f32)
         self.rollout_t = torch.zeros((self.depth + 1, G), **f32)
-        self.act = torch.zeros(G, **i32)
+        self.act2 = torch.zeros(2 * G, **i32)
+        self.act = self.act2[G:]
         self.tmp = [torch.zeros((G, D), **f32) for _ in range(2)]
         self.stamps = None  # set to an int64[32] device tensor to collect per-stage cycle counts
         self.tree_base = (torch.arange(G, **i32) * self.pool.cap)
@@ -264,11 +273,14 @@ class BatchedMCTS:
         # values for every node next to the latent
         dt = getattr(nets, "bottleneck_g", 0)
         self.rollout = torch.zeros((G, self.depth + 1), **f32)   # [r_1 .. r_depth, v] per tree
-        self.rows_buf = [torch.zeros(G, **i32) for _ in range(2)]
+        self.rows2 = torch.zeros(2 * G, **i32)   # rows of the leaf, then rows of the drawn child
+        self.rows_buf = [self.rows2[:G], self.rows2[G:]]
         self.next_rows_buf = torch.zeros((G, A), **i32)
         self.child_slots = (self.tree_base[:, None] + self.arange_a[None, :]).contiguous()
         self.keep_latents = keep_latents or not dt or getattr(nets, "tower_f_t", None) is None
         self.use_graph = True
+        self.fork_rollout = os.environ.get("MZ_FORK_ROLLOUT", "1") != "0"  # see _step_forked / _step_chain
+        self.step_schedule = os.environ.get("MZ_STEP_SCHEDULE", "chain")   # "chain" or "fork"
         self._graph, self._graph_version = None, -1
         self.rand_static = torch.zeros((0, G), **i32)  # the recorded search's child draws [n, G]
         self.replays = 0
@@ -302,9 +314,10 @@ class BatchedMCTS:
             main.wait_stream(self.side)
         pool.expand_commit(node, self.prior, self.reward, rand_child, out_child, out_child_row=self.rows_buf[1])
 
-    def _simulate(self, child: torch.Tensor) -> torch.Tensor:
+    def _simulate(self, child: torch.Tensor, first_action_known: bool = False) -> torch.Tensor:
         """MuZeroSimulation (src/search/simulation.py:23-45) from one node per tree;
-        returns rollout f32[G, depth+1]."""
+        returns rollout f32[G, depth+1].  first_action_known: self.act already holds the greedy action of the
+        first step (f was evaluated for the drawn child together with the leaf)."""
         pool, nets, G = self.pool, self.nets, self.G
         cur, rows = pool.latent, self.rows_buf[1]  # rows of `child`, written by pool.expand_commit
         strided = getattr(nets, "strided_outputs", False)  # heads write into the columns of self.rollout directly
@@ -327,7 +340,8 @@ class BatchedMCTS:
                 main.wait_stream(self.side)
                 nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), base=base, **extra)
             else:
-                nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
+                if not (first_action_known and d == 0):
+                    nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
                 nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), **extra)
             cur, rows = nxt, None
             if self.t_pool is not None:
@@ -347,10 +361,67 @@ class BatchedMCTS:
 
     def _step(self, rand_column: torch.Tensor) -> torch.Tensor:
         """One `_step` (src/search/mcts.py:76-83) for every tree; returns the rollouts."""
+        if self._forked():
+            return self._step_chain(rand_column) if self.step_schedule == "chain" else self._step_forked(rand_column)
         self.pool.select(self.leaf, out_row=self.rows_buf[0], out_child_rows=self.next_rows_buf)
         self._expand(self.leaf, rand_column, self.child)
         rollout = self._simulate(self.child)
         self.pool.backup(self.child, self.leaf, rollout, self.discount)
+        return rollout
+
+    def _step_chain(self, rand_column: torch.Tensor) -> torch.Tensor:
+        """The same step as ONE chain of launches on one stream (no hand-over between queues, each of which
+        costs 5-10 us inside a replayed graph): g's tower for the A children first, then f for the leaf AND the
+        drawn child in one call (2G rows: priors for the first G, greedy actions for the last G), the rollout,
+        and last the children's rewards and the child records, which nothing before the backup reads.
+        Same kernels on the same data as `_expand` + `_simulate`: identical results."""
+        pool, nets, G, A = self.pool, self.nets, self.G, self.A
+        pool.select(self.leaf, out_row=self.rows_buf[0], out_child_rows=self.next_rows_buf, rand_child=rand_column,
+                    out_drawn_row=self.rows_buf[1])
+        rows, next_rows = self.rows_buf[0], self.next_rows_buf.view(-1)
+        nets.dynamics(pool.latent, G * A, rows=rows, action=None, next_latent=pool.latent, next_rows=next_rows, reward=None,
+                      t_in=(self.t_pool, rows), t_out=self.t_pool, want_latent=False)
+        nets.prediction(pool.latent, 2 * G, rows=self.rows2, softmax_times=1, policy=self.prior2, argmax=self.act2,
+                        t_in=(self.t_pool, self.rows2))
+        rollout = self._simulate(self.child, first_action_known=True)
+        nets.reward_on_t(self.t_pool, next_rows, G * A, self.reward)
+        pool.expand_commit(self.leaf, self.prior, self.reward, rand_column, self.child)
+        pool.backup(self.child, self.leaf, rollout, self.discount)
+        return rollout
+
+    def _forked(self) -> bool:
+        """Whether a step can run the rollout beside the commit of the expansion: the rollout reads only the
+        children's bottleneck values (no tree record), the row of the drawn child is known at selection time,
+        and the networks can evaluate the reward head on its own (`reward_on_t`)."""
+        nets = self.nets
+        return (self.fork_rollout and self.side is not None and self.t_pool is not None and not self.keep_latents
+                and getattr(nets, "fused_g", False) and hasattr(nets, "reward_on_t")
+                and not getattr(nets, "track_running_stats", False)  # f would advance its buffers on both streams at once
+                and self.G >= getattr(nets, "fuse_min_rows", 0))
+
+    def _step_forked(self, rand_column: torch.Tensor) -> torch.Tensor:
+        """The same step with a shorter chain of dependent launches: as soon as the children's bottleneck values
+        exist (g's tower for the A children), the main stream starts the rollout from the drawn child, while the
+        side stream evaluates the leaf's priors, the children's rewards and writes the child records
+        (src/search/expansion.py:25-35).  Both meet before the backup.  Same kernels on the same data as
+        `_expand` + `_simulate`: identical results."""
+        pool, nets, G, A = self.pool, self.nets, self.G, self.A
+        pool.select(self.leaf, out_row=self.rows_buf[0], out_child_rows=self.next_rows_buf, rand_child=rand_column,
+                    out_drawn_row=self.rows_buf[1])
+        rows, next_rows = self.rows_buf[0], self.next_rows_buf.view(-1)
+        main, side = torch.cuda.current_stream(), self.side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior, t_in=(self.t_pool, rows))
+        nets.dynamics(pool.latent, G * A, rows=rows, action=None, next_latent=pool.latent, next_rows=next_rows, reward=None,
+                      t_in=(self.t_pool, rows), t_out=self.t_pool, want_latent=False)
+        side.wait_stream(main)  # the children's bottleneck values are in the pool
+        with torch.cuda.stream(side):
+            nets.reward_on_t(self.t_pool, next_rows, G * A, self.reward)
+            pool.expand_commit(self.leaf, self.prior, self.reward, rand_column, self.child)
+        rollout = self._simulate(self.child)  # reads rows_buf[1] (written by select) and bottleneck values only
+        main.wait_stream(side)
+        pool.backup(self.child, self.leaf, rollout, self.discount)
         return rollout
 
     def advance(self, rand_child: torch.Tensor, trace: dict | None = None) -> None:

@@ -456,6 +456,10 @@ class TowerNetworks:
             return None
         return res
 
+    def reward_on_t(self, t, rows, B, out) -> None:
+        """reward_mlp on the bottleneck values of B latents (rows of t), into out f32[B] (bottleneck form only)."""
+        self._mlp_on(self.reward_t, "reward_t", t, t.shape[-1], rows, B, out=out)
+
     def merge_conv(self, t, t_rows, action, n_src) -> torch.Tensor:
         """fc_merge on bottleneck values + the per-action term + the first product of g's tower in one launch
         (only when `fused_g`): Y f32[rows][H*W][32] for rows = n_src (action i32[n_src]) or n_src * A (action None:
