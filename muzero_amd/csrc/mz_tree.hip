@@ -148,6 +148,77 @@ __global__ void k_backup(mz_pool p, const int32_t *__restrict__ child, const int
     mzt::backup_path(p, o, node, (int8_t)mzt::node_to_play(p, o + lf), ret);
 }
 
+// The tree side of one lock-step simulation step as ONE launch instead of three: the child records of this
+// step's expansion (k_expand_commit), the backup of this step's rollout (k_backup) and, unless this was the
+// last step, the descent of the NEXT step (k_select) -- all per tree and in this order, LPT lanes per tree.
+// The lanes of a tree sit in one wave; between the phases the wave's stores are made visible to its own
+// later loads (workgroup-scope release / acquire around a wave barrier).  `leaf` holds this step's leaves on
+// entry and the next step's on exit.
+template <int LPT>
+__global__ void k_commit_backup_select(mz_pool p, int32_t *__restrict__ leaf, const float *__restrict__ prior,
+                                       const float *__restrict__ reward, const int32_t *__restrict__ rand_child,
+                                       int32_t *__restrict__ out_child, const float *__restrict__ rollout, int n_rollout,
+                                       double discount, const double *__restrict__ sqrt_tab,
+                                       const double *__restrict__ log_tab, int tab_len, int flags, int do_select,
+                                       int32_t *__restrict__ out_row, int32_t *__restrict__ out_child_rows,
+                                       const int32_t *__restrict__ rand_next, int32_t *__restrict__ out_drawn_row) {
+    extern __shared__ double s_tab[];  // [tab_len] sqrt, then [tab_len] log term
+    if (do_select)
+        for (int i = threadIdx.x; i < tab_len; i += blockDim.x) {
+            s_tab[i] = sqrt_tab[i];
+            s_tab[tab_len + i] = log_tab[i];
+        }
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t / LPT;
+    const int a = t % LPT;
+    if (g >= p.G) return;
+    const size_t o = (size_t)g * p.cap;
+    auto phase_fence = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // ---- child records (k_expand_commit)
+    const int base = p.n_nodes[g];
+    const int lf = leaf[g];
+    const bool ok = lf >= 0 && lf < base && base + p.A <= p.cap && p.node[o + lf].first_child < 0;
+    if (ok && a < p.A)
+        mzt::write_child(p, o, base, a, lf, prior[(size_t)g * p.A + a], reward[(size_t)g * p.A + a], (int8_t)mzt::node_to_play(p, o + lf));
+    __builtin_amdgcn_wave_barrier();  // every lane of the group has read n_nodes / first_child before lane 0 rewrites them
+    int child = -1;
+    if (a == 0) {
+        if (ok) {
+            p.node[o + lf].first_child = base;
+            p.n_nodes[g] = base + p.A;
+            const int rc = rand_child[g];
+            child = (rc >= 0 && rc < p.A) ? base + rc : -1;
+        }
+        out_child[g] = child;
+    }
+    phase_fence();
+    // ---- backup (k_backup)
+    if (a == 0 && child >= 0 && lf >= 0) {
+        const double ret = mzt::discounted_return(rollout + (size_t)g * n_rollout, n_rollout, discount);
+        mzt::backup_path(p, o, child, (int8_t)mzt::node_to_play(p, o + lf), ret);
+    }
+    if (!do_select) return;
+    phase_fence();
+    // ---- the next step's descent (k_select)
+    int depth = 0;
+    const int next = mzt::select_leaf<LPT>(p, o, a, s_tab, tab_len, flags & 1, &depth);
+    const int nn = p.n_nodes[g];
+    if (a == 0) {
+        leaf[g] = next;
+        if (out_row) out_row[g] = next >= 0 ? g * p.cap + next : -1;
+        if (out_drawn_row) {
+            const int rc = rand_next[g];
+            out_drawn_row[g] = (next >= 0 && nn + p.A <= p.cap && rc >= 0 && rc < p.A) ? g * p.cap + nn + rc : -1;
+        }
+    }
+    if (out_child_rows && a < p.A) out_child_rows[g * p.A + a] = (next >= 0 && nn + p.A <= p.cap) ? g * p.cap + nn + a : -1;
+}
+
 // src/search/mcts.py:71-72,97-103.
 __global__ void k_result(mz_pool p, double *__restrict__ policy, float *__restrict__ policy32,
                          double *__restrict__ value, int32_t *__restrict__ visits) {
@@ -274,6 +345,30 @@ int mz_tree_backup(const mz_pool *pool, const int32_t *child, const int32_t *lea
     hipLaunchKernelGGL(k_backup, dim3(blocks_for(pool->G, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *pool, child,
                        leaf, rollout, n_rollout, discount);
     return mz::check_launch("k_backup");
+}
+
+int mz_tree_commit_backup_select(const mz_pool *pool, int32_t *leaf, const float *prior, const float *reward,
+                                 const int32_t *rand_child, int32_t *out_child, const float *rollout, int32_t n_rollout,
+                                 double discount, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
+                                 int32_t flags, int32_t do_select, int32_t *out_row, int32_t *out_child_rows,
+                                 const int32_t *rand_next, int32_t *out_drawn_row, void *stream) {
+    MZ_TRY(mz::check_pool(pool, false));
+    if (!leaf || !prior || !reward || !rand_child || !out_child || !rollout || n_rollout <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: NULL argument or n_rollout <= 0");
+    if (do_select && (!sqrt_tab || !log_tab || tab_len <= 0 || (out_drawn_row && !rand_next)))
+        return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: NULL table or tab_len <= 0");
+    if ((long long)pool->G * pool->cap > INT32_MAX)
+        return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: G * cap exceeds the 32-bit row index");
+    const size_t lds = do_select ? sizeof(double) * 2 * (size_t)tab_len : 0;
+    if (lds > 64 * 1024) return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: tab_len %d exceeds the 4096-entry LDS table", tab_len);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_lpt(pool->A, [&](auto lpt) {
+        constexpr int LPT = decltype(lpt)::value;
+        hipLaunchKernelGGL(k_commit_backup_select<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), lds,
+                           st, *pool, leaf, prior, reward, rand_child, out_child, rollout, n_rollout, discount, sqrt_tab,
+                           log_tab, tab_len, flags, do_select, out_row, out_child_rows, rand_next, out_drawn_row);
+        return mz::check_launch("k_commit_backup_select");
+    });
 }
 
 int mz_tree_result(const mz_pool *pool, double *policy, float *policy32, double *value, int32_t *visits,

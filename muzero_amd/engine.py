@@ -133,6 +133,22 @@ class TreePool:
         _hip.check(_hip.lib().mz_tree_backup(C.byref(self.c), ptr(child), ptr(leaf), ptr(rollout),
                                              rollout.shape[1], float(discount), _stream()), "mz_tree_backup")
 
+    def commit_backup_select(self, leaf, prior, reward, rand_child, out_child, rollout, discount, *, select_next: bool,
+                             root_f32: bool = True, out_row=None, out_child_rows=None, rand_next=None,
+                             out_drawn_row=None) -> None:
+        """expand_commit + backup of one step and (select_next) the selection of the next one in one launch; `leaf`
+        holds this step's leaves on entry and the next step's on exit."""
+        assert rollout.dtype == torch.float32 and rollout.is_contiguous() and rollout.shape[0] == self.G
+        assert prior.is_contiguous() and reward.is_contiguous() and prior.numel() == reward.numel() == self.G * self.A
+        for t, n in ((leaf, self.G), (rand_child, self.G), (out_child, self.G), (out_row, self.G),
+                     (out_child_rows, self.G * self.A), (rand_next, self.G), (out_drawn_row, self.G)):
+            assert t is None or (t.dtype == torch.int32 and t.numel() == n and t.is_contiguous())
+        _hip.check(_hip.lib().mz_tree_commit_backup_select(
+            C.byref(self.c), ptr(leaf), ptr(prior), ptr(reward), ptr(rand_child), ptr(out_child), ptr(rollout),
+            rollout.shape[1], float(discount), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
+            _hip.SELECT_ROOT_F32 if root_f32 else 0, 1 if select_next else 0, ptr(out_row), ptr(out_child_rows),
+            ptr(rand_next), ptr(out_drawn_row), _stream()), "mz_tree_commit_backup_select")
+
     def result(self):
         dev = self.device
         policy = torch.empty((self.G, self.A), dtype=torch.float64, device=dev)
@@ -281,6 +297,7 @@ class BatchedMCTS:
         self.use_graph = True
         self.fork_rollout = os.environ.get("MZ_FORK_ROLLOUT", "1") != "0"  # see _step_forked / _step_chain
         self.step_schedule = os.environ.get("MZ_STEP_SCHEDULE", "chain")   # "chain" or "fork"
+        self.fuse_tree_kernels = os.environ.get("MZ_FUSE_TREE_KERNELS", "1") != "0"  # see _run_steps
         self._graph, self._graph_version = None, -1
         self.rand_static = torch.zeros((0, G), **i32)  # the recorded search's child draws [n, G]
         self.replays = 0
@@ -389,6 +406,33 @@ class BatchedMCTS:
         pool.backup(self.child, self.leaf, rollout, self.discount)
         return rollout
 
+    def _run_steps(self, rand: torch.Tensor) -> None:
+        """All steps of a search (rand i32[n, G]: one row of child draws per step).  In the chain schedule the tree
+        side of a step is one launch: the child records and the backup of step s and the selection of step s + 1
+        (mz_tree_commit_backup_select) -- 11 launches per step instead of 13."""
+        n = rand.shape[0]
+        if not (self._forked() and self.step_schedule == "chain" and self.fuse_tree_kernels and self.strided_rollout()):
+            for s in range(n):
+                self._step(rand[s])
+            return
+        pool, nets, G, A = self.pool, self.nets, self.G, self.A
+        rows, next_rows = self.rows_buf[0], self.next_rows_buf.view(-1)
+        pool.select(self.leaf, out_row=rows, out_child_rows=self.next_rows_buf, rand_child=rand[0], out_drawn_row=self.rows_buf[1])
+        for s in range(n):
+            nets.dynamics(pool.latent, G * A, rows=rows, action=None, next_latent=pool.latent, next_rows=next_rows, reward=None,
+                          t_in=(self.t_pool, rows), t_out=self.t_pool, want_latent=False)
+            nets.prediction(pool.latent, 2 * G, rows=self.rows2, softmax_times=1, policy=self.prior2, argmax=self.act2,
+                            t_in=(self.t_pool, self.rows2))
+            rollout = self._simulate(self.child, first_action_known=True)
+            nets.reward_on_t(self.t_pool, next_rows, G * A, self.reward)
+            last = s + 1 == n
+            pool.commit_backup_select(self.leaf, self.prior, self.reward, rand[s], self.child, rollout, self.discount,
+                                      select_next=not last, out_row=rows, out_child_rows=self.next_rows_buf,
+                                      rand_next=rand[s if last else s + 1], out_drawn_row=self.rows_buf[1])
+
+    def strided_rollout(self) -> bool:
+        return bool(getattr(self.nets, "strided_outputs", False))
+
     def _forked(self) -> bool:
         """Whether a step can run the rollout beside the commit of the expansion: the rollout reads only the
         children's bottleneck values (no tree record), the row of the drawn child is known at selection time,
@@ -444,8 +488,7 @@ class BatchedMCTS:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    for s in range(n):
-                        self._step(self.rand_static[s])
+                    self._run_steps(self.rand_static)
                 self._graph, self._graph_version = graph, version
             self.rand_static.copy_(rand_t)
             self._graph.replay()
@@ -526,10 +569,12 @@ class BatchedMCTS:
 
 
 def run_recorded(pool: TreePool, root_to_play, prior_stream, reward_stream, rand_stream, sim_stream, eta,
-                 noise_frac: float, discount: float):
+                 noise_frac: float, discount: float, fused_steps: bool = False):
     """Tree kernels only, driven by recorded network outputs (the parity harness of the
     bit-exact contract).  Streams are device tensors shaped [S+1, G, A], [S+1, G, A],
-    [S+1, G], [S, G, depth+1], eta [G, A].  Returns (leaf[S, G], child[S, G])."""
+    [S+1, G], [S, G, depth+1], eta [G, A].  Returns (leaf[S, G], child[S, G]).
+    fused_steps: one launch per step (mz_tree_commit_backup_select) instead of select / expand_commit / backup;
+    also returns the rows it reported, (row[S, G], child_rows[S, G, A], drawn_row[S, G])."""
     S = sim_stream.shape[0]
     G = pool.G
     dev = pool.device
@@ -540,6 +585,27 @@ def run_recorded(pool: TreePool, root_to_play, prior_stream, reward_stream, rand
     pool.init(root_to_play)
     pool.expand_commit(leaf, prior_stream[0], reward_stream[0], rand_stream[0], child)
     pool.root_noise(eta, noise_frac)
+    if fused_steps:
+        A = pool.A
+        row = torch.zeros(G, dtype=torch.int32, device=dev)
+        crows = torch.zeros((G, A), dtype=torch.int32, device=dev)
+        drawn = torch.zeros(G, dtype=torch.int32, device=dev)
+        rows_s = torch.zeros((S, G), dtype=torch.int32, device=dev)
+        crows_s = torch.zeros((S, G, A), dtype=torch.int32, device=dev)
+        drawn_s = torch.zeros((S, G), dtype=torch.int32, device=dev)
+        if S > 0:
+            pool.select(leaf, out_row=row, out_child_rows=crows, rand_child=rand_stream[1].contiguous(), out_drawn_row=drawn)
+        for s in range(S):
+            leaves[s].copy_(leaf)
+            rows_s[s].copy_(row)
+            crows_s[s].copy_(crows)
+            drawn_s[s].copy_(drawn)
+            last = s + 1 == S
+            pool.commit_backup_select(leaf, prior_stream[s + 1], reward_stream[s + 1], rand_stream[s + 1].contiguous(), child,
+                                      sim_stream[s], discount, select_next=not last, out_row=row, out_child_rows=crows,
+                                      rand_next=rand_stream[s + 1 if last else s + 2].contiguous(), out_drawn_row=drawn)
+            children[s].copy_(child)
+        return leaves, children, (rows_s, crows_s, drawn_s)
     for s in range(S):
         pool.select(leaf)
         pool.expand_commit(leaf, prior_stream[s + 1], reward_stream[s + 1], rand_stream[s + 1], child)

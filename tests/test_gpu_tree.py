@@ -165,3 +165,34 @@ def test_row_index_outputs(A, S, G):
         a.backup(child_a, leaf_a, d["sim"][s], 0.997)
         b.backup(child_b, leaf_b, d["sim"][s], 0.997)
     assert torch.equal(a.visit, b.visit) and torch.equal(a.value_sum, b.value_sum)
+
+
+@pytest.mark.parametrize("A,S,depth,G,noise,disc", [
+    (7, 50, 1, 1000, 0.25, 0.998),
+    (5, 50, 1, 256, 0.25, 0.998),    # the residual-tower configuration's tree shape
+    (2, 30, 2, 333, 0.25, 1.0),
+    (18, 12, 1, 130, 0.25, 0.997),   # 32 lanes per tree
+    (40, 6, 1, 65, 0.1, 0.997),      # one wavefront per tree
+    (1, 9, 1, 70, 0.25, 0.99),
+])
+def test_one_launch_per_step_matches_oracle(A, S, depth, G, noise, disc):
+    """mz_tree_commit_backup_select (child records + backup of a step and the next step's descent in one launch):
+    the same bit-exact trees as the three kernels, and the pool rows it reports for the leaf, its children-to-be
+    and the drawn child."""
+    from muzero_amd.engine import TreePool, run_recorded
+    st = random_streams(G, A, S, depth, seed=A * 100 + S + 1)
+    ref = otree.run_batch(A, S, depth, st["to_play"], st["prior"], st["reward"], st["rand"], st["sim"], st["eta"],
+                          noise, disc)
+    pool = TreePool(G, A, S, D=1, with_latent=False)
+    d = streams_to_device(st)
+    leaves, children, (rows, crows, drawn) = run_recorded(pool, d["to_play"], d["prior"], d["reward"], d["rand"], d["sim"],
+                                                          d["eta"], noise, disc, fused_steps=True)
+    policy, _, value, visits = pool.result()
+    torch.cuda.synchronize()
+    _compare(pool, leaves.cpu().numpy().T, children.cpu().numpy().T, policy.cpu().numpy(), value.cpu().numpy(),
+             visits.cpu().numpy(), ref)
+    base = (np.arange(G) * pool.cap)[None, :]
+    assert np.array_equal(rows.cpu().numpy(), base + ref["leaf"].T)
+    assert np.array_equal(drawn.cpu().numpy(), base + ref["child"].T)
+    first = 1 + A * (1 + np.arange(S))[:, None, None]        # lock step: step s creates nodes 1 + A (s + 1) ...
+    assert np.array_equal(crows.cpu().numpy(), base[:, :, None] + first + np.arange(A)[None, None, :])
