@@ -128,11 +128,13 @@ int mz_tree_select_rows_drawn(const mz_pool *pool, const double *sqrt_tab, const
 /* The tree side of one lock-step step in one launch: mz_tree_expand_commit (child records of this step's
  * expansion; `leaf` holds this step's leaves), mz_tree_backup of this step's rollout from out_child, and --
  * with do_select != 0 -- mz_tree_select_rows_drawn for the NEXT step (its leaves overwrite `leaf`, rand_next
- * names its drawn children), per tree and in this order.  Same records and the same descents as the three calls
+ * names its drawn children), per tree and in this order.  reward0 f32[G] (optional, n_rollout <= 8): read in
+ * place of rollout[g][0] (a caller that evaluates the first rollout reward together with the children's
+ * rewards leaves it in an array of its own).  Same records and the same descents as the three calls
  * (src/search/expansion.py:30-35, backpropagation.py:9-18, selection.py:43-59). */
 int mz_tree_commit_backup_select(const mz_pool *pool, int32_t *leaf, const float *prior, const float *reward,
                                  const int32_t *rand_child, int32_t *out_child, const float *rollout,
-                                 int32_t n_rollout, double discount, const double *sqrt_tab,
+                                 const float *reward0, int32_t n_rollout, double discount, const double *sqrt_tab,
                                  const double *log_tab, int32_t tab_len, int32_t flags, int32_t do_select,
                                  int32_t *out_row, int32_t *out_child_rows, const int32_t *rand_next,
                                  int32_t *out_drawn_row, void *stream);

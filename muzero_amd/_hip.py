@@ -101,7 +101,7 @@ _SIGS = {
     "mz_tree_select": (C.c_int, [C.POINTER(Pool), _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "mz_tree_expand_commit": (C.c_int, [C.POINTER(Pool), _P, _P, _P, _P, _P, _P, _P]),
     "mz_tree_select_rows": (C.c_int, [C.POINTER(Pool), _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
-    "mz_tree_commit_backup_select": (C.c_int, [C.POINTER(Pool), _P, _P, _P, _P, _P, _P, C.c_int32, C.c_double, _P, _P, C.c_int32,
+    "mz_tree_commit_backup_select": (C.c_int, [C.POINTER(Pool), _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_double, _P, _P, C.c_int32,
                                                C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "mz_tree_select_rows_drawn": (C.c_int, [C.POINTER(Pool), _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "mz_tree_expand_commit_rows": (C.c_int, [C.POINTER(Pool), _P, _P, _P, _P, _P, _P, _P, _P]),

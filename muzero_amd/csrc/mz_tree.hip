@@ -157,7 +157,8 @@ __global__ void k_backup(mz_pool p, const int32_t *__restrict__ child, const int
 template <int LPT>
 __global__ void k_commit_backup_select(mz_pool p, int32_t *__restrict__ leaf, const float *__restrict__ prior,
                                        const float *__restrict__ reward, const int32_t *__restrict__ rand_child,
-                                       int32_t *__restrict__ out_child, const float *__restrict__ rollout, int n_rollout,
+                                       int32_t *__restrict__ out_child, const float *__restrict__ rollout,
+                                       const float *__restrict__ reward0, int n_rollout,
                                        double discount, const double *__restrict__ sqrt_tab,
                                        const double *__restrict__ log_tab, int tab_len, int flags, int do_select,
                                        int32_t *__restrict__ out_row, int32_t *__restrict__ out_child_rows,
@@ -199,7 +200,15 @@ __global__ void k_commit_backup_select(mz_pool p, int32_t *__restrict__ leaf, co
     phase_fence();
     // ---- backup (k_backup)
     if (a == 0 && child >= 0 && lf >= 0) {
-        const double ret = mzt::discounted_return(rollout + (size_t)g * n_rollout, n_rollout, discount);
+        double ret;
+        if (reward0 != nullptr) {  // the first step's reward arrives in an array of its own (n_rollout <= 8 then)
+            float roll[8];
+            for (int k = 0; k < n_rollout; ++k) roll[k] = rollout[(size_t)g * n_rollout + k];
+            roll[0] = reward0[g];
+            ret = mzt::discounted_return(roll, n_rollout, discount);
+        } else {
+            ret = mzt::discounted_return(rollout + (size_t)g * n_rollout, n_rollout, discount);
+        }
         mzt::backup_path(p, o, child, (int8_t)mzt::node_to_play(p, o + lf), ret);
     }
     if (!do_select) return;
@@ -348,13 +357,13 @@ int mz_tree_backup(const mz_pool *pool, const int32_t *child, const int32_t *lea
 }
 
 int mz_tree_commit_backup_select(const mz_pool *pool, int32_t *leaf, const float *prior, const float *reward,
-                                 const int32_t *rand_child, int32_t *out_child, const float *rollout, int32_t n_rollout,
-                                 double discount, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
+                                 const int32_t *rand_child, int32_t *out_child, const float *rollout, const float *reward0,
+                                 int32_t n_rollout, double discount, const double *sqrt_tab, const double *log_tab, int32_t tab_len,
                                  int32_t flags, int32_t do_select, int32_t *out_row, int32_t *out_child_rows,
                                  const int32_t *rand_next, int32_t *out_drawn_row, void *stream) {
     MZ_TRY(mz::check_pool(pool, false));
-    if (!leaf || !prior || !reward || !rand_child || !out_child || !rollout || n_rollout <= 0)
-        return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: NULL argument or n_rollout <= 0");
+    if (!leaf || !prior || !reward || !rand_child || !out_child || !rollout || n_rollout <= 0 || (reward0 && n_rollout > 8))
+        return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: NULL argument, n_rollout <= 0, or reward0 with n_rollout > 8");
     if (do_select && (!sqrt_tab || !log_tab || tab_len <= 0 || (out_drawn_row && !rand_next)))
         return mz::fail(MZ_ERR_ARG, "mz_tree_commit_backup_select: NULL table or tab_len <= 0");
     if ((long long)pool->G * pool->cap > INT32_MAX)
@@ -365,7 +374,7 @@ int mz_tree_commit_backup_select(const mz_pool *pool, int32_t *leaf, const float
     return dispatch_lpt(pool->A, [&](auto lpt) {
         constexpr int LPT = decltype(lpt)::value;
         hipLaunchKernelGGL(k_commit_backup_select<LPT>, dim3(blocks_for((long long)pool->G * LPT, kBlock)), dim3(kBlock), lds,
-                           st, *pool, leaf, prior, reward, rand_child, out_child, rollout, n_rollout, discount, sqrt_tab,
+                           st, *pool, leaf, prior, reward, rand_child, out_child, rollout, reward0, n_rollout, discount, sqrt_tab,
                            log_tab, tab_len, flags, do_select, out_row, out_child_rows, rand_next, out_drawn_row);
         return mz::check_launch("k_commit_backup_select");
     });

@@ -135,7 +135,7 @@ class TreePool:
 
     def commit_backup_select(self, leaf, prior, reward, rand_child, out_child, rollout, discount, *, select_next: bool,
                              root_f32: bool = True, out_row=None, out_child_rows=None, rand_next=None,
-                             out_drawn_row=None) -> None:
+                             out_drawn_row=None, reward0=None) -> None:
         """expand_commit + backup of one step and (select_next) the selection of the next one in one launch; `leaf`
         holds this step's leaves on entry and the next step's on exit."""
         assert rollout.dtype == torch.float32 and rollout.is_contiguous() and rollout.shape[0] == self.G
@@ -143,9 +143,10 @@ class TreePool:
         for t, n in ((leaf, self.G), (rand_child, self.G), (out_child, self.G), (out_row, self.G),
                      (out_child_rows, self.G * self.A), (rand_next, self.G), (out_drawn_row, self.G)):
             assert t is None or (t.dtype == torch.int32 and t.numel() == n and t.is_contiguous())
+        assert reward0 is None or (reward0.dtype == torch.float32 and reward0.numel() == self.G and reward0.is_contiguous())
         _hip.check(_hip.lib().mz_tree_commit_backup_select(
             C.byref(self.c), ptr(leaf), ptr(prior), ptr(reward), ptr(rand_child), ptr(out_child), ptr(rollout),
-            rollout.shape[1], float(discount), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
+            ptr(reward0), rollout.shape[1], float(discount), ptr(self.sqrt_tab), ptr(self.log_tab), self.tab_len,
             _hip.SELECT_ROOT_F32 if root_f32 else 0, 1 if select_next else 0, ptr(out_row), ptr(out_child_rows),
             ptr(rand_next), ptr(out_drawn_row), _stream()), "mz_tree_commit_backup_select")
 
@@ -274,7 +275,9 @@ class BatchedMCTS:
         # the last G entries of a [2G] buffer: one f call can serve the leaf and the drawn child (_step_chain)
         self.prior2 = torch.zeros((2 * G, A), **f32)
         self.prior = self.prior2[:G]
-        self.reward = torch.zeros((G, A), **f32)
+        # the children's rewards, then (one-chain schedule) the reward of the rollout's first step: one head call
+        self.reward3 = torch.zeros(G * A + G, **f32)
+        self.reward = self.reward3[:G * A].view(G, A)
         self.rollout_t = torch.zeros((self.depth + 1, G), **f32)
         self.act2 = torch.zeros(2 * G, **i32)
         self.act = self.act2[G:]
@@ -291,7 +294,8 @@ class BatchedMCTS:
         self.rollout = torch.zeros((G, self.depth + 1), **f32)   # [r_1 .. r_depth, v] per tree
         self.rows2 = torch.zeros(2 * G, **i32)   # rows of the leaf, then rows of the drawn child
         self.rows_buf = [self.rows2[:G], self.rows2[G:]]
-        self.next_rows_buf = torch.zeros((G, A), **i32)
+        self.rows3 = torch.zeros(G * A + G, **i32)   # rows of the children-to-be, then the rows the first rollout step writes
+        self.next_rows_buf = self.rows3[:G * A].view(G, A)
         self.child_slots = (self.tree_base[:, None] + self.arange_a[None, :]).contiguous()
         self.keep_latents = keep_latents or not dt or getattr(nets, "tower_f_t", None) is None
         self.use_graph = True
@@ -302,8 +306,11 @@ class BatchedMCTS:
         self.rand_static = torch.zeros((0, G), **i32)  # the recorded search's child draws [n, G]
         self.replays = 0
         self._warm_version = None
-        self.t_pool = torch.zeros((G * self.pool.cap, dt), **f32) if dt else None
-        self.tmp_t = [torch.zeros((G, dt), **f32) for _ in range(2)] if dt else None
+        # bottleneck values of every node, followed by G rows for the latents of the rollout's first step
+        self.t_pool = torch.zeros((G * self.pool.cap + G, dt), **f32) if dt else None
+        self.tmp_t = [self.t_pool[G * self.pool.cap:], torch.zeros((G, dt), **f32)] if dt else None
+        if dt:
+            self.rows3[G * A:] = torch.arange(G * self.pool.cap, G * self.pool.cap + G, **i32)
 
     def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor, root: bool = False) -> None:
         """expand_node (src/search/expansion.py:9-35) for one node per tree (`root`: the nodes are
@@ -331,7 +338,7 @@ class BatchedMCTS:
             main.wait_stream(self.side)
         pool.expand_commit(node, self.prior, self.reward, rand_child, out_child, out_child_row=self.rows_buf[1])
 
-    def _simulate(self, child: torch.Tensor, first_action_known: bool = False) -> torch.Tensor:
+    def _simulate(self, child: torch.Tensor, first_action_known: bool = False, reward_with_children: bool = False) -> torch.Tensor:
         """MuZeroSimulation (src/search/simulation.py:23-45) from one node per tree;
         returns rollout f32[G, depth+1].  first_action_known: self.act already holds the greedy action of the
         first step (f was evaluated for the drawn child together with the leaf)."""
@@ -359,7 +366,14 @@ class BatchedMCTS:
             else:
                 if not (first_action_known and d == 0):
                     nets.prediction(cur, G, rows=rows, argmax=self.act, **f_extra)
-                nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), **extra)
+                if reward_with_children and d == 0:
+                    # the first step's reward and the A children's rewards in one head call: the step's bottleneck
+                    # values were written behind the pool's (tmp_t[0]), rows3 names both sets of rows; the step's
+                    # reward stays in reward3[G * A:] (the tree kernel reads it from there)
+                    nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=None, **extra)
+                    nets.reward_on_t(self.t_pool, self.rows3, G * self.A + G, self.reward3)
+                else:
+                    nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), **extra)
             cur, rows = nxt, None
             if self.t_pool is not None:
                 t_in = (self.tmp_t[d & 1], None)
@@ -423,12 +437,15 @@ class BatchedMCTS:
                           t_in=(self.t_pool, rows), t_out=self.t_pool, want_latent=False)
             nets.prediction(pool.latent, 2 * G, rows=self.rows2, softmax_times=1, policy=self.prior2, argmax=self.act2,
                             t_in=(self.t_pool, self.rows2))
-            rollout = self._simulate(self.child, first_action_known=True)
-            nets.reward_on_t(self.t_pool, next_rows, G * A, self.reward)
+            merged = self.depth >= 1 and self.depth + 1 <= 8
+            rollout = self._simulate(self.child, first_action_known=True, reward_with_children=merged)
+            if not merged:
+                nets.reward_on_t(self.t_pool, next_rows, G * A, self.reward)
             last = s + 1 == n
             pool.commit_backup_select(self.leaf, self.prior, self.reward, rand[s], self.child, rollout, self.discount,
                                       select_next=not last, out_row=rows, out_child_rows=self.next_rows_buf,
-                                      rand_next=rand[s if last else s + 1], out_drawn_row=self.rows_buf[1])
+                                      rand_next=rand[s if last else s + 1], out_drawn_row=self.rows_buf[1],
+                                      reward0=self.reward3[G * A:] if merged else None)
 
     def strided_rollout(self) -> bool:
         return bool(getattr(self.nets, "strided_outputs", False))
