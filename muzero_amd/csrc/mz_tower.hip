@@ -1429,19 +1429,21 @@ inline ThinBlock thin_block(const mz_tower *T) {
 // over those channels -- x never leaves the registers.  A wave owns 32 channels: its convolution product is
 // a partial sum over them for all 64 rows x 32 columns; the eight partials meet in LDS and are added in
 // wave order.
-constexpr int kMcT = 512, kMcRows = 64, kMcC = 256;
+constexpr int kMcT = 512, kMcC = 256;  // rows per workgroup: 16 * MTR (64, or 32 when there are few rows)
 constexpr int kMcLdP = kYCols + 4;  // row stride of a partial product in LDS: four rows apart land 16 banks apart
 constexpr int kMcMaxKT = 8;         // merge product: at most 128 bottleneck values per row
-constexpr size_t kMcLds = ((size_t)(kMcT / 64) * kMcRows * kMcLdP + kMcRows) * sizeof(float);
+constexpr size_t mc_lds(int rows) { return ((size_t)(kMcT / 64) * rows * kMcLdP + rows) * sizeof(float); }
 
 // Two workgroups share a compute unit (128 registers, 74 KB of LDS each): while one waits at a barrier or
 // for its rows, the other's waves fill the matrix pipe.
+template <int MTR>
 __global__ void __launch_bounds__(kMcT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, long long wg_off,
              const float *__restrict__ t, long long ld_t, const int32_t *__restrict__ t_rows, int B,
              const float *__restrict__ table, const int32_t *__restrict__ action, int A, int nA, int HW,
              float *__restrict__ Y, int skip) {
     extern __shared__ __align__(16) float smem[];
+    constexpr int kMcRows = 16 * MTR, TPR = kMcT / kMcRows;  // rows per workgroup; threads that stage / add up one row
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
     const int pos = blockIdx.y, r0 = blockIdx.x * kMcRows;
@@ -1458,23 +1460,21 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
         b1[1] = wm[(long long)(KTm + 1) * 64];
     }
     {
-        // eight threads per row: the row index is fetched once, then the row's values are requested together
-        const int r = tid >> 3, k0 = tid & 7;
+        // TPR threads per row: the row index is fetched once, then the row's values are requested together
+        const int r = tid / TPR, k0 = tid % TPR;
         long long row = -1;
         if (r0 + r < B) row = t_rows ? (long long)t_rows[r0 + r] : (long long)(r0 + r);
+        constexpr int NV = 16 * kMcMaxKT / TPR;  // values per thread
+        float v[NV];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float v[kMcMaxKT];
+        for (int j = 0; j < NV; ++j) {
+            const int k = k0 + TPR * j;
+            v[j] = (row >= 0 && k < Kt && !(skip & 8)) ? t[row * ld_t + k] : 0.0f;
+        }
 #pragma unroll
-            for (int j = 0; j < kMcMaxKT; ++j) {
-                const int k = k0 + 8 * (h * kMcMaxKT + j);
-                v[j] = (row >= 0 && k < Kt && !(skip & 8)) ? t[row * ld_t + k] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < kMcMaxKT; ++j) {
-                const int k = k0 + 8 * (h * kMcMaxKT + j);
-                if (k < KTm * 16) Ts[r * ldT + k] = v[j];
-            }
+        for (int j = 0; j < NV; ++j) {
+            const int k = k0 + TPR * j;
+            if (k < KTm * 16) Ts[r * ldT + k] = v[j];
         }
     }
     if (tid < kMcRows) {
@@ -1492,9 +1492,9 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
 
     // ---- z for this position, transposed: wave w owns channels 32 w .. 32 w + 31 (two tiles), all four row tiles;
     //      acc[mt][n][i] = z[row 16 mt + m][channel 32 w + 16 n + 4 kq + i]
-    f32x4 acc[4][2];
+    f32x4 acc[MTR][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[mt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < KTm; ++kt) {
@@ -1505,53 +1505,53 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
             b1[0] = wm[(long long)(kt + 2) * 64];
             b1[1] = wm[(long long)(KTm + kt + 2) * 64];
         }
-        f32x4 a4[4];
+        f32x4 a4[MTR];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a4[mt] = *reinterpret_cast<const lds_f4 *>(Ts + (mt * 16 + m) * ldT + kt * 16 + 4 * kq);
+        for (int mt = 0; mt < MTR; ++mt) a4[mt] = *reinterpret_cast<const lds_f4 *>(Ts + (mt * 16 + m) * ldT + kt * 16 + 4 * kq);
         if (!(skip & 1))
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[n][j], a4[mt][j], acc[mt][n], 0, 0, 0);
     }
-    int act_m[4] = {0, 0, 0, 0};
+    int act_m[MTR] = {};
     if (action)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) act_m[mt] = s_act[mt * 16 + m];
+        for (int mt = 0; mt < MTR; ++mt) act_m[mt] = s_act[mt * 16 + m];
     __syncthreads();  // every wave has read its rows of t
     // ---- per action: x = relu(z + table[action]) in registers, this wave's part of Y = x Wg, partials added through LDS
     const int rrow = tid >> 3, rc4 = tid & 7;  // the output piece this thread adds up: row, four columns
     for (int ai = 0; ai < nA; ++ai) {
-        f32x4 y[4][2];
+        f32x4 y[MTR][2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) y[mt][0] = y[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MTR; ++mt) y[mt][0] = y[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 *trow = reinterpret_cast<const f32x4 *>(table + ((long long)ai * HW + pos) * kMcC + 32 * wave + 4 * kq);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             // the table values of this lane's four channels: per row tile where rows carry their own action
-            f32x4 tv[4];
+            f32x4 tv[MTR];
             if (action) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MTR; ++mt)
                     tv[mt] = *reinterpret_cast<const f32x4 *>(table + ((long long)act_m[mt] * HW + pos) * kMcC + 32 * wave + 16 * n + 4 * kq);
             } else {
                 tv[0] = trow[4 * n];
 #pragma unroll
-                for (int mt = 1; mt < 4; ++mt) tv[mt] = tv[0];
+                for (int mt = 1; mt < MTR; ++mt) tv[mt] = tv[0];
             }
-            f32x4 x[4];
+            f32x4 x[MTR];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[mt][i] = fmaxf(acc[mt][n][i] + tv[mt][i], 0.0f);
             if (!(skip & 2))
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2)
                             y[mt][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][j], g[n][c2][j], y[mt][c2], 0, 0, 0);
@@ -1559,13 +1559,13 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
         // y[mt][c2][i] = partial Y[row 16 mt + 4 kq + i][column 16 c2 + m]
         lds_f *pw = Ps + (size_t)wave * kMcRows * kMcLdP;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MTR; ++mt)
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pw[(mt * 16 + 4 * kq + i) * kMcLdP + 16 * c2 + m] = y[mt][c2][i];
         __syncthreads();
-        {
+        if (tid < kMcRows * 8) {
             f32x4 sum = *reinterpret_cast<const lds_f4 *>(Ps + rrow * kMcLdP + 4 * rc4);
 #pragma unroll
             for (int w = 1; w < kMcT / 64; ++w) {
@@ -1847,15 +1847,30 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
         return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: the convolution product must map %d channels to at most %d columns", C, kYCols);
     if (HW > 65535) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: more than 65535 positions");
     const int KTm = h_merge->Kp >> 4;
-    const size_t lds = kMcLds;  // the rows of t (64 x at most 132 floats) fit the area of the partial products
-    MZ_TRY(allow_lds(k_merge_conv, lds, "k_merge_conv"));
+    // 64 rows per workgroup, or 32 when 64-row workgroups number more than the compute units but fewer than a few
+    // per unit (512 .. 2048 trees): two half-size workgroups share a unit and hide each other's barriers and
+    // round trips (1024 trees: 3.90 -> 4.08 M sims/s).  With fewer workgroups than units halving them only
+    // doubles up some units (256 trees: slower), with many the larger tile's weight reuse wins.
+    static const int small_lo = [] { const char *e = getenv("MZ_MC_SMALL_LO"); return e ? atoi(e) : 256; }();   // tuning aids
+    static const int small_hi = [] { const char *e = getenv("MZ_MC_SMALL_HI"); return e ? atoi(e) : 1200; }();
+    const long long wgs64 = (long long)((B + 63) / 64) * HW;
+    const bool small = wgs64 > small_lo && wgs64 < small_hi;
+    const int rows = small ? 32 : 64;
+    const size_t lds = mc_lds(rows);  // the rows of t (at most 132 floats each) fit the area of the partial products
+    MZ_TRY(allow_lds(k_merge_conv<4>, mc_lds(64), "k_merge_conv"));
+    MZ_TRY(allow_lds(k_merge_conv<2>, mc_lds(32), "k_merge_conv"));
     static const int skip = [] {
         const char *e = getenv("MZ_MC_SKIP");  // timing aid: leaves out parts of the kernel (results are then meaningless)
         return e ? atoi(e) : 0;
     }();
-    hipLaunchKernelGGL(k_merge_conv, dim3((B + kMcRows - 1) / kMcRows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
-                       (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B, table,
-                       action, A, action ? 1 : A, HW, Y, skip);
+    if (small)
+        hipLaunchKernelGGL(k_merge_conv<2>, dim3((B + rows - 1) / rows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
+                           (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B,
+                           table, action, A, action ? 1 : A, HW, Y, skip);
+    else
+        hipLaunchKernelGGL(k_merge_conv<4>, dim3((B + rows - 1) / rows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
+                           (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B,
+                           table, action, A, action ? 1 : A, HW, Y, skip);
     return mz::check_launch("k_merge_conv");
 }
 
