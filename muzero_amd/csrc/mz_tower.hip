@@ -1443,7 +1443,7 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
              const float *__restrict__ table, const int32_t *__restrict__ action, int A, int nA, int HW,
              float *__restrict__ Y, int skip) {
     extern __shared__ __align__(16) float smem[];
-    constexpr int kMcRows = 16 * MTR, TPR = kMcT / kMcRows;  // rows per workgroup; threads that stage / add up one row
+    constexpr int kMcRows = 16 * MTR, TPR = 8;  // rows per workgroup; threads that stage one row
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kq = lane >> 4;
     const int pos = blockIdx.y, r0 = blockIdx.x * kMcRows;
@@ -1463,7 +1463,7 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
         // TPR threads per row: the row index is fetched once, then the row's values are requested together
         const int r = tid / TPR, k0 = tid % TPR;
         long long row = -1;
-        if (r0 + r < B) row = t_rows ? (long long)t_rows[r0 + r] : (long long)(r0 + r);
+        if (r < kMcRows && r0 + r < B) row = t_rows ? (long long)t_rows[r0 + r] : (long long)(r0 + r);
         constexpr int NV = 16 * kMcMaxKT / TPR;  // values per thread
         float v[NV];
 #pragma unroll
@@ -1474,7 +1474,7 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int k = k0 + TPR * j;
-            if (k < KTm * 16) Ts[r * ldT + k] = v[j];
+            if (k < KTm * 16 && r < kMcRows) Ts[r * ldT + k] = v[j];
         }
     }
     if (tid < kMcRows) {
@@ -1847,30 +1847,35 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
         return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: the convolution product must map %d channels to at most %d columns", C, kYCols);
     if (HW > 65535) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: more than 65535 positions");
     const int KTm = h_merge->Kp >> 4;
-    // 64 rows per workgroup, or 32 when 64-row workgroups number more than the compute units but fewer than a few
-    // per unit (512 .. 2048 trees): two half-size workgroups share a unit and hide each other's barriers and
-    // round trips (1024 trees: 3.90 -> 4.08 M sims/s).  With fewer workgroups than units halving them only
-    // doubles up some units (256 trees: slower), with many the larger tile's weight reuse wins.
+    // Rows per workgroup.  64 with many workgroups per compute unit (the larger tile's weight reuse wins); 32 when
+    // 64-row workgroups number more than the units but fewer than a few per unit (512 .. 2048 trees: two half-size
+    // workgroups share a unit and hide each other's barriers and round trips, 1024 trees 3.90 -> 4.08 M sims/s);
+    // with fewer 64-row workgroups than units (a few hundred trees: the launch is one latency chain per workgroup)
+    // the smallest of 64 / 48 / 32 that still gives every workgroup a unit of its own.
     static const int small_lo = [] { const char *e = getenv("MZ_MC_SMALL_LO"); return e ? atoi(e) : 256; }();   // tuning aids
     static const int small_hi = [] { const char *e = getenv("MZ_MC_SMALL_HI"); return e ? atoi(e) : 1200; }();
-    const long long wgs64 = (long long)((B + 63) / 64) * HW;
-    const bool small = wgs64 > small_lo && wgs64 < small_hi;
-    const int rows = small ? 32 : 64;
+    auto wgs = [&](int r) { return (long long)((B + r - 1) / r) * HW; };
+    int rows = 64;
+    if (wgs(64) > small_lo && wgs(64) < small_hi) rows = 32;
+    else if (wgs(64) <= small_lo) rows = wgs(32) <= small_lo ? 32 : wgs(48) <= small_lo ? 48 : 64;
+    static const int force_rows = [] { const char *e = getenv("MZ_MC_ROWS"); return e ? atoi(e) : 0; }();
+    if (force_rows == 32 || force_rows == 48 || force_rows == 64) rows = force_rows;
     const size_t lds = mc_lds(rows);  // the rows of t (at most 132 floats each) fit the area of the partial products
     MZ_TRY(allow_lds(k_merge_conv<4>, mc_lds(64), "k_merge_conv"));
     MZ_TRY(allow_lds(k_merge_conv<2>, mc_lds(32), "k_merge_conv"));
+    MZ_TRY(allow_lds(k_merge_conv<3>, mc_lds(48), "k_merge_conv"));
     static const int skip = [] {
         const char *e = getenv("MZ_MC_SKIP");  // timing aid: leaves out parts of the kernel (results are then meaningless)
         return e ? atoi(e) : 0;
     }();
-    if (small)
-        hipLaunchKernelGGL(k_merge_conv<2>, dim3((B + rows - 1) / rows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((B + rows - 1) / rows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
                            (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B,
                            table, action, A, action ? 1 : A, HW, Y, skip);
-    else
-        hipLaunchKernelGGL(k_merge_conv<4>, dim3((B + rows - 1) / rows, HW), dim3(kMcT), lds, (hipStream_t)stream, blob,
-                           (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B,
-                           table, action, A, action ? 1 : A, HW, Y, skip);
+    };
+    if (rows == 32) launch(k_merge_conv<2>);
+    else if (rows == 48) launch(k_merge_conv<3>);
+    else launch(k_merge_conv<4>);
     return mz::check_launch("k_merge_conv");
 }
 
