@@ -214,6 +214,14 @@ int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *
 int mz_mlp_forward_post(const mz_packed_mlp *plan, const float *blob, const float *x, int64_t ldx,
                         const int32_t *x_rows, float *y, int64_t ldy, int32_t B,
                         int32_t softmax_times, int32_t *argmax, void *stream);
+/* Two mz_mlp_forward calls in one launch (both packed in the same blob; no softmax / argmax): heads whose inputs
+ * are ready at the same moment, e.g. reward_mlp over new children and value_mlp at the end of a rollout
+ * (neural_network.py:186-188, :256-262).  Same results as the two calls; batches of 8192 rows or more are
+ * run as two launches. */
+int mz_mlp_forward_pair(const mz_packed_mlp *plan0, const float *x0, int64_t ldx0, const int32_t *x_rows0,
+                        float *y0, int64_t ldy0, int32_t B0, const mz_packed_mlp *plan1, const float *x1,
+                        int64_t ldx1, const int32_t *x_rows1, float *y1, int64_t ldy1, int32_t B1,
+                        const float *blob, void *stream);
 
 /* g: DynamicsNetwork.forward for MLP-only configs, src/neural_networks/neural_network.py:152-188
  *    next = relu(fc_merge([latent ; action_embedding[action]])), reward = reward_mlp(next).

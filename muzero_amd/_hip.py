@@ -112,6 +112,8 @@ _SIGS = {
     "mz_mlp_plan": (C.c_int64, [C.POINTER(Mlp), C.c_int64, C.POINTER(PackedMlp)]),
     "mz_mlp_pack": (C.c_int, [C.POINTER(Mlp), C.POINTER(PackedMlp), _P, _P]),
     "mz_mlp_forward": (C.c_int, [C.POINTER(PackedMlp), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P]),
+    "mz_mlp_forward_pair": (C.c_int, [C.POINTER(PackedMlp), _P, C.c_int64, _P, _P, C.c_int64, C.c_int32,
+                                      C.POINTER(PackedMlp), _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     "mz_mlp_forward_post": (C.c_int, [C.POINTER(PackedMlp), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, C.c_int32,
                                       _P, _P]),
     "mz_nets_plan": (C.c_int, [C.POINTER(DynamicsNet), C.POINTER(PredictionNet), C.POINTER(PackedNets)]),

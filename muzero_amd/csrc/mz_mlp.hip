@@ -82,6 +82,49 @@ k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__re
     }
 }
 
+// Two independent MLPs in one launch (workgroups [0, blocks0) run the first, the rest the second): heads that
+// have their inputs at the same moment of a latency-bound chain share a launch instead of queueing.
+struct MlpJob {
+    const float *x;
+    long long ldx;
+    const int32_t *x_rows;
+    float *y;
+    long long ldy;
+    int B;
+};
+__device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const float *__restrict__ blob, const MlpJob &J, int row0,
+                                                 float *smem) {
+    constexpr int TM = 16;
+    const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
+    lds_f *X = to_lds(smem), *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
+    const int rows = min(TM, J.B - row0);
+    const float *x = J.x;
+    const int32_t *x_rows = J.x_rows;
+    const long long ldx = J.ldx;
+    load_rows(X, ld_in, TM, rows, M.in_features, [&](int r) -> const float * {
+        long long src = x_rows ? (long long)x_rows[row0 + r] : (long long)(row0 + r);
+        return src < 0 ? nullptr : x + src * ldx;
+    });
+    int ld_out;
+    lds_f *out = mlp_tile<1>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    const int N = M.out_features;
+    float *y = J.y;
+    const long long ldy = J.ldy;
+    for (int i = threadIdx.x; i < rows * N; i += kThreads) {
+        const int r = i / N, c = i - r * N;
+        y[(long long)(row0 + r) * ldy + c] = out[r * ld_out + c];
+    }
+}
+// (two branches rather than a selected plan: a plan chosen at run time would be copied to per-lane stack memory)
+__global__ void __launch_bounds__(kThreads)
+k_mlp_forward_pair(mz_packed_mlp M0, mz_packed_mlp M1, const float *__restrict__ blob, MlpJob j0, MlpJob j1, int blocks0) {
+    extern __shared__ __align__(16) float smem[];
+    if ((int)blockIdx.x < blocks0)
+        mlp_rows_forward(M0, blob, j0, (int)blockIdx.x * 16, smem);
+    else
+        mlp_rows_forward(M1, blob, j1, ((int)blockIdx.x - blocks0) * 16, smem);
+}
+
 template <int MT>
 __global__ void __launch_bounds__(kThreads)
 k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__restrict__ latent, long long ld_latent,
@@ -284,6 +327,28 @@ int mz_mlp_forward_post(const mz_packed_mlp *h_plan, const float *blob, const fl
                                (long long)ldx, x_rows, y, (long long)ldy, B, softmax_times, argmax);
             return mz::check_launch("k_mlp_forward<2>");
         });
+}
+
+int mz_mlp_forward_pair(const mz_packed_mlp *h_plan0, const float *x0, int64_t ldx0, const int32_t *x_rows0, float *y0,
+                        int64_t ldy0, int32_t B0, const mz_packed_mlp *h_plan1, const float *x1, int64_t ldx1,
+                        const int32_t *x_rows1, float *y1, int64_t ldy1, int32_t B1, const float *blob, void *stream) {
+    if (!h_plan0 || !h_plan1 || !blob || !x0 || !x1 || !y0 || !y1 || B0 < 0 || B1 < 0 || ldx0 < h_plan0->in_features ||
+        ldx1 < h_plan1->in_features || ldy0 < h_plan0->out_features || ldy1 < h_plan1->out_features)
+        return mz::fail(MZ_ERR_ARG, "mz_mlp_forward_pair: NULL argument, negative B, or row stride below the row width");
+    // large batches gain more from the 32-row tiles of mz_mlp_forward than from sharing a launch
+    if (B0 == 0 || B1 == 0 || B0 >= 16 * 512 || B1 >= 16 * 512) {
+        MZ_TRY(mz_mlp_forward(h_plan0, blob, x0, ldx0, x_rows0, y0, ldy0, B0, stream));
+        return mz_mlp_forward(h_plan1, blob, x1, ldx1, x_rows1, y1, ldy1, B1, stream);
+    }
+    auto per_row = [](const mz_packed_mlp *p) { return (size_t)lds_stride(p->in_features) + 2 * (size_t)lds_stride(p->max_width); };
+    const size_t lds = 16 * std::max(per_row(h_plan0), per_row(h_plan1)) * sizeof(float);
+    if (lds > kMaxLds) return mz::fail(MZ_ERR_ARG, "network too wide: needs %zu bytes of LDS per tile", lds);
+    MZ_TRY(allow_lds(k_mlp_forward_pair, lds, "k_mlp_forward_pair"));
+    const int blocks0 = (B0 + 15) / 16, blocks1 = (B1 + 15) / 16;
+    hipLaunchKernelGGL(k_mlp_forward_pair, dim3(blocks0 + blocks1), dim3(kThreads), lds, (hipStream_t)stream, *h_plan0, *h_plan1,
+                       blob, MlpJob{x0, (long long)ldx0, x_rows0, y0, (long long)ldy0, B0},
+                       MlpJob{x1, (long long)ldx1, x_rows1, y1, (long long)ldy1, B1}, blocks0);
+    return mz::check_launch("k_mlp_forward_pair");
 }
 
 int mz_mlp_forward(const mz_packed_mlp *h_plan, const float *blob, const float *x, int64_t ldx,

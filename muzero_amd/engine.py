@@ -371,6 +371,9 @@ class BatchedMCTS:
                     # values were written behind the pool's (tmp_t[0]), rows3 names both sets of rows; the step's
                     # reward stays in reward3[G * A:] (the tree kernel reads it from there)
                     nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=None, **extra)
+                    if self.depth == 1 and hasattr(nets, "value_with_rewards") and nets.value_with_rewards(
+                            (self.tmp_t[0], None), G, out_col(1), self.t_pool, self.rows3, G * self.A + G, self.reward3):
+                        return self.rollout if strided else self.rollout_t.t().contiguous()  # f's block, then both heads at once
                     nets.reward_on_t(self.t_pool, self.rows3, G * self.A + G, self.reward3)
                 else:
                     nets.dynamics(cur, G, rows=rows, action=self.act, next_latent=nxt, reward=out_col(d), **extra)

@@ -460,6 +460,25 @@ class TowerNetworks:
         """reward_mlp on the bottleneck values of B latents (rows of t), into out f32[B] (bottleneck form only)."""
         self._mlp_on(self.reward_t, "reward_t", t, t.shape[-1], rows, B, out=out)
 
+    def value_with_rewards(self, t_in, B, value, t, rows, n, reward) -> bool:
+        """f's value for B nodes given by their bottleneck values (t_in = (t, rows)) and reward_mlp for n other rows
+        of `t`, the two heads in one launch (mz_mlp_forward_pair) after f's block.  value: f32[B], contiguous or a
+        1-D view with a stride; reward f32[n] contiguous.  False: not available in this form (nothing was run)."""
+        if not (self.bottleneck_f and self.tower_f_t is not None and self.value_t is not None and self.reward_t is not None):
+            return False
+        if value.dtype != torch.float32 or reward.dtype != torch.float32 or not reward.is_contiguous():
+            return False
+        ldv = 1 if value.is_contiguous() else (value.stride(0) if value.dim() == 1 else 0)
+        if ldv <= 0:
+            return False
+        src, src_rows = t_in
+        ft = self._buf("f_t", (B, self.bottleneck_f))
+        self._tower_call(self.tower_f_t, src, src.shape[-1], src_rows, None, None, None, 0, None, B, 1, t_out=ft)
+        _hip.check(_hip.lib().mz_mlp_forward_pair(C.byref(self.reward_t), ptr(t), t.shape[-1], ptr(rows), ptr(reward), 1, n,
+                                                  C.byref(self.value_t), ptr(ft), ft.shape[-1], None, ptr(value), ldv, B,
+                                                  ptr(self.blob), _stream()), "mz_mlp_forward_pair")
+        return True
+
     def merge_conv(self, t, t_rows, action, n_src) -> torch.Tensor:
         """fc_merge on bottleneck values + the per-action term + the first product of g's tower in one launch
         (only when `fused_g`): Y f32[rows][H*W][32] for rows = n_src (action i32[n_src]) or n_src * A (action None:

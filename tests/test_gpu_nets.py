@@ -139,3 +139,34 @@ def test_reference_vectors_c4_mlp():
     np.testing.assert_allclose(r.cpu().numpy(), z["g_reward"][:, 0], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(p.cpu().numpy(), z["f_policy"], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(v.cpu().numpy(), z["f_value"][:, 0], rtol=RTOL, atol=ATOL)
+
+
+def test_two_heads_in_one_launch_equal_two_launches():
+    """mz_mlp_forward_pair (reward head over gathered rows + value head over other rows, one launch) against two
+    mz_mlp_forward calls: identical bits, ragged row counts, a strided one-output destination."""
+    import ctypes as C
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    from muzero_amd.engine import PackedNetworks
+    _, g, f = _c4_nets(1)
+    nets = PackedNetworks(g, f)
+    lib = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    D = nets.plan.D
+    B0, B1 = 1301, 77
+    x0 = torch.randn(B0 + 5, D, device="cuda", generator=gen)
+    r0 = torch.randperm(B0 + 5, device="cuda", generator=gen)[:B0].to(torch.int32)
+    r0[3] = -1   # an absent row reads as zeros
+    x1 = torch.randn(B1, D, device="cuda", generator=gen)
+    p0, p1 = nets.plan.reward, nets.plan.value
+    blob = nets.blob
+    want0, want1 = torch.zeros(B0, device="cuda"), torch.zeros(B1, 2, device="cuda")
+    _hip.check(lib.mz_mlp_forward(C.byref(p0), ptr(blob), ptr(x0), D, ptr(r0), ptr(want0), 1, B0, st), "a")
+    _hip.check(lib.mz_mlp_forward(C.byref(p1), ptr(blob), ptr(x1), D, None, ptr(want1), 2, B1, st), "b")
+    got0, got1 = torch.zeros(B0, device="cuda"), torch.zeros(B1, 2, device="cuda")
+    _hip.check(lib.mz_mlp_forward_pair(C.byref(p0), ptr(x0), D, ptr(r0), ptr(got0), 1, B0,
+                                       C.byref(p1), ptr(x1), D, None, ptr(got1), 2, B1, ptr(blob), st), "pair")
+    torch.cuda.synchronize()
+    assert torch.equal(got0, want0) and torch.equal(got1, want1)
+    assert float(got1[:, 1].abs().max()) == 0.0 and float(got0.abs().max()) > 0.0
