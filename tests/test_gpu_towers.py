@@ -857,3 +857,39 @@ def test_tower_running_statistics_follow_the_reference_calls(ni, ti):
     # the parameters were not touched
     assert all(torch.equal(p, q) for p, q in zip(list(g.parameters()) + list(f.parameters()),
                                                  list(g_ref.parameters()) + list(f_ref.parameters())))
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_one_chain_recorded_search_equals_launch_by_launch(depth):
+    """Shipped network shapes (latent [256, 6, 6]), nodes kept as bottleneck values: the recorded search runs a step as
+    one chain of launches -- one-launch tree step (mz_tree_commit_backup_select), the children's rewards together with
+    the first rollout step's, reward and value heads side by side -- whereas the launch-by-launch search uses the
+    separate kernels.  Same pools, bottleneck values and results, bit for bit, with a look-ahead of 1 and of 2 and a
+    tree count that fills no tile."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    A = 5
+    g, f = build_nets((256, 6, 6), A)
+    nets = TowerNetworks(g, f)
+    assert nets.fused_g
+    G, S, D = 40, 8, 256 * 36
+    rng = np.random.default_rng(21 + depth)
+    eager = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25, keep_latents=False)
+    eager.use_graph = False
+    graphed = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25, keep_latents=False)
+    assert graphed._forked() and graphed.step_schedule == "chain" and graphed.fuse_tree_kernels
+    for round_ in range(3):
+        lat = torch.from_numpy(rng.standard_normal((G, D)).astype(np.float32)).cuda()
+        eta = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).cuda()
+        rand = torch.from_numpy(rng.integers(0, A, size=(G, S + 1)).astype(np.int32)).cuda()
+        to_play = torch.ones(G, dtype=torch.int8, device="cuda")
+        a, b = eager.run(lat, to_play, eta, rand), graphed.run(lat, to_play, eta, rand)
+        torch.cuda.synchronize()
+        assert graphed.replays == (0, 1, 2)[round_]
+        for name in ("visit", "value_sum", "prior", "reward", "first_child"):
+            assert torch.equal(getattr(eager.pool, name), getattr(graphed.pool, name)), (round_, name)
+        cap = eager.pool.cap
+        assert torch.equal(eager.t_pool[:G * cap], graphed.t_pool[:G * cap])
+        assert torch.equal(a.policy, b.policy) and torch.equal(a.value, b.value) and torch.equal(a.visits, b.visits)
+        assert int(a.visits.sum()) == G * S
