@@ -76,9 +76,32 @@ def run(G: int, S: int, A: int, depth: int = 1) -> dict:
     d = depth_sum / S
     bytes_per_sim = 20 * A * d + 4 * d + 32 * A + 24 * (d + 2)
     sims = G * S
+
+    # the same search with the tree side of a step as ONE launch (child records + backup + next descent)
+    def once_fused():
+        pool.init(to_play)
+        pool.expand_commit(leaf.zero_(), prior[0], reward[0], rand[0], child)
+        pool.root_noise(eta, 0.25)
+        pool.select(leaf)
+        for s in range(S):
+            pool.commit_backup_select(leaf, prior[s + 1], reward[s + 1], rand[s + 1], child, sim[s], 0.998,
+                                      select_next=s + 1 < S)
+
+    visits_separate = pool.visit.clone()
+    once_fused()
+    torch.cuda.synchronize()
+    assert torch.equal(pool.visit, visits_separate), "the one-launch step built other trees"
+    e0.record()
+    once_fused()
+    e1.record()
+    torch.cuda.synchronize()
+    fused_ms = e0.elapsed_time(e1)
     return {"metric": "tree_simulations_per_sec", "value": sims / total_ms * 1e3, "unit": "sims/s", "games": G,
             "sims_per_move": S, "actions": A, "mean_leaf_depth": d, "algorithmic_bytes_per_sim": bytes_per_sim,
             "ms_per_search": total_ms,
+            "one_launch_per_step": {"value": sims / fused_ms * 1e3, "ms_per_search": fused_ms,
+                                    "us_per_launch": fused_ms / S * 1e3,
+                                    "hbm_frac": sims * bytes_per_sim / fused_ms / 1e6 / HBM_PEAK_GBPS},
             "kernel_us_per_launch": {"k_select": t_sel / S * 1e3, "k_expand_commit": t_exp / S * 1e3,
                                      "k_backup": t_bak / S * 1e3},
             "roofline": {"bound": "hbm", "achieved": sims * bytes_per_sim / total_ms / 1e6, "peak": HBM_PEAK_GBPS,
