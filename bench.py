@@ -222,23 +222,32 @@ def tower_search(G, S, dev, steps, with_roofline):
     shape, A = (256, 6, 6), 5
     D = shape[0] * shape[1] * shape[2]
     g, f = build_nets(shape, A)
-    nets = TowerNetworks(g, f, device=dev)
+    # roots in the form the shipped representation network produces them (src/config/config_car_racing.yaml:117-131,
+    # neural_network.py:51,60-61): the final 1x1 convolution 3 -> 256 of 3 x 6 x 6 pooled values; the search starts
+    # from those values (`root_t`), as self-play does
+    torch.manual_seed(1)
+    fin = torch.nn.Conv2d(3, shape[0], 1).to(dev)
+    nets = TowerNetworks(g, f, device=dev, root_final=fin)
     mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev, keep_latents=False)
     gen = torch.Generator(device=dev).manual_seed(0)
-    lat = torch.randn(G, D, device=dev, generator=gen)
+    root_t = torch.randn(G, 3, shape[1], shape[2], device=dev, generator=gen)
+    with torch.no_grad():
+        lat = fin(root_t).reshape(G, D).contiguous()
+    root_kw = {"root_t": root_t} if mcts.root_form_ok(root_t) else {}
     eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((G,)).float().to(dev)
     rand = torch.randint(0, A, (G, S + 1), device=dev, generator=gen, dtype=torch.int32)
     to_play = torch.zeros(G, dtype=torch.int8, device=dev)
     for _ in range(3):  # launch by launch, then the recording, then a replay
-        res = mcts.run(lat, to_play, eta, rand)
+        res = mcts.run(lat, to_play, eta, rand, **root_kw)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = mcts.run(lat, to_play, eta, rand)
+        res = mcts.run(lat, to_play, eta, rand, **root_kw)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
     assert int(res.visits.sum().item()) == G * S and mcts.replays >= steps
-    out = {"workload": f"{G} trees x {S} sims, residual-tower g/f, latent {list(shape)}, {A} actions, lock-step search",
+    out = {"workload": f"{G} trees x {S} sims, residual-tower g/f, latent {list(shape)}, {A} actions, lock-step search, roots as "
+                       + ("the bottleneck values of h's final convolution" if root_kw else "full latents"),
            "sims_per_sec": G * S / dt, "ms_per_search": dt * 1e3, "steps": steps}
     if with_roofline and getattr(nets, "fused_g", False):
         # the kernel that takes most of a step: fc_merge on the bottleneck values + the first product of g's tower

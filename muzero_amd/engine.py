@@ -231,7 +231,8 @@ class PackedNetworks:
             ptr(value), ptr(argmax), B, _stream()), "mz_prediction_forward")
 
 
-def make_networks(dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", track_running_stats: bool = False):
+def make_networks(dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", track_running_stats: bool = False,
+                  root_final: torch.nn.Module | None = None):
     """Device evaluator for a (g, f) pair: `PackedNetworks` (fused kernels, single-launch search)
     for `res_net: []` configurations, `muzero_amd.towers.TowerNetworks` when either network has
     residual blocks or a res_final convolution (`track_running_stats`: its BatchNorm layers' running
@@ -241,7 +242,7 @@ def make_networks(dynamics: torch.nn.Module, prediction: torch.nn.Module, device
     if plain:
         return PackedNetworks(dynamics, prediction, device=device)
     from muzero_amd.towers import TowerNetworks
-    return TowerNetworks(dynamics, prediction, device=device, track_running_stats=track_running_stats)
+    return TowerNetworks(dynamics, prediction, device=device, track_running_stats=track_running_stats, root_final=root_final)
 
 
 @dataclass
@@ -312,7 +313,8 @@ class BatchedMCTS:
         if dt:
             self.rows3[G * A:] = torch.arange(G * self.pool.cap, G * self.pool.cap + G, **i32)
 
-    def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor, root: bool = False) -> None:
+    def _expand(self, node: torch.Tensor, rand_child: torch.Tensor, out_child: torch.Tensor, root: bool = False,
+                root_form: bool = False) -> None:
         """expand_node (src/search/expansion.py:9-35) for one node per tree (`root`: the nodes are
         the roots, whose latents come from h and have no stored bottleneck values)."""
         pool, nets, G, A = self.pool, self.nets, self.G, self.A
@@ -322,7 +324,9 @@ class BatchedMCTS:
         rows, next_rows = self.rows_buf[0], self.next_rows_buf.view(-1)  # else: written by pool.select
         rows_rep = rows if getattr(nets, "strided_outputs", False) else rows.repeat_interleave(A)  # per group is enough there
         main = torch.cuda.current_stream()
-        f_extra = {"t_in": (self.t_pool, rows)} if self.t_pool is not None and not root else {}
+        f_extra = {"t_in": (self.t_pool, rows)} if self.t_pool is not None and (not root or root_form) else {}
+        if root_form:
+            f_extra["root_form"] = True
         if self.side is not None:  # the priors and the children both depend on the leaf only
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
@@ -331,7 +335,10 @@ class BatchedMCTS:
             nets.prediction(pool.latent, G, rows=rows, softmax_times=1, policy=self.prior, **f_extra)
         extra = {}
         if self.t_pool is not None:
-            extra = dict(t_in=None if root else (self.t_pool, rows), t_out=self.t_pool, want_latent=self.keep_latents)
+            extra = dict(t_in=None if (root and not root_form) else (self.t_pool, rows), t_out=self.t_pool,
+                         want_latent=self.keep_latents)
+            if root_form:
+                extra["root_form"] = True
         nets.dynamics(pool.latent, G * A, rows=rows_rep, action=None, next_latent=pool.latent, next_rows=next_rows,
                       reward=self.reward, **extra)
         if self.side is not None:
@@ -383,15 +390,26 @@ class BatchedMCTS:
         nets.prediction(cur, G, rows=rows, value=out_col(self.depth), **({"t_in": t_in} if t_in is not None else {}))
         return self.rollout if strided else self.rollout_t.t().contiguous()
 
-    def begin(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
-              rand_root: torch.Tensor) -> None:
+    def begin(self, root_latent: torch.Tensor | None, root_to_play: torch.Tensor, eta: torch.Tensor,
+              rand_root: torch.Tensor, root_t: torch.Tensor | None = None) -> None:
         """Root creation, root expansion (its child draw `rand_root` i32[G] is discarded, as in
         src/search/mcts.py:89) and the prior perturbation of mcts.py:91-94."""
         pool = self.pool
-        pool.init(root_to_play, root_latent.reshape(self.G, self.D).contiguous())
+        root_form = self.root_form_ok(root_t)
+        assert root_form or root_latent is not None, "root latents are needed unless their bottleneck values can be used"
+        pool.init(root_to_play, root_latent.reshape(self.G, self.D).contiguous() if root_latent is not None else None)
         self.leaf.zero_()
-        self._expand(self.leaf, rand_root.reshape(self.G).contiguous(), self.child, root=True)
+        if root_form:
+            # the roots' latents are final_conv(root_t) of the representation network: kept, like every other node,
+            # as those few values, and expanded in the bottleneck form with weights composed with that convolution
+            self.t_pool[self.tree_base.long()] = root_t.reshape(self.G, -1).to(torch.float32)
+        self._expand(self.leaf, rand_root.reshape(self.G).contiguous(), self.child, root=True, root_form=root_form)
         pool.root_noise(eta.contiguous(), self.noise_frac)
+
+    def root_form_ok(self, root_t) -> bool:
+        """Whether a search can start from the roots' bottleneck values alone (see begin)."""
+        return (root_t is not None and self.t_pool is not None and not self.keep_latents
+                and bool(getattr(self.nets, "has_root_form", False)) and root_t.numel() == self.G * self.t_pool.shape[1])
 
     def _step(self, rand_column: torch.Tensor) -> torch.Tensor:
         """One `_step` (src/search/mcts.py:76-83) for every tree; returns the rollouts."""
@@ -534,9 +552,12 @@ class BatchedMCTS:
         if bool(torch.isnan(result.value).any()):
             raise _hip.HipError("the search kernel reported a stalled wave team (NaN root value)")
 
-    def run(self, root_latent: torch.Tensor, root_to_play: torch.Tensor, eta: torch.Tensor,
-            rand_child: torch.Tensor, trace: dict | None = None, fused: bool | None = None) -> SearchResult:
+    def run(self, root_latent: torch.Tensor | None, root_to_play: torch.Tensor, eta: torch.Tensor,
+            rand_child: torch.Tensor, trace: dict | None = None, fused: bool | None = None,
+            root_t: torch.Tensor | None = None) -> SearchResult:
         """root_latent f32[G, D]; root_to_play i8[G]; eta f32[G, A]; rand_child i32[G, S+1].
+        root_t f32[G, bottleneck] (optional): the few values the roots' latents are the representation network's
+        final 1x1 convolution of; used instead of root_latent (which may then be None) where `root_form_ok`.
 
         `fused` (default: whenever A <= 32) runs the whole search as ONE kernel launch
         (mz_search_run); otherwise the per-stage kernels are driven in lock step.  Both leave
@@ -550,7 +571,7 @@ class BatchedMCTS:
                                       "these networks run in lock step (fused=False)")
         if fused:
             return self.run_fused(root_latent, root_to_play, eta, rand_child, trace)
-        self.begin(root_latent, root_to_play, eta, rand_child[:, 0])
+        self.begin(root_latent, root_to_play, eta, rand_child[:, 0], root_t=root_t)
         self.advance(rand_child[:, 1:], trace)
         return self.finish()
 

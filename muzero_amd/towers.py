@@ -70,13 +70,17 @@ class TowerNetworks:
     strided_outputs = True  # reward / value may be 1-D views with a stride (a column of a [G, n] buffer)
 
     def __init__(self, dynamics: torch.nn.Module, prediction: torch.nn.Module, device="cuda", wide_above: int = 4096,
-                 track_running_stats: bool = False, fuse_merge_conv: bool = True):
+                 track_running_stats: bool = False, fuse_merge_conv: bool = True, root_final: torch.nn.Module | None = None):
         """track_running_stats: every tower call also advances the BatchNorm running statistics of its
         blocks as the reference's train-mode calls do (network_builder.py:94,104,118), one update per
         reference call, the calls of one launch in row order (with one tree that is the reference's
         order; with G trees in lock step the trees' calls interleave).  `sync_running_stats()` writes
         the buffers and num_batches_tracked back into the modules.  No output depends on them."""
         self.device = torch.device(device)
+        # root_final: the representation network's final 1x1 convolution (neural_network.py:51,60-61) when it widens a
+        # few channels to the latent's C: a root latent is then the same kind of affine image, final_conv(pool(x)), of
+        # a few values as g's outputs are, and the root expansion can run in the bottleneck form too (`root_form`)
+        self.root_final = root_final
         self.fuse_merge_conv = fuse_merge_conv  # False keeps fc_merge and the tower of g as separate kernels
         # source rows from which the fused form is used (default: always; 256 trees 1.33 -> 1.41 M sims/s, the
         # expansion's separate kernels take 57 us there, the fused pair 43 us)
@@ -275,10 +279,12 @@ class TowerNetworks:
         # F t + b are convolutions of t with weights pre-multiplied by F.  The folded bias of conv1
         # depends on the position (taps outside the image contribute nothing) -> conv1_bias map; the
         # constant the skip convolution picks up cancels in its BatchNorm.
-        self.tower_f_t = None
+        self.tower_f_t = self.tower_f_root = None
+        self.merge_root_perm = self.table_root_perm = None
         blk0 = f.res_blocks[0] if len(f.res_blocks) else None
-        if bn_g and bn_f and blk0 is not None and blk0.downsample is not None:
-            Cl, wf, bf = bn_g
+
+        def f_tower_on(bn):
+            Cl, wf, bf = bn
             c, hgt, wid = self.shape
             wc = blk0.conv1.weight.detach().to(self.device, torch.float64)          # [o, C, k, k]
             w1 = torch.einsum("ocyx,cj->ojyx", wc, wf).contiguous()                 # [o, Cl, k, k]
@@ -292,12 +298,30 @@ class TowerNetworks:
             b0.conv1_w = ptr(self._dev(w1.to(torch.float32)))
             b0.conv1_bias = ptr(self._dev(bias_map.to(torch.float32)))
             b0.down_w = ptr(self._dev(wd.to(torch.float32)))
-            self.tower_f_t = t
             self._running[id(t)] = self._running.get(id(self.tower_f))  # the same blocks, pre-multiplied weights
             self._calls[id(t)] = self._calls.get(id(self.tower_f))
             # ... but it is part of that layer's batch mean (layer 2 of block 0: the skip path's BatchNorm)
             wdf = blk0.downsample[0].weight.detach().to(self.device, torch.float64).reshape(-1, c)
             self._mean_shift[id(t)] = {2: (wdf @ bf).to(torch.float32).contiguous()}
+            return t
+
+        if bn_g and bn_f and blk0 is not None and blk0.downsample is not None:
+            self.tower_f_t = f_tower_on(bn_g)
+        # the same for a root latent, which is h's final 1x1 convolution of a few pooled channels
+        bn_h = None
+        fin = self.root_final
+        if (isinstance(fin, torch.nn.Conv2d) and fin.kernel_size == (1, 1) and fin.out_channels == self.shape[0]
+                and fin.in_channels * self.shape[1] * self.shape[2] == self.bottleneck_g):
+            bn_h = (fin.in_channels, fin.weight.detach().to(self.device, torch.float64).reshape(fin.out_channels, fin.in_channels),
+                    fin.bias.detach().to(self.device, torch.float64) if fin.bias is not None
+                    else torch.zeros(fin.out_channels, dtype=torch.float64, device=self.device))
+        merge_const_root = None
+        if bn_h is not None and self.fused_g and self.tower_f_t is not None:
+            c, hgt, wid = self.shape
+            wr, merge_const_root = through(g.fc_merge.weight[:, :D], None, bn_h)
+            wrp = self._dev(wr.view(c, hgt * wid, wr.shape[1]).permute(1, 0, 2).reshape(D, wr.shape[1]))
+            self.merge_root_perm = plan_wide(_hip.Dense(ptr(wrp), None, wr.shape[1], D, _hip.ACT["none"], 0))
+            self.tower_f_root = f_tower_on(bn_h)
         if self.blob is None or self.blob.numel() != off:
             self.blob = torch.empty(off, dtype=torch.float32, device=self.device)
         for kind, src, pl in plans:
@@ -314,6 +338,9 @@ class TowerNetworks:
         if self.fused_g:
             c, hgt, wid = self.shape
             self.table_t_perm = self.table_t.view(A, c, hgt * wid).permute(0, 2, 1).contiguous()  # [A][HW][C]
+            if merge_const_root is not None:
+                self.table_root_perm = (self.table + merge_const_root[None, :]).view(A, c, hgt * wid).permute(0, 2, 1).contiguous()
+        self.has_root_form = self.merge_root_perm is not None and self.tower_f_root is not None and self.table_root_perm is not None
 
     # ---- scratch ----------------------------------------------------------------------------
     def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
@@ -479,15 +506,16 @@ class TowerNetworks:
                                                   ptr(self.blob), _stream()), "mz_mlp_forward_pair")
         return True
 
-    def merge_conv(self, t, t_rows, action, n_src) -> torch.Tensor:
+    def merge_conv(self, t, t_rows, action, n_src, root_form: bool = False) -> torch.Tensor:
         """fc_merge on bottleneck values + the per-action term + the first product of g's tower in one launch
         (only when `fused_g`): Y f32[rows][H*W][32] for rows = n_src (action i32[n_src]) or n_src * A (action None:
         every source row with all A actions)."""
         c, hgt, wid = self.shape
         B = n_src if action is not None else n_src * self.A
         Y = self._buf("g_Y", (B, hgt * wid, 32))
-        _hip.check(_hip.lib().mz_merge_conv_forward(C.byref(self.merge_t_perm), C.byref(self.conv_g), ptr(self.blob), ptr(t),
-                                                    t.shape[-1], ptr(t_rows), ptr(self.table_t_perm), ptr(action), self.A, n_src,
+        plan, table = (self.merge_root_perm, self.table_root_perm) if root_form else (self.merge_t_perm, self.table_t_perm)
+        _hip.check(_hip.lib().mz_merge_conv_forward(C.byref(plan), C.byref(self.conv_g), ptr(self.blob), ptr(t),
+                                                    t.shape[-1], ptr(t_rows), ptr(table), ptr(action), self.A, n_src,
                                                     c, hgt * wid, ptr(Y), _stream()), "mz_merge_conv_forward")
         return Y
 
@@ -505,7 +533,7 @@ class TowerNetworks:
         return base
 
     def dynamics(self, latent, B, *, ld=None, rows=None, action=None, next_latent=None, ld_next=None, next_rows=None,
-                 reward=None, base=None, t_in=None, t_out=None, want_latent=True) -> None:
+                 reward=None, base=None, t_in=None, t_out=None, want_latent=True, root_form: bool = False) -> None:
         """action None: the expansion pattern -- consecutive groups of A rows share one latent and
         take actions 0..A-1; each group is one call of the reference (shared batch statistics).
         action i32[B]: B independent calls of batch size 1.
@@ -530,7 +558,7 @@ class TowerNetworks:
                 n_src, group = U, A
             else:
                 n_src, group = B, 1
-            Y = self.merge_conv(t, t_rows, action, n_src)
+            Y = self.merge_conv(t, t_rows, action, n_src, root_form=root_form)
             layers = self._running.get(id(self.tower_g)) if self.track_running_stats else None
             stats, calls = None, B // group
             if layers:
@@ -542,6 +570,7 @@ class TowerNetworks:
             if reward is not None:
                 self._mlp_on(self.reward_t, "reward_t", t_out, t_out.shape[-1], next_rows, B, out=reward)
             return
+        assert not root_form, "the root form needs the fused fc_merge + convolution path"
         if action is None:
             assert B % A == 0, "expansion rows come in groups of A"
             U = B // A
@@ -580,7 +609,7 @@ class TowerNetworks:
                 (reward if reward.dim() == 1 else reward.view(-1)[:B]).copy_(out.view(-1))
 
     def prediction(self, latent, B, *, ld=None, rows=None, softmax_times=0, policy=None, value=None, argmax=None,
-                   t_in=None) -> None:
+                   t_in=None, root_form: bool = False) -> None:
         """t_in = (t f32[*, bottleneck_g], rows): the bottleneck values of the latents (non-root nodes of
         the search); f's first block then reads them instead of the latents."""
         if policy is None and value is None and argmax is None:
@@ -592,7 +621,8 @@ class TowerNetworks:
             t = self._buf("f_t", (B, dt))
             if t_in is not None and self.tower_f_t is not None:
                 src, src_rows = t_in
-                self._tower_call(self.tower_f_t, src, src.shape[-1], src_rows, None, None, None, 0, None, B, 1, t_out=t)
+                self._tower_call(self.tower_f_root if root_form else self.tower_f_t, src, src.shape[-1], src_rows, None, None, None,
+                                 0, None, B, 1, t_out=t)
             else:
                 self._tower_call(self.tower_f, latent, ld or D, rows, None, None, None, 0, None, B, 1, t_out=t)
             head = lambda plan, name: self._mlp_on(plan, name, t, dt, None, B)  # noqa: E731

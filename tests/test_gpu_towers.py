@@ -893,3 +893,49 @@ def test_one_chain_recorded_search_equals_launch_by_launch(depth):
         assert torch.equal(eager.t_pool[:G * cap], graphed.t_pool[:G * cap])
         assert torch.equal(a.policy, b.policy) and torch.equal(a.value, b.value) and torch.equal(a.visits, b.visits)
         assert int(a.visits.sum()) == G * S
+
+
+def test_root_expansion_from_the_representation_networks_bottleneck_values():
+    """A root latent is h's final 1x1 convolution of a few pooled channels (neural_network.py:51,60-61), the same kind
+    of affine image of 108 values as g's outputs: with `root_final` the root expansion runs in the bottleneck form
+    from those values (weights composed with that convolution) instead of on the 9216-wide latent.  Priors, rewards
+    and the children's bottleneck values of the root expansion agree with the plain form to 1e-5 of scale; whole
+    searches build the same trees wherever no near-tie decides, and run without the root latents at all."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    A, G, S = 5, 48, 10
+    g, f = build_nets((256, 6, 6), A)
+    torch.manual_seed(5)
+    fin = torch.nn.Conv2d(3, 256, 1).cuda()
+    rng = np.random.default_rng(3)
+    root_t = torch.from_numpy(rng.standard_normal((G, 3, 6, 6)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        lat = fin(root_t).reshape(G, -1).contiguous()
+    eta = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).cuda()
+    rand = torch.from_numpy(rng.integers(0, A, size=(G, S + 1)).astype(np.int32)).cuda()
+    to_play = torch.ones(G, dtype=torch.int8, device="cuda")
+    nets = TowerNetworks(g, f, root_final=fin)
+    assert nets.has_root_form and not TowerNetworks(g, f).has_root_form
+    plain = BatchedMCTS(nets, G, S, 1, discount=0.997, noise_frac=0.25, keep_latents=False)
+    rooted = BatchedMCTS(nets, G, S, 1, discount=0.997, noise_frac=0.25, keep_latents=False)
+    assert rooted.root_form_ok(root_t) and not plain.root_form_ok(None)
+    plain.begin(lat, to_play, eta, rand[:, 0])
+    rooted.begin(None, to_play, eta, rand[:, 0], root_t=root_t)
+    torch.cuda.synchronize()
+    cap = plain.pool.cap
+    kids = (torch.arange(G, device="cuda")[:, None] * cap + 1 + torch.arange(A, device="cuda")[None, :]).reshape(-1)
+    for name, a, b in (("prior", rooted.pool.prior[:, 1:1 + A], plain.pool.prior[:, 1:1 + A]),
+                       ("reward", rooted.pool.reward[:, 1:1 + A], plain.pool.reward[:, 1:1 + A]),
+                       ("children", rooted.t_pool[kids], plain.t_pool[kids])):
+        a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5 * float(np.abs(b).max()), err_msg=name)
+    assert float(rooted.pool.latent.abs().max()) == 0.0   # no latent was ever stored
+    ra = plain.run(lat, to_play, eta, rand)
+    rb = rooted.run(None, to_play, eta, rand, root_t=root_t)
+    rb2 = rooted.run(None, to_play, eta, rand, root_t=root_t)   # recorded graph
+    torch.cuda.synchronize()
+    assert int(rb.visits.sum()) == G * S and torch.equal(rb.visits, rb2.visits) and torch.equal(rb.policy, rb2.policy)
+    same = (ra.visits == rb.visits).all(dim=1)
+    assert float(same.float().mean()) >= 0.85, f"only {int(same.sum())} of {G} trees agree"
+    np.testing.assert_allclose(rb.value[same].cpu().numpy(), ra.value[same].cpu().numpy(), rtol=1e-4, atol=1e-6)

@@ -93,6 +93,9 @@ def main() -> None:
     ap.add_argument("--actions", type=int, default=5)
     ap.add_argument("--latent", type=int, nargs=3, default=[256, 6, 6])
     ap.add_argument("--cpu-seconds", type=float, default=0.0, help="time the torch modules on the host for this long")
+    ap.add_argument("--plain-root", action="store_true",
+                    help="expand the roots from their 9216-wide latents (default: from the bottleneck values of the "
+                         "representation network's final 1x1 convolution, as self-play with the shipped h does)")
     args = ap.parse_args()
     from muzero_amd.engine import BatchedMCTS
     from muzero_amd.towers import TowerNetworks
@@ -104,12 +107,21 @@ def main() -> None:
     if args.cpu_seconds > 0:
         cpu = cpu_network_time(g, f, shape, A, args.cpu_seconds, min(16, os.cpu_count() or 1))
         t0 = time.time()
-    nets = TowerNetworks(g, f)
+    # the shipped representation network ends in ResBlock(256 -> 3), a 1x1 convolution 3 -> 256 and an adaptive
+    # average pool (src/config/config_car_racing.yaml:117-131, neural_network.py:51,60-61): a root latent is that
+    # convolution of 3 x 6 x 6 pooled values, and the synthetic roots are drawn in that form
+    torch.manual_seed(1)
+    fin = torch.nn.Conv2d(3, shape[0], 1).cuda() if shape[0] != 3 else None
+    nets = TowerNetworks(g, f, root_final=fin)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, keep_latents=False)
     gen = torch.Generator(device="cuda").manual_seed(0)
-    lat = torch.randn(G, D, device="cuda", generator=gen)
+    root_t = torch.randn(G, 3, shape[1], shape[2], device="cuda", generator=gen) if fin is not None else None
+    with torch.no_grad():
+        lat = fin(root_t).reshape(G, D).contiguous() if fin is not None else torch.randn(G, D, device="cuda", generator=gen)
+    use_root_t = root_t is not None and not args.plain_root and mcts.root_form_ok(root_t)
+    root_kw = {"root_t": root_t} if use_root_t else {}
     eta = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((G,)).float().cuda()
     rand = torch.randint(0, A, (G, S + 1), device="cuda", generator=gen, dtype=torch.int32)
     to_play = torch.zeros(G, dtype=torch.int8, device="cuda")
@@ -117,12 +129,12 @@ def main() -> None:
     for _ in range(args.warmup):
         torch.cuda.synchronize()
         t0 = time.time()
-        res = mcts.run(lat, to_play, eta, rand)
+        res = mcts.run(lat, to_play, eta, rand, **root_kw)
         torch.cuda.synchronize()
         warm_s.append(time.time() - t0)
     t0 = time.time()
     for _ in range(args.steps):
-        res = mcts.run(lat, to_play, eta, rand)
+        res = mcts.run(lat, to_play, eta, rand, **root_kw)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / args.steps
     assert int(res.visits.sum()) == G * S
@@ -191,7 +203,8 @@ def main() -> None:
         "metric": "mcts_simulations_per_sec", "value": G * S / dt, "unit": "sims/s", "n_gpus": 1,
         "ms_per_step": dt * 1e3, "steps": args.steps, "dtype": "f32+f64", "data": "synthetic",
         "config": {"workload": f"{G} trees x {S} simulations, lock-step search, residual-tower g/f, latent "
-                               f"{list(shape)}, {A} actions"},
+                               f"{list(shape)}, {A} actions",
+                   "roots": "bottleneck values of h's final 1x1 convolution" if use_root_t else "full latents"},
         "reference_flop_per_sim": 3 * F_f + (A + 1) * F_g,
         "algorithmic_tflops": (3 * F_f + (A + 1) * F_g) * G * S / dt / 1e12,
         "stage_ms": {"f(G rows)": f_ms, "g expansion (G*A rows)": gA_ms, "g step (G rows)": g1_ms},
