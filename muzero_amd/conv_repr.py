@@ -373,9 +373,21 @@ class ConvRepresentation:
         return first is not None and first.fast and not (self.staged_range and first.stride == 1 and first.k in (1, 3)
                                                          and first.pad == (first.k - 1) // 2)
 
-    def __call__(self, history: torch.Tensor) -> torch.Tensor:
-        """history f32[G, C*K+K, H, W] (the tensor of mz_history_push_assemble) -> latent f32[G, c, h, w]."""
+    def final_is_pointwise(self) -> bool:
+        """Whether the network ends in a 1x1, stride-1 convolution (neural_network.py:51,60-61): the latent is then
+        that convolution of the pooled tensor before it, final_conv(pool(x)) = pool(final_conv(x))."""
+        last = self.steps[-1] if self.steps else None
+        return (last is not None and last[0] == "conv" and last[1].module is self.src.final_conv
+                and last[1].k == 1 and last[1].stride == 1 and last[1].pad == 0)
+
+    def __call__(self, history: torch.Tensor, want_root_t: bool = False) -> torch.Tensor:
+        """history f32[G, C*K+K, H, W] (the tensor of mz_history_push_assemble) -> latent f32[G, c, h, w].
+        `want_root_t`: when the network ends in a 1x1 convolution, `self.root_t` f32[G, c_in, h, w] also receives the
+        pooled input of that convolution (the values a residual-tower search can start from instead of the latent);
+        None otherwise."""
         lib = _hip.lib()
+        self.root_t = None
+        pre_final = want_root_t and self.final_is_pointwise()
         G, Cc, H, W = history.shape
         x_in = history.to(self.device, torch.float32).contiguous()
         n_in = G * H * W * Cc
@@ -389,6 +401,11 @@ class ConvRepresentation:
         for si, step in enumerate(self.steps):
             tag = f"s{si % 2}"
             split_next = self._wants_split(si)
+            if pre_final and si == len(self.steps) - 1:
+                h, w = self.latent_hw
+                self.root_t = torch.empty((G, Cc, h, w), dtype=torch.float32, device=self.device)
+                _hip.check(lib.mz_adaptive_avg_to_nchw(ptr(self._f32(x, "pre_final")), G, H, W, Cc, h, w, ptr(self.root_t),
+                                                       _stream()), "mz_adaptive_avg_to_nchw")
             if step[0] == "conv":
                 cv = step[1]
                 if cv.cin != Cc:

@@ -94,8 +94,16 @@ class RepresentationRunner:
         if self.conv is not None:
             self.conv.sync_running_stats()
 
-    def __call__(self, history: torch.Tensor) -> torch.Tensor:
+    def root_final(self):
+        """The network's final 1x1 convolution when root latents are its image of a pooled tensor (then
+        `__call__(..., want_root_t=True)` leaves that tensor in `self.root_t`), else None."""
+        if self.pointwise or self.conv is None or not self.conv.final_is_pointwise():
+            return None
+        return self.src.final_conv
+
+    def __call__(self, history: torch.Tensor, want_root_t: bool = False) -> torch.Tensor:
         self.refresh()
+        self.root_t = None
         G, cin, H, W = history.shape
         if self.pointwise and (H, W) == self.latent_hw:
             x = history.to(self.device, torch.float32).contiguous()
@@ -107,7 +115,9 @@ class RepresentationRunner:
         if self.conv is None:  # a point-wise module asked for another latent size: 1x1 convolution + adaptive pool
             from muzero_amd.conv_repr import ConvRepresentation
             self.conv = ConvRepresentation(self.src, device=self.device, track_running_stats=self.track_running_stats)
-        return self.conv(history)
+        out = self.conv(history, want_root_t=want_root_t)
+        self.root_t = self.conv.root_t
+        return out
 
 
 def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_action: torch.Tensor | None,
@@ -143,7 +153,11 @@ class SelfPlayEngine:
         assert getattr(self.env, "G", G) == G, "the environment batch must hold G games"
         self.A = self.env.num_actions
         self.h = RepresentationRunner(repr_net, device=device, track_running_stats=track_running_stats)
-        self.nets = make_networks(dyn_net, pred_net, device=device, track_running_stats=track_running_stats)
+        # with a representation network that ends in a 1x1 convolution of a few channels, a residual-tower search starts
+        # from those channels' pooled values (the bottleneck form of its expansions) instead of the 256-channel latent
+        self._root_final = self.h.root_final()
+        self.nets = make_networks(dyn_net, pred_net, device=device, track_running_stats=track_running_stats,
+                                  root_final=self._root_final)
         self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
                                 device=device, keep_latents=False)  # nothing here reads the children's latents
         self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
@@ -178,7 +192,16 @@ class SelfPlayEngine:
         G, A, S, dev = self.G, self.A, self.mcts.S, self.device
         obs, to_play = self.env.observe()
         hist = self.history.push(obs, self.step_in_episode, None)  # self-play stores action id 0 with every frame
-        latent = self.h(hist).reshape(G, -1)
+        root_form = bool(getattr(self.nets, "has_root_form", False))
+        latent = self.h(hist, want_root_t=root_form).reshape(G, -1)
+        root_t = self.h.root_t.reshape(G, -1) if root_form and self.h.root_t is not None else None
+        if root_t is not None and not self.mcts.root_form_ok(root_t):
+            root_t = None
+        if root_t is not None:
+            seen = tuple((t._version, t.data_ptr()) for t in self._root_final.parameters())
+            if seen != getattr(self, "_root_seen", seen):
+                self.nets.refresh()  # the composed root weights hold a copy of the final convolution's
+            self._root_seen = seen
         eps = self.epsilon(training_steps)
         if self.device_rng:
             rand = torch.randint(0, A, (G, S + 1), device=dev, dtype=torch.int32, generator=self.gen)
@@ -193,7 +216,7 @@ class SelfPlayEngine:
             explore = torch.from_numpy((self.rng.random(G) < eps).astype(np.int8)).to(dev)
             p = self.cfg.random_action_probability
             rnd = torch.from_numpy(self.rng.choice(A, size=G, p=p).astype(np.int32)).to(dev)
-        res = self.mcts.run(latent, to_play, eta, rand)
+        res = self.mcts.run(latent if root_t is None else None, to_play, eta, rand, root_t=root_t)
         pick_action(res.policy32, explore, rnd, self.action)
         reward, done = self.env.step(self.action)
         self.step_in_episode += 1

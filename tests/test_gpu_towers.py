@@ -939,3 +939,71 @@ def test_root_expansion_from_the_representation_networks_bottleneck_values():
     same = (ra.visits == rb.visits).all(dim=1)
     assert float(same.float().mean()) >= 0.85, f"only {int(same.sum())} of {G} trees agree"
     np.testing.assert_allclose(rb.value[same].cpu().numpy(), ra.value[same].cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_selfplay_starts_tower_searches_from_the_pooled_input_of_hs_final_convolution():
+    """Self-play with a representation network that ends in a 1x1 convolution of 3 channels and the shipped tower
+    shape: the engine hands the search the pooled 3-channel tensor (checked against the module's own input of that
+    convolution, pooled by torch) and the moves agree with an engine that starts from the 256-channel latents."""
+    from muzero_amd.config import (ConvLayerConfig, MCTSConfig, RepresentationNetworkConfig, TrainingDataGeneratorConfig)
+    from muzero_amd.environments.host_pool import HostEnvPool
+    from muzero_amd.neural_networks import RepresentationNetwork
+    from muzero_amd.selfplay import SelfPlayEngine
+    from tests.test_host_pool import CountingEnv
+    from tools.bench_towers import build_nets
+    A, G, S, K = 5, 24, 10, 2
+    shape = (256, 6, 6)
+    g, f = build_nets(shape, A)
+    torch.manual_seed(11)
+    h = RepresentationNetwork((2, 24, 24), shape, RepresentationNetworkConfig(history_length=K, downsample=[
+        ConvLayerConfig(out_channels=3, kernel_size=2, stride=2, padding=0, activation="relu")], res_net=[]))
+    assert h.final_conv.in_channels == 3 and h.final_conv.kernel_size == (1, 1)
+
+    class Env(CountingEnv):
+        def get_to_play(self):
+            return 0
+
+        def _obs(self):
+            gen = torch.Generator().manual_seed(self.gid * 1000 + self.t)
+            return torch.rand((1,) + self.shape, generator=gen)
+
+    cfg = TrainingDataGeneratorConfig(
+        num_episodes=1, max_steps_per_episode=50, total_time=0, epsilon=0.0, epsilon_decay=1.0, min_epsilon=0.0,
+        mcts=MCTSConfig(selection_strategy="puct", max_iterations=S, max_time=0, model_look_ahead=1,
+                        discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
+    mk = lambda: SelfPlayEngine(h, g, f, G, cfg, seed=3,  # noqa: E731
+                                env=HostEnvPool([Env(gi, 30, shape=(2, 24, 24), actions=A) for gi in range(G)], workers=2))
+    rooted, plain = mk(), mk()
+    assert rooted.nets.has_root_form
+    plain.nets.has_root_form = False
+    seen = []
+    hook = h.final_conv.register_forward_pre_hook(lambda m, x: seen.append(x[0].detach()))
+    first_obs = torch.cat([Env(gi, 30, shape=(2, 24, 24), actions=A)._obs() for gi in range(G)])
+    hist = torch.cat([first_obs.repeat(1, K, 1, 1), torch.zeros(G, K, 24, 24)], dim=1)
+    with torch.no_grad():
+        h(hist)
+    hook.remove()
+    want_t = torch.nn.functional.adaptive_avg_pool2d(seen[0], (6, 6))
+    pa = plain.move()
+    ra = rooted.move()
+    torch.cuda.synchronize()
+    assert plain.h.root_t is None and rooted.h.root_t is not None
+    np.testing.assert_allclose(rooted.h.root_t.cpu().numpy(), want_t.numpy(), rtol=1e-5, atol=1e-6)
+    assert float(rooted.mcts.pool.latent.abs().max()) == 0.0   # the 256-channel latents never reached the search
+    # same trees wherever no near-tie decides: policies within rounding, then equal values and actions
+    same = ((pa[1] - ra[1]).abs() <= 1e-5).all(dim=1)
+    assert float(same.float().mean()) >= 0.85, f"only {int(same.sum())} of {G} games agree"
+    np.testing.assert_allclose(ra[2][same].cpu().numpy(), pa[2][same].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert torch.equal(ra[3][same], pa[3][same])
+    # a weight update of h reaches the composed root weights without an explicit refresh of the towers
+    with torch.no_grad():
+        h.final_conv.weight.mul_(1.5)
+    v0 = rooted.nets.version
+    rb, pb = rooted.move(), plain.move()
+    torch.cuda.synchronize()
+    assert rooted.nets.version == v0 + 1
+    both = same & ((pb[1] - rb[1]).abs() <= 1e-5).all(dim=1)
+    assert float(both.float().mean()) >= 0.7
+    np.testing.assert_allclose(rb[2][both].cpu().numpy(), pb[2][both].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    rooted.env.close()
+    plain.env.close()
