@@ -92,9 +92,10 @@ struct MlpJob {
     long long ldy;
     int B;
 };
+template <int MT>
 __device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const float *__restrict__ blob, const MlpJob &J, int row0,
                                                  float *smem) {
-    constexpr int TM = 16;
+    constexpr int TM = 16 * MT;
     const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
     lds_f *X = to_lds(smem), *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
     const int rows = min(TM, J.B - row0);
@@ -106,7 +107,7 @@ __device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const f
         return src < 0 ? nullptr : x + src * ldx;
     });
     int ld_out;
-    lds_f *out = mlp_tile<1>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    lds_f *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
     float *y = J.y;
     const long long ldy = J.ldy;
@@ -115,14 +116,16 @@ __device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const f
         y[(long long)(row0 + r) * ldy + c] = out[r * ld_out + c];
     }
 }
-// (two branches rather than a selected plan: a plan chosen at run time would be copied to per-lane stack memory)
+// (two branches rather than a selected plan: a plan chosen at run time would be copied to per-lane stack memory;
+// each job with the row tile its own batch size asks for)
+template <int MT0, int MT1>
 __global__ void __launch_bounds__(kThreads)
 k_mlp_forward_pair(mz_packed_mlp M0, mz_packed_mlp M1, const float *__restrict__ blob, MlpJob j0, MlpJob j1, int blocks0) {
     extern __shared__ __align__(16) float smem[];
     if ((int)blockIdx.x < blocks0)
-        mlp_rows_forward(M0, blob, j0, (int)blockIdx.x * 16, smem);
+        mlp_rows_forward<MT0>(M0, blob, j0, (int)blockIdx.x * 16 * MT0, smem);
     else
-        mlp_rows_forward(M1, blob, j1, ((int)blockIdx.x - blocks0) * 16, smem);
+        mlp_rows_forward<MT1>(M1, blob, j1, ((int)blockIdx.x - blocks0) * 16 * MT1, smem);
 }
 
 template <int MT>
@@ -249,11 +252,17 @@ int allow_lds(K kernel, size_t bytes, const char *what) {
     return MZ_OK;
 }
 
+// rows from which the 32-row tile is used (MZ_MLP_MT2_MIN_ROWS: a tuning aid)
+int mt2_min_rows() {
+    static const int v = [] { const char *e = getenv("MZ_MLP_MT2_MIN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 16 * 512; }();
+    return v;
+}
+
 template <typename Launch1, typename Launch2>
 int launch_by_rows(int B, size_t lds_per_row_floats, size_t extra_bytes, Launch1 &&l1, Launch2 &&l2) {
     // 32-row tiles halve the weight traffic per row; 16-row tiles keep all 256 CUs busy when
     // the batch is small.
-    int mt = (B >= 16 * 512) ? 2 : 1;
+    int mt = (B >= mt2_min_rows()) ? 2 : 1;
     if ((size_t)mt * 16 * lds_per_row_floats * sizeof(float) + extra_bytes > kMaxLds) mt = 1;
     size_t lds = (size_t)mt * 16 * lds_per_row_floats * sizeof(float) + extra_bytes;
     if (lds > kMaxLds) return mz::fail(MZ_ERR_ARG, "network too wide: needs %zu bytes of LDS per tile", lds);
@@ -335,19 +344,30 @@ int mz_mlp_forward_pair(const mz_packed_mlp *h_plan0, const float *x0, int64_t l
     if (!h_plan0 || !h_plan1 || !blob || !x0 || !x1 || !y0 || !y1 || B0 < 0 || B1 < 0 || ldx0 < h_plan0->in_features ||
         ldx1 < h_plan1->in_features || ldy0 < h_plan0->out_features || ldy1 < h_plan1->out_features)
         return mz::fail(MZ_ERR_ARG, "mz_mlp_forward_pair: NULL argument, negative B, or row stride below the row width");
-    // large batches gain more from the 32-row tiles of mz_mlp_forward than from sharing a launch
-    if (B0 == 0 || B1 == 0 || B0 >= 16 * 512 || B1 >= 16 * 512) {
+    if (B0 == 0 || B1 == 0) {
         MZ_TRY(mz_mlp_forward(h_plan0, blob, x0, ldx0, x_rows0, y0, ldy0, B0, stream));
         return mz_mlp_forward(h_plan1, blob, x1, ldx1, x_rows1, y1, ldy1, B1, stream);
     }
     auto per_row = [](const mz_packed_mlp *p) { return (size_t)lds_stride(p->in_features) + 2 * (size_t)lds_stride(p->max_width); };
-    const size_t lds = 16 * std::max(per_row(h_plan0), per_row(h_plan1)) * sizeof(float);
+    // row tile per job as mz_mlp_forward picks it: 32 rows from 8192 rows on (half the weight traffic per row)
+    auto tile = [&](const mz_packed_mlp *p, int B) {
+        return (B >= mt2_min_rows() && 32 * per_row(p) * sizeof(float) <= kMaxLds) ? 2 : 1;
+    };
+    const int mt0 = tile(h_plan0, B0), mt1 = tile(h_plan1, B1);
+    const size_t lds = 16 * std::max(mt0 * per_row(h_plan0), mt1 * per_row(h_plan1)) * sizeof(float);
     if (lds > kMaxLds) return mz::fail(MZ_ERR_ARG, "network too wide: needs %zu bytes of LDS per tile", lds);
-    MZ_TRY(allow_lds(k_mlp_forward_pair, lds, "k_mlp_forward_pair"));
-    const int blocks0 = (B0 + 15) / 16, blocks1 = (B1 + 15) / 16;
-    hipLaunchKernelGGL(k_mlp_forward_pair, dim3(blocks0 + blocks1), dim3(kThreads), lds, (hipStream_t)stream, *h_plan0, *h_plan1,
-                       blob, MlpJob{x0, (long long)ldx0, x_rows0, y0, (long long)ldy0, B0},
-                       MlpJob{x1, (long long)ldx1, x_rows1, y1, (long long)ldy1, B1}, blocks0);
+    const int blocks0 = (B0 + 16 * mt0 - 1) / (16 * mt0), blocks1 = (B1 + 16 * mt1 - 1) / (16 * mt1);
+    auto launch = [&](auto kernel) -> int {
+        MZ_TRY(allow_lds(kernel, lds, "k_mlp_forward_pair"));
+        hipLaunchKernelGGL(kernel, dim3(blocks0 + blocks1), dim3(kThreads), lds, (hipStream_t)stream, *h_plan0, *h_plan1, blob,
+                           MlpJob{x0, (long long)ldx0, x_rows0, y0, (long long)ldy0, B0},
+                           MlpJob{x1, (long long)ldx1, x_rows1, y1, (long long)ldy1, B1}, blocks0);
+        return MZ_OK;
+    };
+    if (mt0 == 1 && mt1 == 1) MZ_TRY(launch(k_mlp_forward_pair<1, 1>));
+    else if (mt0 == 2 && mt1 == 1) MZ_TRY(launch(k_mlp_forward_pair<2, 1>));
+    else if (mt0 == 1 && mt1 == 2) MZ_TRY(launch(k_mlp_forward_pair<1, 2>));
+    else MZ_TRY(launch(k_mlp_forward_pair<2, 2>));
     return mz::check_launch("k_mlp_forward_pair");
 }
 

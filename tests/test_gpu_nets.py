@@ -141,9 +141,12 @@ def test_reference_vectors_c4_mlp():
     np.testing.assert_allclose(v.cpu().numpy(), z["f_value"][:, 0], rtol=RTOL, atol=ATOL)
 
 
-def test_two_heads_in_one_launch_equal_two_launches():
+@pytest.mark.parametrize("B0,B1", [(1301, 77), (8200, 1000), (500, 8195), (8192 + 17, 8192 + 40)],
+                         ids=["16+16", "32+16", "16+32", "32+32"])
+def test_two_heads_in_one_launch_equal_two_launches(B0, B1):
     """mz_mlp_forward_pair (reward head over gathered rows + value head over other rows, one launch) against two
-    mz_mlp_forward calls: identical bits, ragged row counts, a strided one-output destination."""
+    mz_mlp_forward calls: identical bits, ragged row counts, a strided one-output destination; each job with the row
+    tile (16 or 32 rows per workgroup) its own batch size selects."""
     import ctypes as C
     from muzero_amd import _hip
     from muzero_amd._hip import ptr
@@ -154,7 +157,6 @@ def test_two_heads_in_one_launch_equal_two_launches():
     st = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator(device="cuda").manual_seed(4)
     D = nets.plan.D
-    B0, B1 = 1301, 77
     x0 = torch.randn(B0 + 5, D, device="cuda", generator=gen)
     r0 = torch.randperm(B0 + 5, device="cuda", generator=gen)[:B0].to(torch.int32)
     r0[3] = -1   # an absent row reads as zeros
