@@ -1085,46 +1085,57 @@ struct ThinBlock {
     int cin, cout, act, H, W;
 };
 
-// The float64 tail of N BatchNorm channels at once: lane c < N evaluates channel c (the same operations
-// in the same order as one channel at a time), scale / shift come back as wave-uniform values.
-// s, q: sums of the deviations from `pivot` and of their squares over the call's P values; lane c < N
-// also stores the channel's mean and biased variance to mean_dst / var_dst (per-lane addresses; NULL: no export).
-template <int N>
-__device__ __forceinline__ void thin_bn_tail(const double (&s)[N], const double (&q)[N], const float (&pivot)[N],
-                                             const float (&gamma)[N], const float (&beta)[N], const float (&eps)[N], int P,
-                                             float *mean_dst, float *var_dst, float (&scale)[N], float (&shift)[N]) {
-    const int lane = threadIdx.x & 63;
-    double S = s[0], Q = q[0];
-    float pv = pivot[0], ga = gamma[0], be = beta[0], ep = eps[0];
+// BatchNorm2d statistics of up to 8 channels of a call at once.  The values sit in LDS as 4-channel cells
+// (position-major); lane l adds up channel l >> 3 over the positions (l & 7), (l & 7) + 8, ... (deviations
+// from the channel's value at position 0 and their squares, float64), an exchange over each group of 8 lanes
+// (two quad permutations and a half-row mirror on the DPP path) leaves every lane of a group with the
+// channel's totals, and all lanes evaluate the float64 tail of their channel together; scale / shift return as
+// wave-uniform values by lane reads.  A few dozen instructions per layer, against a wave-wide reduction
+// per channel and sum.
+// src: this lane's channel in cell 0 (any valid address for lanes without a channel: `on` false);
+// mean_dst / var_dst: per-lane addresses for the channel's mean and biased variance (NULL: no export).
+template <int N, int NP>
+__device__ __forceinline__ void thin_bn_lanes(const lds_f *src, bool on, int P, float ga, float be, float ep,
+                                              float *mean_dst, float *var_dst, float (&scale)[N], float (&shift)[N]) {
+    static_assert(N <= 8, "eight groups of eight lanes");
+    const int j = threadIdx.x & 7;
+    const float pv = src[0];
+    double S = 0.0, Q = 0.0;
 #pragma unroll
-    for (int c = 1; c < N; ++c) {
-        const bool me = lane == c;
-        S = me ? s[c] : S;
-        Q = me ? q[c] : Q;
-        pv = me ? pivot[c] : pv;
-        ga = me ? gamma[c] : ga;
-        be = me ? beta[c] : be;
-        ep = me ? eps[c] : ep;
+    for (int i = 0; i < 8 * NP; ++i) {
+        if (8 * i >= P) break;  // wave-uniform
+        const int pp = j + 8 * i;
+        const float x = src[4 * min(pp, P - 1)];
+        const double d = pp < P ? (double)x - (double)pv : 0.0;
+        S += d;
+        Q += d * d;
     }
+    S = dpp_add<0xB1>(S);   // quad_perm [1, 0, 3, 2]
+    Q = dpp_add<0xB1>(Q);
+    S = dpp_add<0x4E>(S);   // quad_perm [2, 3, 0, 1]
+    Q = dpp_add<0x4E>(Q);
+    S = dpp_add<0x141>(S);  // row_half_mirror: the other quad of the group of 8
+    Q = dpp_add<0x141>(Q);
     const double ds = S / P, mean = (double)pv + ds;
     const double var = fmax(Q / P - ds * ds, 0.0);
     const double invstd = 1.0 / sqrt(var + (double)ep);
     const float sc = (float)((double)ga * invstd), sh = (float)((double)be - mean * (double)ga * invstd);
-    if (mean_dst != nullptr && lane < N) {
+    if (on && mean_dst != nullptr) {
         *mean_dst = (float)mean;
         *var_dst = (float)var;
     }
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        scale[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), c));
-        shift[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sh), c));
+        scale[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), 8 * c));
+        shift[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sh), 8 * c));
     }
 }
 
 // CI / CO: compile-time bounds of the channel counts (the shipped towers: exactly 3 -> 3, EXACT; other
 // shapes run with CI = CO = 4 and guards), so that the per-channel values live in registers and every
-// loop unrolls.
-template <bool FROM_Y, int K, int CI, int CO, bool EXACT>
+// loop unrolls.  NP: position slots per lane the build carries (P <= 64 NP); calls of at most 64 positions
+// -- every call but the expansion's -- run the NP = 1 build, a third of the instructions and registers.
+template <bool FROM_Y, int K, int CI, int CO, bool EXACT, int NP = kThinMaxPos, bool SPLIT = false>
 __global__ void __launch_bounds__(kThinT)
 k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int32_t *__restrict__ x_rows,
              float *__restrict__ t_out, long long ld_t, const int32_t *__restrict__ y_rows, int group, int calls,
@@ -1135,21 +1146,35 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
     const int H = R.H, W = R.W, HW = H * W, P = group * HW;
     const int Cin = EXACT ? CI : R.cin, Cout = EXACT ? CO : R.cout;
     const bool down = R.down_w != nullptr;
-    const int call = blockIdx.x * ((int)blockDim.x >> 6) + wave;
-    if (call >= calls) return;  // no workgroup barrier anywhere
+    // SPLIT (NP = 1): the waves of a workgroup share ONE call, wave w takes positions 64 w .. 64 w + 63 -- the
+    // expansion's calls of 180 positions as three short waves instead of one long one (their LDS, 26 KB per call,
+    // lets six calls share a compute unit either way); the waves meet at workgroup barriers
+    static_assert(!SPLIT || NP == 1, "one position slot per wave");
+    const int call = SPLIT ? (int)blockIdx.x : blockIdx.x * ((int)blockDim.x >> 6) + wave;
+    if (call >= calls) return;  // workgroup-uniform with SPLIT; no workgroup barrier anywhere without
     const int cells = (P + 1) * kThinMaxC;
-    lds_f *a_mid = to_lds(smem) + wave * (FROM_Y ? cells + (P + 1) * kYCols : 2 * cells), *a_in = a_mid + cells;  // [P + 1][4] each
+    lds_f *a_mid = to_lds(smem) + (SPLIT ? 0 : wave) * (FROM_Y ? cells + (P + 1) * kYCols : 2 * cells), *a_in = a_mid + cells;  // [P + 1][4] each
     const int r0 = call * group;
-    const int npos = (P + 63) >> 6;  // position slots in use (wave-uniform)
+    const int npos = SPLIT ? 1 : (P + 63) >> 6;  // position slots in use (wave-uniform)
+    const int lane_p = lane + (SPLIT ? 64 * wave : 0);  // this lane's first position
+    auto sync = [] {  // between writing LDS and reading what other lanes wrote
+        if constexpr (SPLIT) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
     cst_f *w1 = as_constant(R.conv1_w), *w2 = as_constant(R.conv2_w), *wd = as_constant(R.down_w);
 
     // this lane's positions: row of the call, position in the image, the cell each tap reads (P: the zero cell)
-    int prow[kThinMaxPos], psp[kThinMaxPos], cell[kThinMaxPos][KK];
-    bool live[kThinMaxPos];
+    int prow[NP], psp[NP], cell[NP][KK];
+    bool live[NP];
 #pragma unroll
-    for (int u = 0; u < kThinMaxPos; ++u) {
-        live[u] = u < npos && lane + 64 * u < P;
-        const int p = min(lane + 64 * u, P - 1);
+    for (int u = 0; u < NP; ++u) {
+        live[u] = u < npos && lane_p + 64 * u < P;
+        const int p = min(lane_p + 64 * u, P - 1);
         prow[u] = p / HW;
         psp[u] = p - prow[u] * HW;
         const int py = psp[u] / W, px = psp[u] - py * W;
@@ -1181,15 +1206,15 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
         }
     };
 
-    float c1[CO][kThinMaxPos], sk[CO][kThinMaxPos];
+    float c1[CO][NP], sk[CO][NP];
 #pragma unroll
     for (int c = 0; c < CO; ++c)
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) c1[c][u] = sk[c][u] = 0.0f;
+        for (int u = 0; u < NP; ++u) c1[c][u] = sk[c][u] = 0.0f;
     // destination rows of the result, requested now
-    long long drow[kThinMaxPos];
+    long long drow[NP];
 #pragma unroll
-    for (int u = 0; u < kThinMaxPos; ++u)
+    for (int u = 0; u < NP; ++u)
         drow[u] = live[u] ? (y_rows ? (long long)y_rows[r0 + prow[u]] : (long long)(r0 + prow[u])) : -1;
     if (lane < (FROM_Y ? 1 : 2) * kThinMaxC) a_mid[(lane < kThinMaxC ? 0 : cells - kThinMaxC) + P * kThinMaxC + lane] = 0.0f;  // the zero cells
 
@@ -1201,22 +1226,21 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
         {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(x + (long long)r0 * ldx);
             const int n4 = P * (kYCols / 4);
-            for (int i0 = lane; i0 < n4; i0 += 64 * 8) {  // eight pieces per lane in flight
+            const int nt = SPLIT ? (int)blockDim.x : 64;  // threads that copy this call's rows
+            for (int i0 = SPLIT ? (int)threadIdx.x : lane; i0 < n4; i0 += nt * 8) {  // eight pieces per lane in flight
                 f32x4 v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (i0 + 64 * j < n4) v[j] = src[i0 + 64 * j];
+                    if (i0 + nt * j < n4) v[j] = src[i0 + nt * j];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (i0 + 64 * j < n4) *reinterpret_cast<lds_f4 *>(ys + 4 * (i0 + 64 * j)) = v[j];
+                    if (i0 + nt * j < n4) *reinterpret_cast<lds_f4 *>(ys + 4 * (i0 + nt * j)) = v[j];
             }
             if (lane < kYCols) ys[P * kYCols + lane] = 0.0f;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sync();
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) {
+        for (int u = 0; u < NP; ++u) {
             if (u >= npos) break;
             const lds_f *yc = ys + (prow[u] * HW + psp[u]) * kYCols;
             const lds_f *yt[KK];
@@ -1234,10 +1258,10 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
         }
     } else {
         // the block's input -> LDS cells (every value requested before the first is used), then conv1 and the skip path
-        float xin[kThinMaxC][kThinMaxPos];
-        const float *xr[kThinMaxPos];
+        float xin[kThinMaxC][NP];
+        const float *xr[NP];
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) {
+        for (int u = 0; u < NP; ++u) {
             xr[u] = nullptr;
             if (live[u]) {
                 const long long s = x_rows ? (long long)x_rows[r0 + prow[u]] : (long long)(r0 + prow[u]);
@@ -1245,7 +1269,7 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
             }
         }
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u)
+        for (int u = 0; u < NP; ++u)
 #pragma unroll
             for (int ci = 0; ci < kThinMaxC; ++ci)
                 xin[ci][u] = (ci < CI && xr[u] && (EXACT || ci < Cin)) ? xr[u][ci * HW] : 0.0f;
@@ -1253,17 +1277,15 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
 #pragma unroll
             for (int co = 0; co < CO; ++co)
 #pragma unroll
-                for (int u = 0; u < kThinMaxPos; ++u)
+                for (int u = 0; u < NP; ++u)
                     if ((EXACT || co < Cout) && live[u]) c1[co][u] = R.conv1_bias[co * HW + psp[u]];
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u)
+        for (int u = 0; u < NP; ++u)
             if (live[u])
-                *reinterpret_cast<lds_f4 *>(a_in + 4 * (lane + 64 * u)) = f32x4{xin[0][u], xin[1][u], xin[2][u], xin[3][u]};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                *reinterpret_cast<lds_f4 *>(a_in + 4 * (lane_p + 64 * u)) = f32x4{xin[0][u], xin[1][u], xin[2][u], xin[3][u]};
+        sync();
 #pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) {
+        for (int u = 0; u < NP; ++u) {
             if (u >= npos) break;
             float acc[CO];
 #pragma unroll
@@ -1286,74 +1308,64 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
         }
     }
 
-    // BatchNorm2d over the call's P values of a channel (mean / biased variance in float64 around a
-    // pivot, as the general kernel): per channel the two wave sums, then thin_bn_tail for all channels at once
-    auto sums = [&](const float (&v)[kThinMaxPos], float &pivot, double &s, double &q) {
-        pivot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0])));
-        s = 0.0, q = 0.0;
-#pragma unroll
-        for (int u = 0; u < kThinMaxPos; ++u) {
-            if (u >= npos) break;
-            const double d = live[u] ? (double)v[u] - (double)pivot : 0.0;
-            s += d;
-            q += d * d;
-        }
-        s = wave_total(s);
-        q = wave_total(q);
+    // BatchNorm2d over the call's P values of a channel (mean / biased variance in float64 around a pivot, as
+    // the general kernel).  bn1 and the skip path's BatchNorm share one pass (2 * CO channels): the values go to
+    // LDS cells first (conv1's output where conv2's input will be, the skip path's over the block's input, which
+    // is in registers by now), see thin_bn_lanes.
+    auto cell4 = [&](const float (&v)[CO][NP], int u) {
+        return f32x4{v[0][u], CO > 1 ? v[CO > 1 ? 1 : 0][u] : 0.0f, CO > 2 ? v[CO > 2 ? 2 : 0][u] : 0.0f, CO > 3 ? v[CO > 3 ? 3 : 0][u] : 0.0f};
     };
+    lds_f *a_skip = FROM_Y ? a_mid + cells : a_in;  // P cells: the products / the block's input are not read again
     float *st1 = stats, *st2 = stats ? stats + 2LL * calls * Cout : nullptr, *st3 = stats ? stats + 4LL * calls * Cout : nullptr;
-    {   // bn1 (+ activation) and the skip path's BatchNorm: 2 * CO channels in one tail
+    const int sch = lane >> 3;  // the channel this lane adds up
+    {
         constexpr int N = 2 * CO;
-        double s[N], q[N];
-        float pivot[N], gamma[N], beta[N], eps[N], scale[N], shift[N];
-#pragma unroll
-        for (int c = 0; c < N; ++c) {
-            s[c] = q[c] = 0.0;
-            pivot[c] = gamma[c] = beta[c] = 0.0f;
-            eps[c] = 1.0f;
+        const bool is_skip = sch >= CO;
+        const int comp = is_skip ? sch - CO : sch;
+        const bool on = sch < N && comp < Cout && (!is_skip || down);
+        float ga = 0.0f, be = 0.0f;
+        if (on) {
+            ga = R.bn[is_skip ? 4 : 0][comp];
+            be = R.bn[is_skip ? 5 : 1][comp];
         }
+        sync();  // every lane has taken its windows
 #pragma unroll
-        for (int co = 0; co < CO; ++co) {
-            if (!EXACT && co >= Cout) break;
-            sums(c1[co], pivot[co], s[co], q[co]);
-            gamma[co] = as_constant(R.bn[0])[co], beta[co] = as_constant(R.bn[1])[co], eps[co] = R.eps1;
-            if (down) {
-                sums(sk[co], pivot[CO + co], s[CO + co], q[CO + co]);
-                gamma[CO + co] = as_constant(R.bn[4])[co], beta[CO + co] = as_constant(R.bn[5])[co], eps[CO + co] = R.epsd;
+        for (int u = 0; u < NP; ++u)
+            if (live[u]) {
+                *reinterpret_cast<lds_f4 *>(a_mid + 4 * (lane_p + 64 * u)) = cell4(c1, u);
+                if (down) *reinterpret_cast<lds_f4 *>(a_skip + 4 * (lane_p + 64 * u)) = cell4(sk, u);
             }
-        }
+        sync();
         float *mean_dst = nullptr, *var_dst = nullptr;
-        if (stats != nullptr) {
-            const int c = lane < CO ? lane : lane - CO;
-            float *st = lane < CO ? st1 : st3;
-            if (c < Cout && (lane < CO || down)) {
-                mean_dst = st + (long long)call * Cout + c;
-                var_dst = st + (long long)(calls + call) * Cout + c;
-            }
+        if (stats != nullptr && on && (lane & 7) == 0 && (!SPLIT || wave == 0)) {
+            float *st = is_skip ? st3 : st1;
+            mean_dst = st + (long long)call * Cout + comp;
+            var_dst = st + (long long)(calls + call) * Cout + comp;
         }
-        thin_bn_tail<N>(s, q, pivot, gamma, beta, eps, P, mean_dst, var_dst, scale, shift);
+        float scale[N], shift[N];
+        thin_bn_lanes<N, SPLIT ? kThinMaxPos : NP>((is_skip ? a_skip : a_mid) + (on ? comp : 0), on, P, ga, be, is_skip ? R.epsd : R.eps1, mean_dst,
+                             var_dst, scale, shift);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
             if (!EXACT && co >= Cout) break;
 #pragma unroll
-            for (int u = 0; u < kThinMaxPos; ++u) {
+            for (int u = 0; u < NP; ++u) {
                 c1[co][u] = activate(c1[co][u] * scale[co] + shift[co], R.act);
                 if (down) sk[co][u] = sk[co][u] * scale[CO + co] + shift[CO + co];
             }
         }
     }
+    if constexpr (SPLIT) __syncthreads();  // the other waves have read conv1's raw output
 #pragma unroll
-    for (int u = 0; u < kThinMaxPos; ++u)
+    for (int u = 0; u < NP; ++u)
         if (live[u])
-            *reinterpret_cast<lds_f4 *>(a_mid + 4 * (lane + 64 * u)) =
+            *reinterpret_cast<lds_f4 *>(a_mid + 4 * (lane_p + 64 * u)) =
                 f32x4{c1[0][u], CO > 1 ? c1[CO > 1 ? 1 : 0][u] : 0.0f, CO > 2 ? c1[CO > 2 ? 2 : 0][u] : 0.0f, CO > 3 ? c1[CO > 3 ? 3 : 0][u] : 0.0f};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    sync();
     // conv2 (Cout -> Cout), its BatchNorm, the skip sum and the activation
-    float c2[CO][kThinMaxPos];
+    float c2[CO][NP];
 #pragma unroll
-    for (int u = 0; u < kThinMaxPos; ++u) {
+    for (int u = 0; u < NP; ++u) {
         float acc[CO];
 #pragma unroll
         for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
@@ -1362,28 +1374,29 @@ k_tower_thin(ThinBlock R, const float *__restrict__ x, long long ldx, const int3
         for (int co = 0; co < CO; ++co) c2[co][u] = acc[co];
     }
     {
-        double s[CO], q[CO];
-        float pivot[CO], gamma[CO], beta[CO], eps[CO], scale[CO], shift[CO];
+        const bool on = sch < CO && sch < Cout;
+        float ga = 0.0f, be = 0.0f;
+        if (on) {
+            ga = R.bn[2][sch];
+            be = R.bn[3][sch];
+        }
+        sync();  // every lane has read its windows of conv2's input: its cells take conv2's output
 #pragma unroll
-        for (int co = 0; co < CO; ++co) {
-            s[co] = q[co] = 0.0;
-            pivot[co] = gamma[co] = beta[co] = 0.0f;
-            eps[co] = 1.0f;
-            if (!EXACT && co >= Cout) continue;
-            sums(c2[co], pivot[co], s[co], q[co]);
-            gamma[co] = as_constant(R.bn[2])[co], beta[co] = as_constant(R.bn[3])[co], eps[co] = R.eps2;
-        }
+        for (int u = 0; u < NP; ++u)
+            if (live[u]) *reinterpret_cast<lds_f4 *>(a_mid + 4 * (lane_p + 64 * u)) = cell4(c2, u);
+        sync();
         float *mean_dst = nullptr, *var_dst = nullptr;
-        if (stats != nullptr && lane < Cout) {
-            mean_dst = st2 + (long long)call * Cout + lane;
-            var_dst = st2 + (long long)(calls + call) * Cout + lane;
+        if (stats != nullptr && on && (lane & 7) == 0 && (!SPLIT || wave == 0)) {
+            mean_dst = st2 + (long long)call * Cout + sch;
+            var_dst = st2 + (long long)(calls + call) * Cout + sch;
         }
-        thin_bn_tail<CO>(s, q, pivot, gamma, beta, eps, P, mean_dst, var_dst, scale, shift);
+        float scale[CO], shift[CO];
+        thin_bn_lanes<CO, SPLIT ? kThinMaxPos : NP>(a_mid + (on ? sch : 0), on, P, ga, be, R.eps2, mean_dst, var_dst, scale, shift);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
             if (!EXACT && co >= Cout) break;
 #pragma unroll
-            for (int u = 0; u < kThinMaxPos; ++u)
+            for (int u = 0; u < NP; ++u)
                 if (live[u] && drow[u] >= 0)
                     t_out[drow[u] * ld_t + co * HW + psp[u]] = activate((c2[co][u] * scale[co] + shift[co]) + sk[co][u], R.act);
         }
@@ -1905,7 +1918,21 @@ int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, in
                            (long long)hw * kYCols, nullptr, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
         return mz::check_launch("k_tower_thin");
     };
-    return R.out_channels == 3 ? launch(k_tower_thin<true, 3, 3, 3, true>) : launch(k_tower_thin<true, 3, 4, 4, false>);
+    if (R.out_channels == 3) {
+        const int P = group * hw;
+        if (P <= 64) return launch(k_tower_thin<true, 3, 3, 3, true, 1>);
+        static const bool split = [] { const char *e = getenv("MZ_THIN_SPLIT"); return !e || atoi(e) != 0; }();  // cross-checking aid
+        if (split) {  // one workgroup per call, one wave per 64 positions
+            auto kernel = k_tower_thin<true, 3, 3, 3, true, 1, true>;
+            const size_t lds1 = wave_floats * sizeof(float);
+            MZ_TRY(allow_lds(kernel, lds1, "k_tower_thin"));
+            hipLaunchKernelGGL(kernel, dim3(calls), dim3(64 * ((P + 63) / 64)), lds1, (hipStream_t)stream, tb, Y,
+                               (long long)hw * kYCols, nullptr, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
+            return mz::check_launch("k_tower_thin");
+        }
+        return P <= 192 ? launch(k_tower_thin<true, 3, 3, 3, true, 3>) : launch(k_tower_thin<true, 3, 3, 3, true>);
+    }
+    return launch(k_tower_thin<true, 3, 4, 4, false>);
 }
 
 // Calls per launch from which the one-wave-per-call kernel takes over thin towers.  It is as fast as the
@@ -1968,7 +1995,8 @@ int mz_tower_forward_stats(const mz_tower *h_tower, const float *x, int64_t ldx,
                                (long long)ldx, x_rows, t_out, (long long)ld_t, y_rows, group, calls, bn_stats);
             return mz::check_launch("k_tower_thin");
         };
-        if (R.kernel_size == 3 && R.in_channels == 3 && R.out_channels == 3) return launch_thin(k_tower_thin<false, 3, 3, 3, true>);
+        if (R.kernel_size == 3 && R.in_channels == 3 && R.out_channels == 3)
+            return group * hw <= 64 ? launch_thin(k_tower_thin<false, 3, 3, 3, true, 1>) : launch_thin(k_tower_thin<false, 3, 3, 3, true>);
         return R.kernel_size == 3 ? launch_thin(k_tower_thin<false, 3, 4, 4, false>) : launch_thin(k_tower_thin<false, 1, 4, 4, false>);
     }
     TowerGeom g;
