@@ -1007,3 +1007,44 @@ def test_selfplay_starts_tower_searches_from_the_pooled_input_of_hs_final_convol
     np.testing.assert_allclose(rb[2][both].cpu().numpy(), pb[2][both].cpu().numpy(), rtol=1e-4, atol=1e-6)
     rooted.env.close()
     plain.env.close()
+
+
+def test_root_form_advances_running_statistics_like_the_plain_form():
+    """track_running_stats with roots given as h's bottleneck values: the root expansion (f on the root, g for the A
+    children, in the bottleneck form with weights composed with h's final convolution) leaves the same BatchNorm
+    running statistics and call counts in the modules as the same expansion from the 256-channel latents."""
+    import copy
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    A, G, S = 5, 6, 4
+    g, f = build_nets((256, 6, 6), A)
+    g2, f2 = copy.deepcopy(g), copy.deepcopy(f)
+    torch.manual_seed(9)
+    fin = torch.nn.Conv2d(3, 256, 1).cuda()
+    rng = np.random.default_rng(11)
+    root_t = torch.from_numpy(rng.standard_normal((G, 3, 6, 6)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        lat = fin(root_t).reshape(G, -1).contiguous()
+    eta = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).cuda()
+    rand0 = torch.from_numpy(rng.integers(0, A, size=G).astype(np.int32)).cuda()
+    to_play = torch.zeros(G, dtype=torch.int8, device="cuda")
+    nets_r = TowerNetworks(g, f, track_running_stats=True, root_final=fin)
+    nets_p = TowerNetworks(g2, f2, track_running_stats=True)
+    rooted = BatchedMCTS(nets_r, G, S, 1, discount=0.997, noise_frac=0.25, keep_latents=False)
+    plain = BatchedMCTS(nets_p, G, S, 1, discount=0.997, noise_frac=0.25, keep_latents=False)
+    assert rooted.root_form_ok(root_t)
+    rooted.begin(None, to_play, eta, rand0, root_t=root_t)
+    plain.begin(lat, to_play, eta, rand0)
+    nets_r.sync_running_stats()
+    nets_p.sync_running_stats()
+    torch.cuda.synchronize()
+    bns = lambda *nets: [m for n in nets for m in n.modules() if isinstance(m, torch.nn.BatchNorm2d)]  # noqa: E731
+    seen = 0
+    for a, b in zip(bns(g, f), bns(g2, f2)):
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == G
+        for x, y in ((a.running_mean, b.running_mean), (a.running_var, b.running_var)):
+            x, y = x.detach().double().cpu().numpy(), y.detach().double().cpu().numpy()
+            np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(y).max())))
+        seen += 1
+    assert seen == 6   # three BatchNorm layers in g's block, three in f's
