@@ -654,6 +654,18 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
                           const float *t, int64_t ld_t, const int32_t *t_rows, const float *table,
                           const int32_t *action, int32_t A, int32_t B, int32_t C, int32_t HW, float *Y,
                           void *stream);
+/* The same pass at the bf16 matrix rate with float32 accuracy: every float32 operand is split exactly into three
+ * bf16 terms and a product evaluated as the six bf16 products of relative size >= 2^-24 in float32 accumulators
+ * (results equal mz_merge_conv_forward's up to the summation order of float32: ~1e-7 of their scale; no
+ * counterpart in the reference, which evaluates these layers in float32).  merge3 / conv3: the two layers' weights
+ * as split operands, written once per weight update by mz_packed_split3 from the packed float32 layers
+ * (mz_packed_split3_words 32-bit words each); the other arguments as mz_merge_conv_forward. */
+int64_t mz_packed_split3_words(const mz_packed_layer *h_plan);
+int mz_packed_split3(const mz_packed_layer *h_plan, const float *blob, uint32_t *out, void *stream);
+int mz_merge_conv_forward_split(const mz_packed_layer *h_merge, const uint32_t *merge3, const mz_packed_layer *h_conv,
+                                const uint32_t *conv3, const float *t, int64_t ld_t, const int32_t *t_rows,
+                                const float *table, const int32_t *action, int32_t A, int32_t B, int32_t C, int32_t HW,
+                                float *Y, void *stream);
 int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, int32_t group, float *t_out,
                           int64_t ld_t, const int32_t *y_rows, float *bn_stats, void *stream);
 

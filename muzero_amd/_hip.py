@@ -172,6 +172,10 @@ _SIGS = {
                                C.c_int32, _P]),
     "mz_merge_conv_forward": (C.c_int, [C.POINTER(PackedLayer), C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, _P, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mz_merge_conv_forward_split": (C.c_int, [C.POINTER(PackedLayer), _P, C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, _P,
+                                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mz_packed_split3_words": (C.c_int64, [C.POINTER(PackedLayer)]),
+    "mz_packed_split3": (C.c_int, [C.POINTER(PackedLayer), _P, _P, _P]),
     "mz_tower_thin_min_calls": (C.c_int, [C.c_int32]),
     "mz_tower_tail_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P, _P]),
     "mz_tower_stats_floats": (C.c_int64, [C.POINTER(Tower), C.c_int32]),

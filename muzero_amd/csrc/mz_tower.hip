@@ -1595,6 +1595,217 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
     }
 }
 
+// The same pass at the bf16 matrix rate (v_mfma_f32_16x16x32_bf16: 16 times the rate of the fp32 instruction) with
+// float32 accuracy.  A float32 value splits exactly into three bf16 terms, x = x1 + x2 + x3 (x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significant bits), and a product is, up to terms of relative
+// size 2^-24,   x w = x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1):  six instructions that cover 32 reduction
+// indices where the fp32 form needs eight -- 2.7 times less matrix time.  The packed float32 weights are split in
+// registers as they arrive (same layers as the fp32 form reads), the rows of t once while they are staged (three
+// planes in LDS, a lane's eight values of a pair of k-tiles in one 16-byte piece per plane), x = relu(z + table)
+// in registers: its eight channels per lane are exactly one instruction's operand.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {  // round to nearest even, a in the low half
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// four values -> their three planes, two words (four bf16) each
+__device__ __forceinline__ void split3(const f32x4 &v, u32x2 &p1, u32x2 &p2, u32x2 &p3) {
+    p1.x = bf16_pair(v.x, v.y);
+    p1.y = bf16_pair(v.z, v.w);
+    const float r0 = v.x - bf16_lo(p1.x), r1 = v.y - bf16_hi(p1.x), r2 = v.z - bf16_lo(p1.y), r3 = v.w - bf16_hi(p1.y);
+    p2.x = bf16_pair(r0, r1);
+    p2.y = bf16_pair(r2, r3);
+    p3.x = bf16_pair(r0 - bf16_lo(p2.x), r1 - bf16_hi(p2.x));
+    p3.y = bf16_pair(r2 - bf16_lo(p2.y), r3 - bf16_hi(p2.y));
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x2 &a, const u32x2 &b) {
+    return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
+}
+// acc += a b for operands given as three planes each (smallest terms first)
+__device__ __forceinline__ f32x4 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// A packed float32 layer (tiles [column tile][k-tile][lane] of float4, mz_wide_pack) -> its three bf16 planes as
+// matrix-instruction operands: out[((column tile * pairs + pair) * 3 + plane) * 64 + lane] = the lane's four values of
+// k-tile 2 pair followed by those of k-tile 2 pair + 1 (zeros past the last tile).
+__global__ void k_packed_split3(const float *__restrict__ w, int KT, int NT, u32x4 *__restrict__ out) {
+    const int npairs = (KT + 1) >> 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)NT * npairs * 64) return;
+    const int lane = (int)(i & 63), pr = (int)((i >> 6) % npairs), nt = (int)((i >> 6) / npairs);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(w) + ((long long)nt * KT + 2 * pr) * 64 + lane;
+    const f32x4 a = src[0], b = 2 * pr + 1 < KT ? src[64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 pa[3], pb[3];
+    split3(a, pa[0], pa[1], pa[2]);
+    split3(b, pb[0], pb[1], pb[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[(((long long)nt * npairs + pr) * 3 + pl) * 64 + lane] = u32x4{pa[pl].x, pa[pl].y, pb[pl].x, pb[pl].y};
+}
+
+constexpr int kMcPairs = kMcMaxKT / 2;          // pairs of k-tiles of the merge product
+constexpr int kMcLdT3 = kMcPairs * 16 + 4;      // words per row and plane of the split rows of t (skewed)
+static_assert(3 * kMcLdT3 <= (kMcT / 64) * kMcLdP, "the split rows fit the area of the partial products");
+
+template <int MTR>
+__global__ void __launch_bounds__(kMcT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *__restrict__ conv3,
+                const float *__restrict__ t, long long ld_t, const int32_t *__restrict__ t_rows, int B,
+                const float *__restrict__ table, const int32_t *__restrict__ action, int A, int nA, int HW,
+                float *__restrict__ Y) {
+    extern __shared__ __align__(16) float smem[];
+    constexpr int kMcRows = 16 * MTR, TPR = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int pos = blockIdx.y, r0 = blockIdx.x * kMcRows;
+    lds_f *Ps = to_lds(smem);
+    lds_i *T3 = to_lds_i(smem);  // [plane][row][kMcLdT3]: piece (pair, kq) of a row = its eight values of that pair
+    lds_i *s_act = to_lds_i(smem + (size_t)(kMcT / 64) * kMcRows * kMcLdP);
+    // weights pre-split by mz_packed_split3: [column tile][pair of k-tiles][plane][lane] 16-byte operands
+    const int npairs = (KTm + 1) >> 1;
+    const u32x4 *wm = merge3 + ((long long)(pos * (kMcC / 16) + 2 * wave) * npairs) * 3 * 64 + lane;
+    const u32x4 *wg = conv3 + (long long)wave * 3 * 64 + lane;  // pair w of the 256 channels' 8 pairs
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the first pair of k-tiles of this wave's merge weights (both column tiles) is on its way while the rows are staged
+    u32x4 wn[2][3];  // [column tile][plane] of the pair to come
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wn[n][pl] = wm[((long long)n * npairs * 3 + pl) * 64];
+    {
+        // TPR threads per row; a thread takes the pieces (four consecutive values) k0, k0 + TPR, ... of its row,
+        // splits them and stores each plane's two words into the 16-byte piece of its (pair, lane group)
+        const int r = tid / TPR, k0 = tid % TPR;
+        long long row = -1;
+        if (r < kMcRows && r0 + r < B) row = t_rows ? (long long)t_rows[r0 + r] : (long long)(r0 + r);
+        constexpr int NQ = 4 * kMcMaxKT / TPR;  // pieces per thread: every piece of every pair is written (zeros past K)
+        f32x4 v[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int k = 4 * (k0 + TPR * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[j][i] = (row >= 0 && k + i < Kt) ? t[row * ld_t + k + i] : 0.0f;
+        }
+        if (r < kMcRows)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = k0 + TPR * j, kt = q >> 2, g4 = q & 3;  // piece -> k-tile, lane group
+                u32x2 p[3];
+                split3(v[j], p[0], p[1], p[2]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(
+                        T3 + ((size_t)pl * kMcRows + r) * kMcLdT3 + ((kt >> 1) * 4 + g4) * 4 + (kt & 1) * 2) = p[pl];
+            }
+    }
+    if (tid < kMcRows) {
+        int a = 0;
+        if (action && r0 + tid < B) a = min(max(action[r0 + tid], 0), A - 1);
+        s_act[tid] = a;
+    }
+    // this wave's convolution weights: channels 32 w .. 32 w + 31 (k-tiles 2 w, 2 w + 1) x both column tiles
+    bf16x8 g3[2][3];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) g3[c2][pl] = __builtin_bit_cast(bf16x8, wg[((long long)c2 * (kMcC / 32) * 3 + pl) * 64]);
+    __syncthreads();
+
+    // ---- z for this position, transposed (weights as the A operand): acc[mt][n][i] = z[row 16 mt + m][channel 32 w + 16 n + 4 kq + i]
+    f32x4 acc[MTR][2];
+#pragma unroll
+    for (int mt = 0; mt < MTR; ++mt)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[mt][n] = zero4;
+    for (int kt = 0, pr = 0; kt < KTm; kt += 2, ++pr) {
+        bf16x8 w3[2][3];  // this pair's weights as operands: [column tile][plane]
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                w3[n][pl] = __builtin_bit_cast(bf16x8, wn[n][pl]);
+                if (pr + 1 < npairs) wn[n][pl] = wm[(((long long)n * npairs + pr + 1) * 3 + pl) * 64];
+            }
+#pragma unroll
+        for (int mt = 0; mt < MTR; ++mt) {
+            bf16x8 t3[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                t3[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(
+                                                        T3 + ((size_t)pl * kMcRows + mt * 16 + m) * kMcLdT3 + (pr * 4 + kq) * 4));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[mt][n] = mfma6(w3[n], t3, acc[mt][n]);
+        }
+    }
+    int act_m[MTR] = {};
+    if (action)
+#pragma unroll
+        for (int mt = 0; mt < MTR; ++mt) act_m[mt] = s_act[mt * 16 + m];
+    __syncthreads();  // every wave has read its rows of t
+    // ---- per action: x = relu(z + table[action]) in registers, this wave's part of Y = x Wg, partials added through LDS
+    const int rrow = tid >> 3, rc4 = tid & 7;
+    for (int ai = 0; ai < nA; ++ai) {
+        f32x4 y[MTR][2];
+        const f32x4 *trow = reinterpret_cast<const f32x4 *>(table + ((long long)ai * HW + pos) * kMcC + 32 * wave + 4 * kq);
+        f32x4 tv0[2] = {zero4, zero4};
+        if (!action) {
+            tv0[0] = trow[0];
+            tv0[1] = trow[4];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTR; ++mt) {
+            f32x4 x[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f32x4 tv = action ? *reinterpret_cast<const f32x4 *>(table + ((long long)act_m[mt] * HW + pos) * kMcC + 32 * wave + 16 * n + 4 * kq)
+                                        : tv0[n];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[n][i] = fmaxf(acc[mt][n][i] + tv[i], 0.0f);
+            }
+            u32x2 pa[3], pb[3];
+            split3(x[0], pa[0], pa[1], pa[2]);
+            split3(x[1], pb[0], pb[1], pb[2]);
+            bf16x8 x3[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x3[pl] = as_bf16x8(pa[pl], pb[pl]);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) y[mt][c2] = mfma6(x3, g3[c2], zero4);
+        }
+        // y[mt][c2][i] = partial Y[row 16 mt + 4 kq + i][column 16 c2 + m]
+        lds_f *pw = Ps + (size_t)wave * kMcRows * kMcLdP;
+#pragma unroll
+        for (int mt = 0; mt < MTR; ++mt)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[(mt * 16 + 4 * kq + i) * kMcLdP + 16 * c2 + m] = y[mt][c2][i];
+        __syncthreads();
+        if (tid < kMcRows * 8) {
+            f32x4 sum = *reinterpret_cast<const lds_f4 *>(Ps + rrow * kMcLdP + 4 * rc4);
+#pragma unroll
+            for (int w = 1; w < kMcT / 64; ++w) {
+                const f32x4 v = *reinterpret_cast<const lds_f4 *>(Ps + ((size_t)w * kMcRows + rrow) * kMcLdP + 4 * rc4);
+                sum.x += v.x;
+                sum.y += v.y;
+                sum.z += v.z;
+                sum.w += v.w;
+            }
+            const int rg = r0 + rrow;
+            if (rg < B) *reinterpret_cast<f32x4 *>(Y + (((long long)rg * nA + ai) * HW + pos) * kYCols + 4 * rc4) = sum;
+        }
+        if (ai + 1 < nA) __syncthreads();
+    }
+}
+
 int tower_geometry(const mz_tower *T, int group, int ng, bool vec_ok, TowerGeom *g, size_t *lds_bytes) {
     if (!T || T->n_blocks < 0 || T->n_blocks > MZ_MAX_BLOCKS || T->C <= 0 || T->H <= 0 || T->W <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_tower_forward: bad tower (n_blocks 0..%d, positive C, H, W)", MZ_MAX_BLOCKS);
@@ -1847,9 +2058,12 @@ int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, con
     return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, scratch, need, stream);
 }
 
-int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer *h_conv, const float *blob, const float *t,
-                          int64_t ld_t, const int32_t *t_rows, const float *table, const int32_t *action, int32_t A, int32_t B,
-                          int32_t C, int32_t HW, float *Y, void *stream) {
+static int merge_conv_impl(const mz_packed_layer *h_merge, const mz_packed_layer *h_conv, const float *blob, const float *t,
+                           int64_t ld_t, const int32_t *t_rows, const float *table, const int32_t *action, int32_t A, int32_t B,
+                           int32_t C, int32_t HW, float *Y, void *stream, const uint32_t *merge3 = nullptr,
+                           const uint32_t *conv3 = nullptr) {
+    const bool split = merge3 != nullptr;
+    if (split && !blob) blob = reinterpret_cast<const float *>(merge3);  // the float32 tiles are not read in this form
     if (!h_merge || !h_conv || !blob || !t || !table || !Y || A <= 0 || B <= 0 || HW <= 0)
         return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: NULL argument or non-positive size");
     if (C != kMcC) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward: %d channels (the kernel is built for %d)", C, kMcC);
@@ -1886,10 +2100,52 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
                            (long long)h_merge->w_off, KTm, h_merge->K, (long long)h_conv->w_off, t, (long long)ld_t, t_rows, B,
                            table, action, A, action ? 1 : A, HW, Y, skip);
     };
+    if (split) {
+        MZ_TRY(allow_lds(k_merge_conv_bf<4>, mc_lds(64), "k_merge_conv_bf"));
+        MZ_TRY(allow_lds(k_merge_conv_bf<2>, mc_lds(32), "k_merge_conv_bf"));
+        MZ_TRY(allow_lds(k_merge_conv_bf<3>, mc_lds(48), "k_merge_conv_bf"));
+        auto launch_bf = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((B + rows - 1) / rows, HW), dim3(kMcT), lds, (hipStream_t)stream,
+                               reinterpret_cast<const u32x4 *>(merge3), KTm, h_merge->K, reinterpret_cast<const u32x4 *>(conv3), t,
+                               (long long)ld_t, t_rows, B, table, action, A, action ? 1 : A, HW, Y);
+        };
+        if (rows == 32) launch_bf(k_merge_conv_bf<2>);
+        else if (rows == 48) launch_bf(k_merge_conv_bf<3>);
+        else launch_bf(k_merge_conv_bf<4>);
+        return mz::check_launch("k_merge_conv_bf");
+    }
     if (rows == 32) launch(k_merge_conv<2>);
     else if (rows == 48) launch(k_merge_conv<3>);
     else launch(k_merge_conv<4>);
     return mz::check_launch("k_merge_conv");
+}
+
+int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer *h_conv, const float *blob, const float *t,
+                          int64_t ld_t, const int32_t *t_rows, const float *table, const int32_t *action, int32_t A, int32_t B,
+                          int32_t C, int32_t HW, float *Y, void *stream) {
+    return merge_conv_impl(h_merge, h_conv, blob, t, ld_t, t_rows, table, action, A, B, C, HW, Y, stream);
+}
+
+int mz_merge_conv_forward_split(const mz_packed_layer *h_merge, const uint32_t *merge3, const mz_packed_layer *h_conv,
+                                const uint32_t *conv3, const float *t, int64_t ld_t, const int32_t *t_rows, const float *table,
+                                const int32_t *action, int32_t A, int32_t B, int32_t C, int32_t HW, float *Y, void *stream) {
+    if (!merge3 || !conv3) return mz::fail(MZ_ERR_ARG, "mz_merge_conv_forward_split: NULL split weights");
+    return merge_conv_impl(h_merge, h_conv, nullptr, t, ld_t, t_rows, table, action, A, B, C, HW, Y, stream, merge3, conv3);
+}
+
+int64_t mz_packed_split3_words(const mz_packed_layer *h_plan) {
+    if (!h_plan || h_plan->Kp <= 0 || h_plan->Np <= 0) return mz::fail(MZ_ERR_ARG, "mz_packed_split3_words: NULL or empty layer");
+    return (int64_t)(h_plan->Np / 16) * (((h_plan->Kp / 16) + 1) / 2) * 3 * 64 * 4;
+}
+
+int mz_packed_split3(const mz_packed_layer *h_plan, const float *blob, uint32_t *out, void *stream) {
+    if (!h_plan || !blob || !out || h_plan->Kp <= 0 || h_plan->Np <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_packed_split3: NULL argument or an empty layer");
+    const int KT = h_plan->Kp / 16, NT = h_plan->Np / 16;
+    const long long n = (long long)NT * ((KT + 1) / 2) * 64;
+    hipLaunchKernelGGL(k_packed_split3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, blob + h_plan->w_off,
+                       KT, NT, reinterpret_cast<u32x4 *>(out));
+    return mz::check_launch("k_packed_split3");
 }
 
 int mz_tower_tail_forward(const mz_tower *h_tower, const float *Y, int32_t B, int32_t group, float *t_out, int64_t ld_t,

@@ -82,6 +82,9 @@ class TowerNetworks:
         # a few values as g's outputs are, and the root expansion can run in the bottleneck form too (`root_form`)
         self.root_final = root_final
         self.fuse_merge_conv = fuse_merge_conv  # False keeps fc_merge and the tower of g as separate kernels
+        # the fused pass on operands split into three bf16 terms each: float32 accuracy at the bf16 matrix rate
+        # (MZ_MC_SPLIT=0: float32 matrix instructions)
+        self.split_merge_conv = os.environ.get("MZ_MC_SPLIT", "1") != "0"
         # source rows from which the fused form is used (default: always; 256 trees 1.33 -> 1.41 M sims/s, the
         # expansion's separate kernels take 57 us there, the fused pair 43 us)
         self.fuse_min_rows = int(os.environ.get("MZ_FUSE_MIN_ROWS", "1"))
@@ -329,6 +332,15 @@ class TowerNetworks:
                 _hip.check(lib.mz_wide_pack(C.byref(src), C.byref(pl), ptr(self.blob), _stream()), "mz_wide_pack")
             else:
                 _hip.check(lib.mz_mlp_pack(C.byref(src), C.byref(pl), ptr(self.blob), _stream()), "mz_mlp_pack")
+        # the fused fc_merge + first-convolution pass at the bf16 matrix rate: its layers as three bf16 planes
+        self.split3 = {}
+        if self.fused_g and self.split_merge_conv:
+            for name in ("merge_t_perm", "conv_g", "merge_root_perm"):
+                pl = getattr(self, name)
+                if pl is not None:
+                    out = torch.empty(int(lib.mz_packed_split3_words(C.byref(pl))), dtype=torch.int32, device=self.device)
+                    _hip.check(lib.mz_packed_split3(C.byref(pl), ptr(self.blob), ptr(out), _stream()), "mz_packed_split3")
+                    self.split3[name] = out
         self.table = torch.empty((A, D), dtype=torch.float32, device=self.device)
         _hip.check(lib.mz_action_table(ptr(self._dev(g.action_embedding.weight)), ptr(self._dev(g.fc_merge.weight)),
                                        ptr(self._dev(g.fc_merge.bias)) if g.fc_merge.bias is not None else None,
@@ -514,9 +526,15 @@ class TowerNetworks:
         B = n_src if action is not None else n_src * self.A
         Y = self._buf("g_Y", (B, hgt * wid, 32))
         plan, table = (self.merge_root_perm, self.table_root_perm) if root_form else (self.merge_t_perm, self.table_t_perm)
-        _hip.check(_hip.lib().mz_merge_conv_forward(C.byref(plan), C.byref(self.conv_g), ptr(self.blob), ptr(t),
-                                                    t.shape[-1], ptr(t_rows), ptr(table), ptr(action), self.A, n_src,
-                                                    c, hgt * wid, ptr(Y), _stream()), "mz_merge_conv_forward")
+        if self.split_merge_conv:
+            m3 = self.split3["merge_root_perm" if root_form else "merge_t_perm"]
+            _hip.check(_hip.lib().mz_merge_conv_forward_split(C.byref(plan), ptr(m3), C.byref(self.conv_g), ptr(self.split3["conv_g"]),
+                                                              ptr(t), t.shape[-1], ptr(t_rows), ptr(table), ptr(action), self.A,
+                                                              n_src, c, hgt * wid, ptr(Y), _stream()), "mz_merge_conv_forward_split")
+        else:
+            _hip.check(_hip.lib().mz_merge_conv_forward(C.byref(plan), C.byref(self.conv_g), ptr(self.blob), ptr(t),
+                                                        t.shape[-1], ptr(t_rows), ptr(table), ptr(action), self.A, n_src,
+                                                        c, hgt * wid, ptr(Y), _stream()), "mz_merge_conv_forward")
         return Y
 
     # ---- batched g / f (same calls as PackedNetworks) -----------------------------------------

@@ -43,8 +43,13 @@ def timed(name, call, flop):
 
 def merge_conv(action):
     def call():
-        _hip.check(lib.mz_merge_conv_forward(C.byref(nets.merge_t_perm), C.byref(nets.conv_g), ptr(nets.blob), ptr(t), 108, None,
-                                             ptr(nets.table_t_perm), ptr(action), A, G, c, hw, ptr(Y), st), "mz_merge_conv_forward")
+        if nets.split_merge_conv:
+            _hip.check(lib.mz_merge_conv_forward_split(C.byref(nets.merge_t_perm), ptr(nets.split3["merge_t_perm"]), C.byref(nets.conv_g),
+                                                       ptr(nets.split3["conv_g"]), ptr(t), 108, None, ptr(nets.table_t_perm), ptr(action),
+                                                       A, G, c, hw, ptr(Y), st), "mz_merge_conv_forward_split")
+        else:
+            _hip.check(lib.mz_merge_conv_forward(C.byref(nets.merge_t_perm), C.byref(nets.conv_g), ptr(nets.blob), ptr(t), 108, None,
+                                                 ptr(nets.table_t_perm), ptr(action), A, G, c, hw, ptr(Y), st), "mz_merge_conv_forward")
     return call
 
 
