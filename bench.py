@@ -256,11 +256,9 @@ def tower_search(G, S, dev, steps, with_roofline):
         s = time_kernel(lambda: nets.merge_conv(t, None, None, G), iters=20)
         hw = shape[1] * shape[2]
         flop = 2.0 * G * nets.merge_t_perm.Kp * D + 2.0 * G * A * hw * shape[0] * 32
-        out["roofline_tower"] = {"bound": "mfma", "kernel": "k_merge_conv [g expansion: fc_merge on the bottleneck values, "
-                                 "action term, first tower product; search form]",
-                                 "achieved": flop / s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": flop / s / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us": s * 1e6,
-                                 "flop_per_launch": flop, "traffic": None}
+        from tools.bench_towers import merge_conv_roofline
+        out["roofline_tower"] = merge_conv_roofline(nets, G, A, D, hw, shape[0], s, flop)
+        out["roofline_tower"]["traffic"] = None
     del mcts, nets
     torch.cuda.empty_cache()
     return out

@@ -1048,3 +1048,68 @@ def test_root_form_advances_running_statistics_like_the_plain_form():
             np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(y).max())))
         seen += 1
     assert seen == 6   # three BatchNorm layers in g's block, three in f's
+
+
+@pytest.mark.parametrize("rows", [5, 300, 4096])
+def test_merge_conv_on_bf16_planes_equals_the_fp32_form(rows):
+    """mz_merge_conv_forward_split (every float32 operand as three bf16 terms, six bf16 products per product in
+    float32 accumulators) against mz_merge_conv_forward (fp32 matrix instructions) on the shipped shape: the
+    products Y agree to 1e-6 of their scale, for the expansion (all actions) and for one action per row, ragged row
+    counts and gathered rows; and against a float64 evaluation both are equally close."""
+    import ctypes as C
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    from muzero_amd.towers import TowerNetworks
+    from tools.bench_towers import build_nets
+    A = 5
+    g, f = build_nets((256, 6, 6), A)
+    nets = TowerNetworks(g, f)
+    assert nets.fused_g and nets.split_merge_conv and "merge_t_perm" in nets.split3
+    lib = _hip.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device="cuda").manual_seed(rows)
+    t = torch.randn(rows + 3, 108, device="cuda", generator=gen)
+    t_rows = torch.randperm(rows + 3, device="cuda", generator=gen)[:rows].to(torch.int32)
+    act = torch.randint(0, A, (rows,), device="cuda", generator=gen, dtype=torch.int32)
+    c, hgt, wid = nets.shape
+    for action, n_out in ((None, rows * A), (act, rows)):
+        y32 = torch.zeros(n_out, hgt * wid, 32, device="cuda")
+        y16 = torch.zeros_like(y32)
+        _hip.check(lib.mz_merge_conv_forward(C.byref(nets.merge_t_perm), C.byref(nets.conv_g), ptr(nets.blob), ptr(t), 108,
+                                             ptr(t_rows), ptr(nets.table_t_perm), ptr(action), A, rows, c, hgt * wid, ptr(y32), st),
+                   "mz_merge_conv_forward")
+        _hip.check(lib.mz_merge_conv_forward_split(C.byref(nets.merge_t_perm), ptr(nets.split3["merge_t_perm"]),
+                                                   C.byref(nets.conv_g), ptr(nets.split3["conv_g"]), ptr(t), 108, ptr(t_rows),
+                                                   ptr(nets.table_t_perm), ptr(action), A, rows, c, hgt * wid, ptr(y16), st),
+                   "mz_merge_conv_forward_split")
+        torch.cuda.synchronize()
+        scale = float(y32.abs().max())
+        assert scale > 0 and float((y16 - y32).abs().max()) <= 1e-6 * scale, (float((y16 - y32).abs().max()), scale)
+    # float64 evaluation of the expansion for a few rows: z = W t, x = relu(z + table[a]), Y = x Wg (first block's columns)
+    with torch.no_grad():
+        blk = g.res_blocks[0]
+        co = blk.conv1.out_channels
+        sel = t_rows[:4].long()
+        lat = nets_latent_from_t(nets, g, t[sel].double())
+        base = lat @ g.fc_merge.weight[:, :nets.D].double().cuda().T
+        x = torch.relu(base[:, None, :] + nets.table.double()[None, :, :]).view(4, A, c, hgt * wid)
+        wg = torch.cat([blk.conv1.weight.double().cuda().permute(0, 2, 3, 1).reshape(co * 9, c),
+                        blk.downsample[0].weight.double().cuda().reshape(co, c)])
+        want = torch.einsum("racp,kc->rapk", x, wg)
+    y16 = torch.zeros(rows * A, hgt * wid, 32, device="cuda")
+    _hip.check(lib.mz_merge_conv_forward_split(C.byref(nets.merge_t_perm), ptr(nets.split3["merge_t_perm"]), C.byref(nets.conv_g),
+                                               ptr(nets.split3["conv_g"]), ptr(t), 108, ptr(t_rows), ptr(nets.table_t_perm), None, A,
+                                               rows, c, hgt * wid, ptr(y16), st), "mz_merge_conv_forward_split")
+    torch.cuda.synchronize()
+    got = y16.view(rows, A, hgt * wid, 32)[:4, :, :, :co * 10].double()
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def nets_latent_from_t(nets, g, t64):
+    """The latent a row of bottleneck values stands for: res_final of g applied to the block output (float64)."""
+    c, hgt, wid = nets.shape
+    fin = g.res_final
+    w = fin.weight.double().cuda().reshape(c, -1)
+    b = fin.bias.double().cuda() if fin.bias is not None else torch.zeros(c, dtype=torch.float64, device="cuda")
+    tt = t64.view(t64.shape[0], -1, hgt * wid)
+    return (torch.einsum("ck,rkp->rcp", w, tt) + b[None, :, None]).reshape(t64.shape[0], -1)

@@ -56,6 +56,29 @@ def build_nets(shape, A):
     return g, f
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of an MI355X
+
+
+def merge_conv_roofline(nets, G, A, D, hw, C, seconds, flop):
+    """Roofline entry of k_merge_conv's expansion call.  `flop`: the algorithmic float32 multiply-adds.  In the split
+    form the kernel executes six bf16 products per product (on 128 of the merge layer's reduction indices: pairs
+    of k-tiles) on the bf16 matrix pipe: `achieved` / `peak` / `frac` then refer to that pipe, and
+    `fp32_equivalent_tflops` says what the same result would need of the fp32 pipe (157.3 TFLOP/s peak)."""
+    out = {"bound": "mfma", "kernel": "k_merge_conv [g expansion, search form]", "unit": "TFLOP/s",
+           "avg_launch_us": seconds * 1e6, "flop_per_launch": flop, "fp32_equivalent_tflops": flop / seconds / 1e12,
+           "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS}
+    if getattr(nets, "split_merge_conv", False):
+        kp32 = (nets.merge_t_perm.Kp + 31) // 32 * 32
+        executed = 6.0 * (2.0 * G * kp32 * D + 2.0 * G * A * hw * C * 32)
+        out.update({"kernel": "k_merge_conv_bf [g expansion, search form: operands as three bf16 planes, six products]",
+                    "achieved": executed / seconds / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
+                    "frac": executed / seconds / 1e12 / BF16_MFMA_PEAK_TFLOPS, "executed_bf16_flop_per_launch": executed})
+    else:
+        out.update({"achieved": flop / seconds / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "frac": flop / seconds / 1e12 / MFMA_F32_PEAK_TFLOPS})
+    return out
+
+
 def cpu_network_time(g, f, shape, A, budget_s, threads):
     """The torch modules on the host, called as the reference calls them per simulation
     (src/search/expansion.py:25-30, src/search/simulation.py:31-44: 3 f calls at batch size 1, one g
@@ -187,13 +210,10 @@ def main() -> None:
         step_flop = 2.0 * G * nets.merge_t_perm.Kp * D + 2.0 * G * hw * shape[0] * 32
         f_t = torch.empty(G, nets.bottleneck_f, device="cuda")
         thin_f_ms = timed(lambda: nets._tower_call(nets.tower_f_t, t, dt_, None, None, None, None, 0, None, G, 1, t_out=f_t))
-        tower_roofline = {"bound": "mfma", "kernel": "k_merge_conv [g expansion, search form]",
-                          "achieved": exp_flop / exp_ms / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": exp_flop / exp_ms / 1e9 / MFMA_F32_PEAK_TFLOPS, "avg_launch_us": exp_ms * 1e3,
-                          "flop_per_launch": exp_flop,
-                          "rollout_step_call": {"avg_launch_us": step_ms * 1e3, "flop_per_launch": step_flop,
-                                                "achieved": step_flop / step_ms / 1e9},
-                          "one_wave_tower_kernel_f_call_us": thin_f_ms * 1e3, "traffic": None}
+        tower_roofline = merge_conv_roofline(nets, G, A, D, hw, shape[0], exp_ms * 1e-3, exp_flop)
+        tower_roofline.update({"rollout_step_call": {"avg_launch_us": step_ms * 1e3, "flop_per_launch": step_flop,
+                                                     "fp32_equivalent_tflops": step_flop / step_ms / 1e9},
+                               "one_wave_tower_kernel_f_call_us": thin_f_ms * 1e3, "traffic": None})
     # reference arithmetic per simulation: 3 f calls and A+1 g calls, each g with the full 2D x D fc_merge
     F_heads = 2.0 * (D * 256 + 256 * 128 + 128 + D * 256 + 256 * 256 + 256 * A)
     F_tower = 2.0 * 36 * (shape[0] * 9 * 3 + 3 * 9 * 3 + shape[0] * 3 + 3 * shape[0])
