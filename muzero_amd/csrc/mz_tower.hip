@@ -1675,12 +1675,17 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
     const u32x4 *wm = merge3 + ((long long)(pos * (kMcC / 16) + 2 * wave) * npairs) * 3 * 64 + lane;
     const u32x4 *wg = conv3 + (long long)wave * 3 * 64 + lane;  // pair w of the 256 channels' 8 pairs
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // the first pair of k-tiles of this wave's merge weights (both column tiles) is on its way while the rows are staged
-    u32x4 wn[2][3];  // [column tile][plane] of the pair to come
+    // the first pair of k-tiles of this wave's merge weights (both column tiles) is on its way while the rows are
+    // staged (PF = 2, two pairs ahead, spills registers at every tile size and is slower: measured)
+    constexpr int PF = 1;
+    u32x4 wn[PF][2][3];  // [stage][column tile][plane] of the pairs to come
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int st = 0; st < PF; ++st)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) wn[n][pl] = wm[((long long)n * npairs * 3 + pl) * 64];
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                wn[st][n][pl] = st < npairs ? wm[(((long long)n * npairs + st) * 3 + pl) * 64] : u32x4{0u, 0u, 0u, 0u};
     {
         // TPR threads per row; a thread takes the pieces (four consecutive values) k0, k0 + TPR, ... of its row,
         // splits them and stores each plane's two words into the 16-byte piece of its (pair, lane group)
@@ -1732,8 +1737,9 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                w3[n][pl] = __builtin_bit_cast(bf16x8, wn[n][pl]);
-                if (pr + 1 < npairs) wn[n][pl] = wm[(((long long)n * npairs + pr + 1) * 3 + pl) * 64];
+                w3[n][pl] = __builtin_bit_cast(bf16x8, wn[0][n][pl]);
+                if (PF > 1) wn[0][n][pl] = wn[PF - 1][n][pl];
+                if (pr + PF < npairs) wn[PF - 1][n][pl] = wm[(((long long)n * npairs + pr + PF) * 3 + pl) * 64];
             }
 #pragma unroll
         for (int mt = 0; mt < MTR; ++mt) {
@@ -1746,28 +1752,33 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
             for (int n = 0; n < 2; ++n) acc[mt][n] = mfma6(w3[n], t3, acc[mt][n]);
         }
     }
+    // the table values of the first action are requested before the barrier (expansion); rows with their own action
+    // read theirs where they are used
+    const float *tab = table + (long long)pos * kMcC + 32 * wave + 4 * kq;  // + action * HW * C + 16 n
+    f32x4 tvn[2] = {zero4, zero4};
     int act_m[MTR] = {};
-    if (action)
+    if (action) {
 #pragma unroll
         for (int mt = 0; mt < MTR; ++mt) act_m[mt] = s_act[mt * 16 + m];
+    } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) tvn[n] = *reinterpret_cast<const f32x4 *>(tab + 16 * n);
+    }
     __syncthreads();  // every wave has read its rows of t
     // ---- per action: x = relu(z + table[action]) in registers, this wave's part of Y = x Wg, partials added through LDS
     const int rrow = tid >> 3, rc4 = tid & 7;
     for (int ai = 0; ai < nA; ++ai) {
         f32x4 y[MTR][2];
-        const f32x4 *trow = reinterpret_cast<const f32x4 *>(table + ((long long)ai * HW + pos) * kMcC + 32 * wave + 4 * kq);
-        f32x4 tv0[2] = {zero4, zero4};
-        if (!action) {
-            tv0[0] = trow[0];
-            tv0[1] = trow[4];
-        }
+        const f32x4 tv0[2] = {tvn[0], tvn[1]};
+        if (!action && ai + 1 < nA)  // the next action's values are on their way during this one
+#pragma unroll
+            for (int n = 0; n < 2; ++n) tvn[n] = *reinterpret_cast<const f32x4 *>(tab + (long long)(ai + 1) * HW * kMcC + 16 * n);
 #pragma unroll
         for (int mt = 0; mt < MTR; ++mt) {
             f32x4 x[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const f32x4 tv = action ? *reinterpret_cast<const f32x4 *>(table + ((long long)act_m[mt] * HW + pos) * kMcC + 32 * wave + 16 * n + 4 * kq)
-                                        : tv0[n];
+                const f32x4 tv = action ? *reinterpret_cast<const f32x4 *>(tab + (long long)act_m[mt] * HW * kMcC + 16 * n) : tv0[n];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[n][i] = fmaxf(acc[mt][n][i] + tv[i], 0.0f);
             }
