@@ -656,7 +656,7 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
                           void *stream);
 /* The same pass at the bf16 matrix rate with float32 accuracy: every float32 operand is split exactly into three
  * bf16 terms and a product evaluated as the six bf16 products of relative size >= 2^-24 in float32 accumulators
- * (results equal mz_merge_conv_forward's up to the summation order of float32: ~1e-7 of their scale; no
+ * (results equal mz_merge_conv_forward's to within 1e-6 of their scale, tests/test_gpu_towers.py; no
  * counterpart in the reference, which evaluates these layers in float32).  merge3 / conv3: the two layers' weights
  * as split operands, written once per weight update by mz_packed_split3 from the packed float32 layers
  * (mz_packed_split3_words 32-bit words each); the other arguments as mz_merge_conv_forward. */
