@@ -1625,31 +1625,26 @@ __device__ __forceinline__ void split3(const f32x4 &v, u32x2 &p1, u32x2 &p2, u32
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x2 &a, const u32x2 &b) {
     return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
 }
-// acc += a b for operands given as three planes each (smallest terms first)
-__device__ __forceinline__ f32x4 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-}
-
-// A packed float32 layer (tiles [column tile][k-tile][lane] of float4, mz_wide_pack) -> its three bf16 planes as
-// matrix-instruction operands: out[((column tile * pairs + pair) * 3 + plane) * 64 + lane] = the lane's four values of
-// k-tile 2 pair followed by those of k-tile 2 pair + 1 (zeros past the last tile).
-__global__ void k_packed_split3(const float *__restrict__ w, int KT, int NT, u32x4 *__restrict__ out) {
-    const int npairs = (KT + 1) >> 1;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)NT * npairs * 64) return;
-    const int lane = (int)(i & 63), pr = (int)((i >> 6) % npairs), nt = (int)((i >> 6) / npairs);
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(w) + ((long long)nt * KT + 2 * pr) * 64 + lane;
-    const f32x4 a = src[0], b = 2 * pr + 1 < KT ? src[64] : f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x2 pa[3], pb[3];
-    split3(a, pa[0], pa[1], pa[2]);
-    split3(b, pb[0], pb[1], pb[2]);
+// Products of operands given as three planes each: the six terms of relative size >= 2^-24, smallest first.
+// Two accumulators at once (alternating, so that no instruction waits for the one before it):
+// acc0 += a0 b, acc1 += a1 b  (shared second operand) or acc0 += a b0, acc1 += a b1 (shared first operand).
+__device__ __forceinline__ void mfma6_shared_b(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x4 &acc0,
+                                               f32x4 &acc1) {
+    constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) out[(((long long)nt * npairs + pr) * 3 + pl) * 64 + lane] = u32x4{pa[pl].x, pa[pl].y, pb[pl].x, pb[pl].y};
+    for (int i = 0; i < 6; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[ia[i]], b[ib[i]], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ia[i]], b[ib[i]], acc1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void mfma6_shared_a(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], f32x4 &acc0,
+                                               f32x4 &acc1) {
+    constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia[i]], b0[ib[i]], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia[i]], b1[ib[i]], acc1, 0, 0, 0);
+    }
 }
 
 constexpr int kMcPairs = kMcMaxKT / 2;          // pairs of k-tiles of the merge product
@@ -1748,8 +1743,7 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
             for (int pl = 0; pl < 3; ++pl)
                 t3[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(
                                                         T3 + ((size_t)pl * kMcRows + mt * 16 + m) * kMcLdT3 + (pr * 4 + kq) * 4));
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[mt][n] = mfma6(w3[n], t3, acc[mt][n]);
+            mfma6_shared_b(w3[0], w3[1], t3, acc[mt][0], acc[mt][1]);
         }
     }
     // the table values of the first action are requested before the barrier (expansion); rows with their own action
@@ -1788,8 +1782,8 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
             bf16x8 x3[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) x3[pl] = as_bf16x8(pa[pl], pb[pl]);
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) y[mt][c2] = mfma6(x3, g3[c2], zero4);
+            y[mt][0] = y[mt][1] = zero4;
+            mfma6_shared_a(x3, g3[0], g3[1], y[mt][0], y[mt][1]);
         }
         // y[mt][c2][i] = partial Y[row 16 mt + 4 kq + i][column 16 c2 + m]
         lds_f *pw = Ps + (size_t)wave * kMcRows * kMcLdP;
