@@ -1625,6 +1625,23 @@ __device__ __forceinline__ void split3(const f32x4 &v, u32x2 &p1, u32x2 &p2, u32
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x2 &a, const u32x2 &b) {
     return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
 }
+// A packed float32 layer (tiles [column tile][k-tile][lane] of float4, mz_wide_pack) -> its three bf16 planes as
+// matrix-instruction operands: out[((column tile * pairs + pair) * 3 + plane) * 64 + lane] = the lane's four values of
+// k-tile 2 pair followed by those of k-tile 2 pair + 1 (zeros past the last tile).
+__global__ void k_packed_split3(const float *__restrict__ w, int KT, int NT, u32x4 *__restrict__ out) {
+    const int npairs = (KT + 1) >> 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)NT * npairs * 64) return;
+    const int lane = (int)(i & 63), pr = (int)((i >> 6) % npairs), nt = (int)((i >> 6) / npairs);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(w) + ((long long)nt * KT + 2 * pr) * 64 + lane;
+    const f32x4 a = src[0], b = 2 * pr + 1 < KT ? src[64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 pa[3], pb[3];
+    split3(a, pa[0], pa[1], pa[2]);
+    split3(b, pb[0], pb[1], pb[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[(((long long)nt * npairs + pr) * 3 + pl) * 64 + lane] = u32x4{pa[pl].x, pa[pl].y, pb[pl].x, pb[pl].y};
+}
+
 // Products of operands given as three planes each: the six terms of relative size >= 2^-24, smallest first.
 // Two accumulators at once (alternating, so that no instruction waits for the one before it):
 // acc0 += a0 b, acc1 += a1 b  (shared second operand) or acc0 += a b0, acc1 += a b1 (shared first operand).
