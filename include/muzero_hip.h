@@ -182,9 +182,12 @@ typedef struct mz_mlp {
     mz_dense layer[MZ_MAX_LAYERS];
 } mz_mlp;
 
-/* Layout of one MLP inside a packed weight blob (offsets in floats from the blob start). */
+/* Layout of one MLP inside a packed weight blob (offsets in floats from the blob start).
+ * fmt 1: a layer evaluated on the matrix cores -- Kp = K rounded up to 32, weights stored as two fp16
+ * planes (value and scaled residual, 4 bytes per weight); fmt 0: fp32 tiles, Kp = K rounded up to 16
+ * (layers with at most 8 outputs, evaluated on the vector ALU; every layer of mz_wide_plan). */
 typedef struct mz_packed_layer {
-    int32_t K, N, Kp, Np, act, _pad;
+    int32_t K, N, Kp, Np, act, fmt;
     int64_t w_off, b_off;
 } mz_packed_layer;
 

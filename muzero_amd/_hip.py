@@ -37,7 +37,7 @@ class Mlp(C.Structure):
 
 class PackedLayer(C.Structure):
     _fields_ = [("K", C.c_int32), ("N", C.c_int32), ("Kp", C.c_int32), ("Np", C.c_int32),
-                ("act", C.c_int32), ("_pad", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
+                ("act", C.c_int32), ("fmt", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
 class PackedMlp(C.Structure):

@@ -10,5 +10,5 @@ char *error_buffer() {
 
 extern "C" {
 const char *mz_last_error(void) { return mz::error_buffer(); }
-int mz_abi_version(void) { return 2; }
+int mz_abi_version(void) { return 3; }
 }

@@ -1,5 +1,6 @@
-// Batched fp32 MFMA forward passes of the MLP-only h/g/f networks (gfx950) and the
-// weight re-tiling they read.  Device-side building blocks: mz_mlp_device.h.
+// Batched MFMA forward passes of the MLP-only h/g/f networks (gfx950) and the weight
+// re-tiling they read (fp32 weights as two fp16 planes for the matrix layers, fp32 tiles
+// for narrow layers and for the wide-layer kernels).  Device-side building blocks: mz_mlp_device.h.
 #include <algorithm>
 #include <cstring>
 
@@ -29,6 +30,30 @@ __global__ void k_pack_layer(const float *__restrict__ W, int ldw, const float *
         b_out[n] = (bias != nullptr && n < N) ? bias[n] : 0.0f;
 }
 
+// Matrix layers: tile (nt, c) = two planes of 64 x 16 bytes (value, scaled residual; see mz_mlp_device.h),
+// lane l = 16 kq + i holding W[16 nt + i][32 c + 8 kq .. +7].  One lane operand per thread.
+__global__ void k_pack_layer_split(const float *__restrict__ W, int ldw, const float *__restrict__ bias, int K, int N,
+                                   int KC, int Np, float *__restrict__ w_out, float *__restrict__ b_out) {
+    const long long total = (long long)(Np >> 4) * KC * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long long tile = i >> 6;
+        const int c = (int)(tile % KC), nt = (int)(tile / KC);
+        const int n = nt * 16 + (lane & 15);
+        const int k0 = 32 * c + 8 * (lane >> 4);
+        float v[8];
+        for (int e = 0; e < 8; ++e) v[e] = (n < N && k0 + e < K) ? W[(size_t)n * ldw + k0 + e] : 0.0f;
+        f32x4 hi, lo;
+        split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+        f32x4 *out = reinterpret_cast<f32x4 *>(w_out) + tile * 128 + lane;
+        out[0] = hi;
+        out[64] = lo;
+    }
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < Np; n += gridDim.x * blockDim.x)
+        b_out[n] = (bias != nullptr && n < N) ? bias[n] : 0.0f;
+}
+
 // table[a][n] = merge_bias[n] + sum_k merge_weight[n][D + k] * embedding[a][k]
 __global__ void k_action_table(const float *__restrict__ emb, const float *__restrict__ Wm,
                                const float *__restrict__ bm, int D, int Dp, int A, float *__restrict__ table) {
@@ -52,15 +77,16 @@ k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__re
     extern __shared__ __align__(16) float smem[];
     constexpr int TM = 16 * MT;
     const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
-    lds_f *X = to_lds(smem), *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
+    lds_f *X = to_lds(smem) + kLdsReserve, *Xs = X + TM * ld_in, *bufA = Xs + TM * ld_in, *bufB = bufA + TM * ld_w;
     const int row0 = blockIdx.x * TM;
     const int rows = min(TM, B - row0);
-    load_rows(X, ld_in, TM, rows, M.in_features, [&](int r) -> const float * {
+    load_rows_split(X, Xs, ld_in, MT, rows, M.in_features, [&](int r) -> const float * {
         long long src = x_rows ? (long long)x_rows[row0 + r] : (long long)(row0 + r);
         return src < 0 ? nullptr : x + src * ldx;
     });
     int ld_out;
-    lds_f *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    Team all = whole_workgroup();
+    lds_f *out = mlp_tile<MT>(all, M, 0, blob, Xs, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
     // policy heads: the first maximum of each row, then `softmax_times` more softmax passes
     // (src/search/simulation.py:35, src/search/expansion.py:30) before the store
@@ -97,17 +123,18 @@ __device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const f
                                                  float *smem) {
     constexpr int TM = 16 * MT;
     const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
-    lds_f *X = to_lds(smem), *bufA = X + TM * ld_in, *bufB = bufA + TM * ld_w;
+    lds_f *X = to_lds(smem) + kLdsReserve, *Xs = X + TM * ld_in, *bufA = Xs + TM * ld_in, *bufB = bufA + TM * ld_w;
     const int rows = min(TM, J.B - row0);
     const float *x = J.x;
     const int32_t *x_rows = J.x_rows;
     const long long ldx = J.ldx;
-    load_rows(X, ld_in, TM, rows, M.in_features, [&](int r) -> const float * {
+    load_rows_split(X, Xs, ld_in, MT, rows, M.in_features, [&](int r) -> const float * {
         long long src = x_rows ? (long long)x_rows[row0 + r] : (long long)(row0 + r);
         return src < 0 ? nullptr : x + src * ldx;
     });
     int ld_out;
-    lds_f *out = mlp_tile<MT>(M, blob, X, ld_in, bufA, bufB, &ld_out);
+    Team all = whole_workgroup();
+    lds_f *out = mlp_tile<MT>(all, M, 0, blob, Xs, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
     float *y = J.y;
     const long long ldy = J.ldy;
@@ -137,7 +164,8 @@ k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__rest
     extern __shared__ __align__(16) float smem[];
     constexpr int TM = 16 * MT;
     const int ld_d = lds_stride(P.D), ld_w = lds_stride(P.reward.max_width);
-    lds_f *X = to_lds(smem), *C = X + TM * ld_d, *bufA = C + TM * ld_d, *bufB = bufA + TM * ld_w;
+    // X: the latents as fp32 rows, later the next latents (fp32 rows); Xs / Cs: their split images
+    lds_f *X = to_lds(smem) + kLdsReserve, *Xs = X + TM * ld_d, *Cs = Xs + TM * ld_d, *bufA = Cs + TM * ld_d, *bufB = bufA + TM * ld_w;
     lds_f *table = bufB + TM * ld_w;  // [A][Dp] per-action additive table of the merge layer
     lds_i *sel = (lds_i *)(table + P.A * P.Dp);
     const int row0 = blockIdx.x * TM;
@@ -149,22 +177,30 @@ k_dynamics(mz_packed_nets P, const float *__restrict__ blob, const float *__rest
         if ((int)threadIdx.x < rows) a = action ? action[r] : (r % P.A);
         sel[threadIdx.x] = min(max(a, 0), P.A - 1);
     }
-    load_rows(X, ld_d, TM, rows, P.D, [&](int r) -> const float * {
+    load_rows_split(X, Xs, ld_d, MT, rows, P.D, [&](int r) -> const float * {
         long long src = latent_rows ? (long long)latent_rows[row0 + r] : (long long)(row0 + r);
         return src < 0 ? nullptr : latent + src * ld_latent;
     });
-    // next = relu(W[:, :D] x + (W[:, D:] e_a + b))
-    dense_tile<MT>(X, ld_d, blob, P.merge.layer[0], C, ld_d, table, P.Dp, sel);
+    // next = relu(W[:, :D] x + (W[:, D:] e_a + b)): as fp32 rows over X (for the store and a narrow reward
+    // layer) and as the image the reward head's first matrix layer reads
+    Team all = whole_workgroup();
+    {
+        const mz_packed_layer Lm = P.merge.layer[0];
+        DensePart part = make_part(Lm, X, ld_d, Lm.act, false, table, P.Dp, sel);
+        part.Ss = Cs;
+        dense_group1<MT>(Xs, ld_d, blob, Lm.Kp, part, all);
+        __syncthreads();
+    }
     if (next_latent) {
         for (int i = threadIdx.x; i < rows * P.D; i += kThreads) {
             const int r = i / P.D, c = i - r * P.D;
             long long dst = next_rows ? (long long)next_rows[row0 + r] : (long long)(row0 + r);
-            if (dst >= 0) next_latent[dst * ld_next + c] = C[r * ld_d + c];
+            if (dst >= 0) next_latent[dst * ld_next + c] = X[r * ld_d + c];
         }
     }
     if (reward) {
         int ld_out;
-        const lds_f *out = mlp_tile<MT>(P.reward, blob, C, ld_d, bufA, bufB, &ld_out);
+        const lds_f *out = mlp_tile<MT>(all, P.reward, 0, blob, Cs, X, ld_d, bufA, bufB, &ld_out);
         if ((int)threadIdx.x < rows) reward[row0 + threadIdx.x] = out[threadIdx.x * ld_out];
     }
 }
@@ -178,16 +214,17 @@ k_prediction(mz_packed_nets P, const float *__restrict__ blob, const float *__re
     constexpr int TM = 16 * MT;
     const int ld_d = lds_stride(P.D);
     const int ld_w = lds_stride(max(P.value.max_width, P.policy.max_width));
-    lds_f *X = to_lds(smem), *bufA = X + TM * ld_d, *bufB = bufA + TM * ld_w;
+    lds_f *X = to_lds(smem) + kLdsReserve, *Xs = X + TM * ld_d, *bufA = Xs + TM * ld_d, *bufB = bufA + TM * ld_w;
     const int row0 = blockIdx.x * TM;
     const int rows = min(TM, B - row0);
-    load_rows(X, ld_d, TM, rows, P.D, [&](int r) -> const float * {
+    load_rows_split(X, Xs, ld_d, MT, rows, P.D, [&](int r) -> const float * {
         long long src = latent_rows ? (long long)latent_rows[row0 + r] : (long long)(row0 + r);
         return src < 0 ? nullptr : latent + src * ld_latent;
     });
     int ld_out;
+    Team all = whole_workgroup();
     if (policy || argmax) {
-        lds_f *out = mlp_tile<MT>(P.policy, blob, X, ld_d, bufA, bufB, &ld_out);
+        lds_f *out = mlp_tile<MT>(all, P.policy, 0, blob, Xs, X, ld_d, bufA, bufB, &ld_out);
         if (argmax && (int)threadIdx.x < rows) {
             const lds_f *p = out + threadIdx.x * ld_out;
             int best = 0;
@@ -208,7 +245,7 @@ k_prediction(mz_packed_nets P, const float *__restrict__ blob, const float *__re
         __syncthreads();
     }
     if (value) {
-        const lds_f *out = mlp_tile<MT>(P.value, blob, X, ld_d, bufA, bufB, &ld_out);
+        const lds_f *out = mlp_tile<MT>(all, P.value, 0, blob, Xs, X, ld_d, bufA, bufB, &ld_out);
         if ((int)threadIdx.x < rows) value[row0 + threadIdx.x] = out[threadIdx.x * ld_out];
     }
 }
@@ -234,11 +271,21 @@ int validate_mlp(const mz_mlp *m, const char *what) {
 
 int pack_layer(const mz_dense &d, const mz_packed_layer &L, float *blob, hipStream_t st) {
     const long long total = (long long)L.Np * L.Kp;
+    if (L.fmt != 0) {
+        const int nb = (int)std::min<long long>((total / 8 + 255) / 256 + 1, 4096);
+        hipLaunchKernelGGL(k_pack_layer_split, dim3(nb), dim3(256), 0, st, d.weight, d.ldw > 0 ? d.ldw : d.in_features, d.bias,
+                           L.K, L.N, L.Kp >> 5, L.Np, blob + L.w_off, blob + L.b_off);
+        return mz::check_launch("k_pack_layer_split");
+    }
     const int nb = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(k_pack_layer, dim3(nb), dim3(256), 0, st, d.weight, d.ldw > 0 ? d.ldw : d.in_features, d.bias,
                        L.K, L.N, L.Kp, L.Np, blob + L.w_off, blob + L.b_off);
     return mz::check_launch("k_pack_layer");
 }
+
+// Packed layout of an MLP; `all_matrix`: every layer in the matrix form whatever its width (the merge layer,
+// which the kernels always evaluate on the matrix cores).
+int64_t plan_mlp(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out, bool all_matrix);
 
 constexpr size_t kMaxLds = 160 * 1024;
 
@@ -262,6 +309,7 @@ template <typename Launch1, typename Launch2>
 int launch_by_rows(int B, size_t lds_per_row_floats, size_t extra_bytes, Launch1 &&l1, Launch2 &&l2) {
     // 32-row tiles halve the weight traffic per row; 16-row tiles keep all 256 CUs busy when
     // the batch is small.
+    extra_bytes += kLdsReserve * sizeof(float);
     int mt = (B >= mt2_min_rows()) ? 2 : 1;
     if ((size_t)mt * 16 * lds_per_row_floats * sizeof(float) + extra_bytes > kMaxLds) mt = 1;
     size_t lds = (size_t)mt * 16 * lds_per_row_floats * sizeof(float) + extra_bytes;
@@ -275,7 +323,12 @@ extern "C" {
 
 constexpr int64_t kPackedSlackFloats = 1024;
 
-int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out) {
+int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out) { return plan_mlp(h_mlp, base_off, h_out, false); }
+
+}  // extern "C"
+
+namespace {
+int64_t plan_mlp(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out, bool all_matrix) {
     if (validate_mlp(h_mlp, "mz_mlp_plan") != MZ_OK) return MZ_ERR_ARG;
     if (!h_out || base_off < 0 || (base_off & 3))
         return mz::fail(MZ_ERR_ARG, "mz_mlp_plan: h_out is NULL or base_off is not a non-negative multiple of 4");
@@ -289,7 +342,8 @@ int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out)
         mz_packed_layer &L = h_out->layer[i];
         L.K = d.in_features;
         L.N = d.out_features;
-        L.Kp = ceil16(L.K);
+        L.fmt = (all_matrix || L.N > 8) ? 1 : 0;
+        L.Kp = L.fmt ? ceil32(L.K) : ceil16(L.K);
         L.Np = ceil16(L.N);
         L.act = d.activation;
         L.w_off = off;
@@ -303,6 +357,9 @@ int64_t mz_mlp_plan(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out)
     off += kPackedSlackFloats;
     return off - base_off;
 }
+}  // namespace
+
+extern "C" {
 
 int mz_mlp_pack(const mz_mlp *h_mlp, const mz_packed_mlp *h_plan, float *blob, void *stream) {
     MZ_TRY(validate_mlp(h_mlp, "mz_mlp_pack"));
@@ -321,7 +378,7 @@ int mz_mlp_forward_post(const mz_packed_mlp *h_plan, const float *blob, const fl
                         "the row width");
     if (B == 0) return MZ_OK;
     hipStream_t st = (hipStream_t)stream;
-    size_t per_row = (size_t)lds_stride(h_plan->in_features) + 2 * (size_t)lds_stride(h_plan->max_width);
+    size_t per_row = 2 * (size_t)lds_stride(h_plan->in_features) + 2 * (size_t)lds_stride(h_plan->max_width);
     return launch_by_rows(
         B, per_row, 0,
         [&](size_t lds) {
@@ -348,13 +405,13 @@ int mz_mlp_forward_pair(const mz_packed_mlp *h_plan0, const float *x0, int64_t l
         MZ_TRY(mz_mlp_forward(h_plan0, blob, x0, ldx0, x_rows0, y0, ldy0, B0, stream));
         return mz_mlp_forward(h_plan1, blob, x1, ldx1, x_rows1, y1, ldy1, B1, stream);
     }
-    auto per_row = [](const mz_packed_mlp *p) { return (size_t)lds_stride(p->in_features) + 2 * (size_t)lds_stride(p->max_width); };
+    auto per_row = [](const mz_packed_mlp *p) { return 2 * (size_t)lds_stride(p->in_features) + 2 * (size_t)lds_stride(p->max_width); };
     // row tile per job as mz_mlp_forward picks it: 32 rows from 8192 rows on (half the weight traffic per row)
     auto tile = [&](const mz_packed_mlp *p, int B) {
-        return (B >= mt2_min_rows() && 32 * per_row(p) * sizeof(float) <= kMaxLds) ? 2 : 1;
+        return (B >= mt2_min_rows() && (32 * per_row(p) + kLdsReserve) * sizeof(float) <= kMaxLds) ? 2 : 1;
     };
     const int mt0 = tile(h_plan0, B0), mt1 = tile(h_plan1, B1);
-    const size_t lds = 16 * std::max(mt0 * per_row(h_plan0), mt1 * per_row(h_plan1)) * sizeof(float);
+    const size_t lds = (16 * std::max(mt0 * per_row(h_plan0), mt1 * per_row(h_plan1)) + kLdsReserve) * sizeof(float);
     if (lds > kMaxLds) return mz::fail(MZ_ERR_ARG, "network too wide: needs %zu bytes of LDS per tile", lds);
     const int blocks0 = (B0 + 16 * mt0 - 1) / (16 * mt0), blocks1 = (B1 + 16 * mt1 - 1) / (16 * mt1);
     auto launch = [&](auto kernel) -> int {
@@ -444,7 +501,7 @@ int mz_nets_plan(const mz_dynamics_net *h_dyn, const mz_prediction_net *h_pred, 
     merge.n_layers = 1;
     merge.layer[0] = mz_dense{h_dyn->merge_weight, nullptr, D, D, MZ_ACT_RELU, 2 * D};
     int64_t off = 0, n;
-    if ((n = mz_mlp_plan(&merge, off, &h_out->merge)) < 0) return (int)n;
+    if ((n = plan_mlp(&merge, off, &h_out->merge, true)) < 0) return (int)n;
     off += n;
     h_out->action_table_off = off;
     off += (int64_t)A * h_out->Dp;
@@ -482,7 +539,7 @@ int mz_dynamics_forward(const mz_packed_nets *h_plan, const float *blob, const f
         return mz::fail(MZ_ERR_ARG, "mz_dynamics_forward: NULL argument, negative B or row stride below D");
     if (B == 0) return MZ_OK;
     hipStream_t st = (hipStream_t)stream;
-    size_t per_row = 2 * (size_t)lds_stride(h_plan->D) + 2 * (size_t)lds_stride(h_plan->reward.max_width);
+    size_t per_row = 3 * (size_t)lds_stride(h_plan->D) + 2 * (size_t)lds_stride(h_plan->reward.max_width);
     return launch_by_rows(
         B, per_row, 32 * sizeof(int) + sizeof(float) * (size_t)h_plan->A * h_plan->Dp,
         [&](size_t lds) {
@@ -508,7 +565,7 @@ int mz_prediction_forward(const mz_packed_nets *h_plan, const float *blob, const
         return mz::fail(MZ_ERR_ARG, "mz_prediction_forward: NULL argument, negative B or row stride below D");
     if (B == 0 || (!policy && !value && !argmax)) return MZ_OK;
     hipStream_t st = (hipStream_t)stream;
-    size_t per_row = (size_t)lds_stride(h_plan->D) +
+    size_t per_row = 2 * (size_t)lds_stride(h_plan->D) +
                      2 * (size_t)lds_stride(std::max(h_plan->value.max_width, h_plan->policy.max_width));
     return launch_by_rows(
         B, per_row, 0,

@@ -1,63 +1,78 @@
-// Device-side building blocks of the fused fp32 MLP kernels (gfx950).
+// Device-side building blocks of the fused MLP kernels (gfx950).
 //
 // A workgroup of kWaves wavefronts owns a tile of 16*MT rows whose activations live in LDS;
-// one dense layer is   Y[rows][N] = act(X[rows][K] * W^T + b)   on v_mfma_f32_16x16x4_f32
-// (exact fp32 multiply-add chains, so results differ from another fp32 GEMM only by
-// summation order).
+// one dense layer is   Y[rows][N] = act(X[rows][K] * W^T + b).
 //
-// Weights are re-tiled once per weight update ("packed"): for a layer with K inputs and N
-// outputs, Kp = ceil16(K), Np = ceil16(N), tile (nt, kt) is 64 float4:
-//     lane l, element j  =  W[nt*16 + (l & 15)][kt*16 + 4*(l >> 4) + j]      (0 outside W)
-// so a wavefront fetches the B operands of four consecutive MFMA k-steps with one fully
-// coalesced 1 KiB global_load_dwordx4, and the matching A operands with one ds_read_b128 per
-// 16-row tile.  Lane l of MFMA k-step j then multiplies X[row l&15][kt*16 + 4*(l>>4) + j]
-// by W[col l&15][same k]: both operands agree on k, which is all the instruction needs.
+// Arithmetic.  gfx950's fp32 matrix instruction runs at 1/16 of the fp16 rate, so the products
+// run on v_mfma_f32_16x16x32_f16 with every fp32 operand v held as TWO fp16 values
+//     hi = fp16(v),   lo = fp16((v - hi) * 2^11)            (v = hi + lo * 2^-11 to 2^-22 |v|)
+// and a product x*w formed as   hi_x*hi_w  +  2^-11 * (hi_x*lo_w + lo_x*hi_w):  three matrix
+// instructions per 16x16x32 block instead of eight fp32 ones, the same 4 bytes per weight, fp32
+// accumulation in two accumulators (the cross terms keep their 2^11 scale until the epilogue, so
+// neither small activations nor small weights fall into fp16's subnormal range).  The dropped
+// lo*lo term is 2^-22 of the product: outputs agree with an fp32 evaluation to a few 1e-7 of
+// their scale.  Operands must stay below 65504 in magnitude (fp16's range): beyond it the
+// conversion gives infinity and the results are NaN -- loud, not silently wrong.
+//
+// The product is formed transposed -- the weight tile is the A operand (16 output columns x 32 k),
+// the activations the B operand (32 k x 16 rows) -- so a lane's four accumulator values are four
+// CONSECUTIVE output columns of one row: the epilogue hands them to the next layer (whose k index
+// they are) as one 8-byte store per plane.
+//
+// Activations feeding a matrix layer are kept in LDS as its operand image ("split image"): per
+// 16-row tile and per 32-wide k-chunk c two 1 KiB planes (hi, then all lo planes behind all hi
+// planes), lane l = 16*kq + m holding row m, k = 32c + 8kq .. +7 as 16 bytes at l*16 -- a wave
+// reads an operand with one conflict-free ds_read_b128.  Activations feeding a narrow layer
+// (N <= 8: scalar heads, policy logits; evaluated on the vector ALU in plain fp32) and the values
+// other code reads (merge pre-activations, logits) stay fp32 rows [16*MT][ld].  Both forms of a
+// buffer of width W fit 16*MT*lds_stride(W) floats.
+//
+// Weights are re-tiled once per weight update ("packed", mz_mlp.hip).  Matrix layers (fmt 1):
+// Kp = ceil32(K), Np = ceil16(N); tile (nt, c) is two 1 KiB planes, lane l = 16*kq + i holding
+// W[16nt + i][32c + 8kq .. +7], so a wave fetches an A operand with one coalesced
+// global_load_dwordx4 per plane.  Narrow layers (fmt 0) keep fp32 tiles (see PackedNarrowWeights).
 // Bias is stored padded to Np behind the tiles.
 //
-// The row tile is small (16..112 rows) and every weight is used once per workgroup, so this
-// is the "GEMV-like" regime: weights go straight from L2 to registers (no LDS staging),
-// kPrefetch k-steps ahead, a wave keeps two column tiles in flight so that the MFMA pipe
-// always has an independent accumulator to issue into, and the weight stream of a wave runs
-// on across its consecutive tiles.  On gfx950 an f32 MFMA and vector-ALU instructions of the
-// same SIMD do not execute concurrently (measured: a wave of independent v_fma makes no
-// progress while another wave issues v_mfma_f32_16x16x4_f32 back to back), so every vector
-// instruction in these routines is paid for in MFMA time: operands are formed with as few of
-// them as possible, addresses stay scalar, and the epilogues are branch-free.
+// The row tile is small (16..112 rows) and every weight is used once per workgroup, so this is
+// the "GEMV-like" regime: weights go straight from L2 to registers (no LDS staging), a batch of
+// k-chunks ahead of the matrix instructions that consume them, and the weight stream of a wave
+// runs on across its consecutive tiles.  With the fp16 forms the matrix time is a fraction of
+// the time the weight stream needs from L2; the routines are organised around keeping that
+// stream busy.
 //
-// The layer functions are deliberately NOT inlined into their callers: each gets its own
-// register allocation (the fused search kernel calls them ~15 times per simulation round and
-// would otherwise spill).  LDS operands are passed as address-space-3 pointers so that the
-// out-of-line code still uses ds_read/ds_write rather than flat accesses.
+// The layer functions are NOT inlined into their callers by default: each gets its own register
+// allocation (the fused search kernel calls them ~15 times per simulation round).  LDS operands
+// are passed as address-space-3 pointers so that the out-of-line code still uses ds_read/ds_write
+// rather than flat accesses.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "muzero_hip.h"
-
-#ifdef MZ_EXP_TIMELINE
-// diagnostic: per-wave time stamps of the most recent dense call, slot-indexed
-__shared__ unsigned long long mz_tl[8][16];
-#define MZ_TL(slot) if ((threadIdx.x & 63) == 0) mz_tl[threadIdx.x >> 6][slot] = clock64();
-#else
-#define MZ_TL(slot)
-#endif
 
 namespace mzd {
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 #ifndef MZ_PREFETCH
-#define MZ_PREFETCH 4
+#define MZ_PREFETCH 2
 #endif
-constexpr int kPrefetch = MZ_PREFETCH;  // k-steps of weights held in registers ahead of the MFMAs
+constexpr int kPrefetch = MZ_PREFETCH;  // k-chunks of weights per batch held in registers ahead of the MFMAs
 #ifndef MZ_WEIGHT_SETS
 #define MZ_WEIGHT_SETS 2
 #endif
-constexpr int kWeightSets = MZ_WEIGHT_SETS;  // register sets of such batches a wave rotates through (short row tiles)
+constexpr int kWeightSets = MZ_WEIGHT_SETS;  // register sets of such batches a wave rotates through
+#ifndef MZ_DENSE_CALL
+#define MZ_DENSE_CALL __noinline__
+#endif
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
 typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(3))) int lds_i;
 typedef __attribute__((address_space(3))) f32x4 lds_f4;
+typedef __attribute__((address_space(3))) f32x2 lds_f2;
 typedef __attribute__((address_space(1))) const float glb_f;    // read-only global memory (weights)
 typedef __attribute__((address_space(1))) const f32x4 glb_f4;
 
@@ -65,9 +80,18 @@ __device__ __forceinline__ lds_f *to_lds(void *generic) { return (lds_f *)generi
 __device__ __forceinline__ lds_i *to_lds_i(void *generic) { return (lds_i *)generic; }
 
 __host__ __device__ inline int ceil16(int x) { return (x + 15) & ~15; }
-// LDS row stride (floats) for a buffer holding rows of `width` valid floats: padded to a
-// multiple of 16 (so a K-loop may read whole 16-float chunks) plus 4 floats of skew.
-__host__ __device__ inline int lds_stride(int width) { return ceil16(width) + 4; }
+__host__ __device__ inline int ceil32(int x) { return (x + 31) & ~31; }
+// LDS row stride (floats) of a buffer holding rows of `width` valid floats: padded to a multiple of
+// 32 (whole k-chunks) plus 4 floats of skew.  16 rows of it also hold the split image of the tile.
+__host__ __device__ inline int lds_stride(int width) { return ceil32(width) + 4; }
+// LDS offset 0 compares equal to the null pointer of the LDS address space, and optional buffers are
+// passed as NULL: the kernels leave the first kLdsReserve floats of their dynamic LDS unused.
+constexpr int kLdsReserve = 4;
+// Floats of one plane of one k-chunk of a 16-row split image (64 lanes x 16 bytes).
+constexpr int kChunkFloats = 256;
+
+constexpr float kLoScale = 2048.0f;          // 2^11: scale of the lo plane
+constexpr float kLoUnscale = 1.0f / 2048.0f;
 
 __device__ __forceinline__ float activate(float v, int act) {
     switch (act) {
@@ -76,6 +100,30 @@ __device__ __forceinline__ float activate(float v, int act) {
         case MZ_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         default: return v;
     }
+}
+
+// v -> (hi, lo) as above.  Exact rounding steps (no contraction): every kernel splits alike.
+__device__ __forceinline__ void split1(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)__fmul_rn(__fsub_rn(v, (float)hi), kLoScale);
+}
+// Four consecutive k of one row -> 8 bytes of the hi plane and 8 bytes of the lo plane.
+__device__ __forceinline__ void split4(const f32x4 &v, f32x2 &hi, f32x2 &lo) {
+    _Float16 a[4], b[4];
+    split1(v.x, a[0], b[0]);
+    split1(v.y, a[1], b[1]);
+    split1(v.z, a[2], b[2]);
+    split1(v.w, a[3], b[3]);
+    hi = __builtin_bit_cast(f32x2, h4{a[0], a[1], a[2], a[3]});
+    lo = __builtin_bit_cast(f32x2, h4{b[0], b[1], b[2], b[3]});
+}
+// Eight consecutive k of one row (one lane's operand) -> 16 bytes per plane.
+__device__ __forceinline__ void split8(const f32x4 &v0, const f32x4 &v1, f32x4 &hi, f32x4 &lo) {
+    f32x2 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    hi = f32x4{h0.x, h0.y, h1.x, h1.y};
+    lo = f32x4{l0.x, l0.y, l1.x, l1.y};
 }
 
 // Wave-uniform values arrive in vector registers when a function is not inlined (arguments
@@ -129,176 +177,114 @@ struct Team {
 };
 __device__ __forceinline__ Team whole_workgroup() { return Team{0, kWaves, nullptr, 0}; }
 
-// One output of a group of layers that read the same input rows (passed by value).
+// One output of a group of matrix layers that read the same input rows (passed by value).
+// The output goes to Ys as fp32 rows (row stride ldy) and / or to Ss as a split image (tile
+// stride s_tile floats, s_kc = ceil32(N) / 32 chunks per plane); either may be NULL.
 struct DensePart {
     int w_off, b_off;  // float offsets of the packed tiles / padded bias inside the blob
     int N, Np, act;
     lds_f *Ys;
     int ldy;
+    lds_f *Ss;
+    int s_tile, s_kc;
     const lds_f *row_add;  // optional additive table in LDS, indexed [row_sel[row]][col]
     int row_add_ld;
     const lds_i *row_sel;
     // Optional folded scalar layer: instead of storing Y, the epilogue multiplies act(Y) by the
-    // weights of a following one-output layer (packed tiles at dot_w_off) and leaves the sum
+    // weights of a following one-output layer (fp32 tiles at dot_w_off) and leaves the sum
     // over this tile's 16 columns in dot_out[tile][row] (row stride 16*MT); finish_dot() adds
     // the tiles.  dot_w_off < 0: plain layer.
     int dot_w_off;
     lds_f *dot_out;
     __device__ __forceinline__ DensePart uniform() const {
-        return DensePart{uni(w_off), uni(b_off), uni(N), uni(Np), uni(act), uni_lds(Ys), uni(ldy),
-                         uni_lds(row_add), uni(row_add_ld), uni_lds(row_sel), uni(dot_w_off), uni_lds(dot_out)};
+        return DensePart{uni(w_off), uni(b_off), uni(N), uni(Np), uni(act), uni_lds(Ys), uni(ldy), uni_lds(Ss), uni(s_tile),
+                         uni(s_kc), uni_lds(row_add), uni(row_add_ld), uni_lds(row_sel), uni(dot_w_off), uni_lds(dot_out)};
     }
 };
-__device__ __forceinline__ DensePart make_part(const mz_packed_layer &L, lds_f *Ys, int ldy, int act,
+// Output as fp32 rows in Ys (split = false) or as a split image in the same memory (split = true).
+__device__ __forceinline__ DensePart make_part(const mz_packed_layer &L, lds_f *Ys, int ldy, int act, bool split = false,
                                                const lds_f *row_add = nullptr, int row_add_ld = 0,
                                                const lds_i *row_sel = nullptr) {
-    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, act, Ys, ldy, row_add, row_add_ld, row_sel, -1, nullptr};
+    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, act, split ? nullptr : Ys, ldy, split ? Ys : nullptr, 16 * ldy,
+                     ceil32(L.N) >> 5, row_add, row_add_ld, row_sel, -1, nullptr};
 }
 // Layer L followed by the one-output layer L1, folded (see DensePart::dot_out).
 __device__ __forceinline__ DensePart make_dot_part(const mz_packed_layer &L, const mz_packed_layer &L1, lds_f *dot_out) {
-    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, L.act, nullptr, 0, nullptr, 0, nullptr, (int)L1.w_off, dot_out};
-}
-// Sum over the 16 lanes of a DPP row (every lane receives it; the association is fixed).
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f32<0x141>(v);  // row_half_mirror
-    v += dpp_f32<0x140>(v);  // row_mirror
-    return v;
+    return DensePart{(int)L.w_off, (int)L.b_off, L.N, L.Np, L.act, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, (int)L1.w_off, dot_out};
 }
 
-// Epilogue of one 16-column tile: bias, optional per-row additive table, activation, store.
-// C layout of the MFMA: column = lane & 15, row = 4*(lane >> 4) + reg.
+// Epilogue of one 16-column tile.  C layout of the transposed product: row = lane & 15, columns
+// 16 nt + 4 (lane >> 4) + r for the lane's four values r.
 template <int MT>
-__device__ __forceinline__ void store_tile(const f32x4 (&acc)[MT], int nt, float b, const DensePart &P, glb_f *packed_f) {
+__device__ __forceinline__ void store_tile(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, const DensePart &P,
+                                           glb_f *packed_f) {
     const int lane = threadIdx.x & 63;
-    const int m = lane & 15, kq = lane >> 4;
-    const int col = nt * 16 + m;
-    const bool real_col = col < P.N;
-    if (P.dot_w_off >= 0) {
-        // weight of column `col` in the packed one-output layer: tile kt = nt, row 0 of the
-        // tile lives in lanes 16*q, element j, with col = 16*nt + 4*q + j
-        const float w2 = real_col ? packed_f[P.dot_w_off + (nt * 64 + 16 * (m >> 2)) * 4 + (m & 3)] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float h = real_col ? activate(acc[mt][r] + b, P.act) : 0.0f;
-                // __fmul_rn: never contracted into the following add, whatever the file's
-                // -ffp-contract setting, so every kernel forms the same sums
-                const float sum = row16_sum(__fmul_rn(h, w2));
-                if (m == 0) P.dot_out[nt * (16 * MT) + mt * 16 + kq * 4 + r] = sum;
-            }
-        }
-        return;
-    }
-    // the common cases (plain relu / identity layers) take a branch-free path; the branches
-    // here are wave-uniform
-    if (P.row_add == nullptr && (P.act == MZ_ACT_RELU || P.act == MZ_ACT_NONE)) {
-        // padded columns need no select here: their packed weights and bias are zero, so the
-        // accumulator holds 0 and relu / identity keep it.  Address arithmetic is scalar: one
-        // base per lane, the row step added per store.
-        lds_f *y = P.Ys + (kq * 4) * P.ldy + col;
-        const int step = P.ldy;
-        if (P.act == MZ_ACT_RELU) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[mt][r] + b;
-                    y[(mt * 16 + r) * step] = v > 0.0f ? v : 0.0f;  // activate(): NaN -> 0
-                }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[(mt * 16 + r) * step] = acc[mt][r] + b;
-        }
-        return;
-    }
+    const int j = lane & 15, rq = lane >> 4;
+    const int col0 = nt * 16 + 4 * rq;
+    const bool plain = P.act == MZ_ACT_RELU || P.act == MZ_ACT_NONE;  // act(0) = 0: padded columns need no select
+    f32x4 w2 = {0.f, 0.f, 0.f, 0.f};
+    if (P.dot_w_off >= 0)  // weights of columns col0 .. col0+3 in the fp32 tiles of the one-output layer (zero beyond N)
+        w2 = *(glb_f4 *)(packed_f + P.dot_w_off + (nt * 64 + 16 * rq) * 4);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + kq * 4 + r;
-            float v = acc[mt][r] + b;
-            if (P.row_add != nullptr && real_col) v += P.row_add[P.row_sel[row] * P.row_add_ld + col];
-            P.Ys[row * P.ldy + col] = real_col ? activate(v, P.act) : 0.0f;
+        const int row = mt * 16 + j;
+        f32x4 v;
+        // the cross terms leave their 2^11 scale here (exact), then bias
+        v.x = (hi[mt].x + __fmul_rn(lo[mt].x, kLoUnscale)) + b.x;
+        v.y = (hi[mt].y + __fmul_rn(lo[mt].y, kLoUnscale)) + b.y;
+        v.z = (hi[mt].z + __fmul_rn(lo[mt].z, kLoUnscale)) + b.z;
+        v.w = (hi[mt].w + __fmul_rn(lo[mt].w, kLoUnscale)) + b.w;
+        if (P.row_add != nullptr) {
+            const f32x4 t = *reinterpret_cast<const lds_f4 *>(P.row_add + P.row_sel[row] * P.row_add_ld + col0);
+            v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+        }
+        if (plain) {
+            if (P.act == MZ_ACT_RELU) {  // as activate(): NaN -> 0
+                v.x = v.x > 0.0f ? v.x : 0.0f;
+                v.y = v.y > 0.0f ? v.y : 0.0f;
+                v.z = v.z > 0.0f ? v.z : 0.0f;
+                v.w = v.w > 0.0f ? v.w : 0.0f;
+            }
+            if (P.row_add != nullptr) {  // the table may be non-zero in padded columns
+                v.x = col0 + 0 < P.N ? v.x : 0.0f;
+                v.y = col0 + 1 < P.N ? v.y : 0.0f;
+                v.z = col0 + 2 < P.N ? v.z : 0.0f;
+                v.w = col0 + 3 < P.N ? v.w : 0.0f;
+            }
+        } else {
+            v.x = col0 + 0 < P.N ? activate(v.x, P.act) : 0.0f;
+            v.y = col0 + 1 < P.N ? activate(v.y, P.act) : 0.0f;
+            v.z = col0 + 2 < P.N ? activate(v.z, P.act) : 0.0f;
+            v.w = col0 + 3 < P.N ? activate(v.w, P.act) : 0.0f;
+        }
+        if (P.dot_w_off >= 0) {
+            // __fmul_rn: never contracted into the following add, whatever the file's
+            // -ffp-contract setting, so every kernel forms the same sums
+            float s = __fmul_rn(v.x, w2.x);
+            s += __fmul_rn(v.y, w2.y);
+            s += __fmul_rn(v.z, w2.z);
+            s += __fmul_rn(v.w, w2.w);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (rq == 0) P.dot_out[nt * (16 * MT) + row] = s;
+            continue;
+        }
+        if (P.Ys != nullptr) *reinterpret_cast<lds_f4 *>(P.Ys + row * P.ldy + col0) = v;
+        if (P.Ss != nullptr) {
+            // columns col0 .. col0+3 are k = 32 c + 8 kq + e .. e+3 of the next layer's operand
+            f32x2 h, l;
+            split4(v, h, l);
+            lds_f *img = P.Ss + mt * P.s_tile + (nt >> 1) * kChunkFloats + (2 * (nt & 1) + (rq >> 1)) * 64 + j * 4 + 2 * (rq & 1);
+            *reinterpret_cast<lds_f2 *>(img) = h;
+            *reinterpret_cast<lds_f2 *>(img + P.s_kc * kChunkFloats) = l;
+            if ((nt & 1) == 0 && nt + 1 == (P.Np >> 4)) {  // an odd number of column tiles: the chunk's upper half is zero
+                const f32x2 z = {0.f, 0.f};
+                *reinterpret_cast<lds_f2 *>(img + 128) = z;
+                *reinterpret_cast<lds_f2 *>(img + 128 + P.s_kc * kChunkFloats) = z;
+            }
         }
     }
 }
-
-// A-operand sources.  X[row 16*mt + m][koff .. koff+3] = form(shared(m, koff), raw(mt, m, koff)):
-// `shared` and `raw` are the LDS reads (shared: common to all row tiles of one k-step), `form`
-// the vector work on them, so a caller can issue every read of a k-step first and form the
-// operands later, between MFMAs.
-struct LdsRows {  // activations resident in LDS
-    const lds_f *x;
-    int ld;
-    static __device__ __forceinline__ LdsRows from(const lds_f *a, int b, const lds_f *, int, const lds_i *) { return LdsRows{a, b}; }
-    __device__ __forceinline__ const lds_i *s4() const { return nullptr; }
-    __device__ __forceinline__ const lds_f *s0() const { return x; }
-    __device__ __forceinline__ int s1() const { return ld; }
-    __device__ __forceinline__ const lds_f *s2() const { return nullptr; }
-    __device__ __forceinline__ int s3() const { return 0; }
-    __device__ __forceinline__ f32x4 shared(int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-    __device__ __forceinline__ f32x4 raw(int mt, int m, int koff) const {
-        return *reinterpret_cast<const lds_f4 *>(x + (mt * 16 + m) * ld + koff);
-    }
-    static __device__ __forceinline__ f32x4 form(const f32x4 &, const f32x4 &r) { return r; }
-};
-__device__ __forceinline__ f32x4 relu_sum(const f32x4 &a, const f32x4 &b) {
-    f32x4 r;
-    r.x = fmaxf(a.x + b.x, 0.f);
-    r.y = fmaxf(a.y + b.y, 0.f);
-    r.z = fmaxf(a.z + b.z, 0.f);
-    r.w = fmaxf(a.w + b.w, 0.f);
-    return r;
-}
-// Rows of the expansion: row (mt = action a, m = tree t) = relu(z[t][:] + table[a][:]), formed
-// on the fly from the merge pre-activation z (LDS, 16 rows) and the per-action table (LDS), so
-// the A*16 child latents never need an LDS image of their own.
-struct ChildRows {
-    const lds_f *z;
-    int ldz;
-    const lds_f *table;
-    int ldt;
-    static __device__ __forceinline__ ChildRows from(const lds_f *a, int b, const lds_f *c, int d, const lds_i *) { return ChildRows{a, b, c, d}; }
-    __device__ __forceinline__ const lds_i *s4() const { return nullptr; }
-    __device__ __forceinline__ const lds_f *s0() const { return z; }
-    __device__ __forceinline__ int s1() const { return ldz; }
-    __device__ __forceinline__ const lds_f *s2() const { return table; }
-    __device__ __forceinline__ int s3() const { return ldt; }
-    __device__ __forceinline__ f32x4 shared(int m, int koff) const { return *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff); }
-    __device__ __forceinline__ f32x4 raw(int mt, int, int koff) const { return *reinterpret_cast<const lds_f4 *>(table + mt * ldt + koff); }
-    static __device__ __forceinline__ f32x4 form(const f32x4 &sh, const f32x4 &r) { return relu_sum(sh, r); }
-};
-
-// Sixteen rows, row m = relu(z[m][:] + table[sel[m]][:]): the child of row m's tree reached by
-// action sel[m], formed on the fly (one row tile only).
-struct PickedRows {
-    const lds_f *z;
-    int ldz;
-    const lds_f *table;
-    int ldt;
-    const lds_i *sel;
-    const lds_f *trow;  // per lane: table row of this lane's A-operand row (lane & 15)
-    static __device__ __forceinline__ PickedRows from(const lds_f *a, int b, const lds_f *c, int d, const lds_i *e) {
-        return PickedRows{a, b, c, d, e, c + e[threadIdx.x & 15] * d};
-    }
-    __device__ __forceinline__ const lds_f *s0() const { return z; }
-    __device__ __forceinline__ int s1() const { return ldz; }
-    __device__ __forceinline__ const lds_f *s2() const { return table; }
-    __device__ __forceinline__ int s3() const { return ldt; }
-    __device__ __forceinline__ const lds_i *s4() const { return sel; }
-    __device__ __forceinline__ f32x4 shared(int m, int koff) const { return *reinterpret_cast<const lds_f4 *>(z + m * ldz + koff); }
-    __device__ __forceinline__ f32x4 raw(int, int, int koff) const { return *reinterpret_cast<const lds_f4 *>(trow + koff); }
-    static __device__ __forceinline__ f32x4 form(const f32x4 &sh, const f32x4 &r) { return relu_sum(sh, r); }
-};
 
 // parts[part] without indexing the array by a run-time value (which would force the array
 // into per-lane stack memory): scalar selects over the compile-time positions instead.
@@ -311,25 +297,26 @@ __device__ __forceinline__ DensePart pick_part(const DensePart (&parts)[NPARTS],
     return r;
 }
 
-// Several dense layers over the SAME input rows in one pass (e.g. the policy head's first
+// Several matrix layers over the SAME input rows in one pass (e.g. the policy head's first
 // layer and the dynamics merge layer both read the latent): their column tiles form one list
 // that is split evenly over the waves, so narrow layers do not leave waves idle and the
 // workgroup pays one barrier for all of them.  All parts must share Kp.
 //
+// xs: split image of the input rows, MT tiles x_tile floats apart, KC chunks per plane.
 // A wave walks its tiles NTW at a time.  The weights of those tiles are consumed as a stream
-// of batches of kPrefetch k-steps; two register sets alternate so that batch i+1 is in flight
-// (global_load_dwordx4, 1 KiB per tile and k-step) while the MFMAs of batch i issue, and the
+// of batches of KP k-chunks; NS register sets rotate so that batch i+1 is in flight
+// (two global_load_dwordx4 of 1 KiB per tile and chunk) while the MFMAs of batch i issue, and the
 // stream runs on from one tile group into the next without draining.  Every loop bound below
 // is wave-uniform (the wave index goes through readfirstlane), so control flow is scalar.
-template <int MT, int NTW, int NPARTS, typename Rows>
-__device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__restrict__ packed,
-                                             const DensePart (&parts)[NPARTS], int KT, int first_tile, int ngroups) {
-    // tall row tiles keep many accumulators and operands: their weight batches are shorter (a
-    // batch still covers >= 100 MFMAs), which keeps the routine out of the callee-saved registers
-    constexpr int KP = MT >= 4 ? 2 : kPrefetch;
+// Per accumulator the instruction sequence is fixed -- chunks ascending; per chunk hi_w*hi_x,
+// then hi_w*lo_x and lo_w*hi_x into the cross-term accumulator -- whatever MT, NTW or the caller:
+// every kernel built on this routine produces the same bits.
+template <int MT, int NTW, int NPARTS>
+__device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC, const float *__restrict__ packed,
+                                             const DensePart (&parts)[NPARTS], int first_tile, int ngroups) {
+    constexpr int KP = MT >= 4 ? 1 : kPrefetch;
     const int lane = threadIdx.x & 63;
-    const int m = lane & 15, kq = lane >> 4;
-    const int nb = (KT + KP - 1) / KP;  // batches per tile group
+    const int nb = (KC + KP - 1) / KP;  // batches per tile group
     const int total = ngroups * nb;
     auto locate = [&](int tl, int &part, int &nt) {
         part = 0;
@@ -351,20 +338,23 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
         for (int t = 0; t < NTW; ++t) {
             int part, nt;
             locate(first_tile + fg * NTW + t, part, nt);
-            fbase[t] = (glb_f4 *)(packed + pick_part(parts, part).w_off) + (size_t)nt * KT * 64;
+            fbase[t] = (glb_f4 *)(packed + pick_part(parts, part).w_off) + (size_t)nt * KC * 128;
         }
     };
     fetch_bases();
-    auto fetch = [&](f32x4 (&w)[NTW][KP]) {
-        const int kt0 = fb * KP;
+    auto fetch = [&](f32x4 (&w)[NTW][KP][2]) {
+        const int kc0 = fb * KP;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            // one scalar base per tile and batch, the k-steps at constant offsets (1 KiB apart):
-            // a group's last batch may read up to KP - 1 k-steps past its tile, i.e. into the next
+            // one scalar base per tile and batch, the planes at constant offsets (1 KiB apart): a
+            // group's last batch may read up to KP - 1 chunks past its tile, i.e. into the next
             // tile or the slack every packed MLP ends with (mz_mlp_plan); those values feed no MFMA
-            glb_f4 *base = fbase[t] + (size_t)kt0 * 64;
+            glb_f4 *base = fbase[t] + (size_t)kc0 * 128;
 #pragma unroll
-            for (int j = 0; j < KP; ++j) w[t][j] = base[j * 64 + lane];
+            for (int k = 0; k < KP; ++k) {
+                w[t][k][0] = base[(2 * k) * 64 + lane];
+                w[t][k][1] = base[(2 * k + 1) * 64 + lane];
+            }
         }
         // The cursor stops at the last batch: fetches past the end of the stream (issued unconditionally, so
         // that every wait below counts an exact number of loads in flight) request that batch once more.
@@ -378,96 +368,90 @@ __device__ __forceinline__ void stream_tiles(const Rows &rows, const float *__re
     };
     // compute cursor
     int cg = 0, cb = 0;
-    f32x4 acc[NTW][MT];
-    float bias[NTW];
+    f32x4 acc_hi[NTW][MT], acc_lo[NTW][MT];
+    f32x4 bias[NTW];
     int c_part[NTW], c_nt[NTW];
-    f32x4 xc[MT];
-    auto compute = [&](const f32x4 (&w)[NTW][KP]) {
-        const int kt0 = cb * KP;
+    f32x4 xh[MT], xl[MT];
+    const lds_f *xlane = xs + lane * 4;
+    const int lo_off = KC * kChunkFloats;
+    auto read_x = [&](int kc, f32x4 (&h)[MT], f32x4 (&l)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const lds_f *p = xlane + mt * x_tile + kc * kChunkFloats;
+            h[mt] = *reinterpret_cast<const lds_f4 *>(p);
+            l[mt] = *reinterpret_cast<const lds_f4 *>(p + lo_off);
+        }
+    };
+    auto compute = [&](const f32x4 (&w)[NTW][KP][2]) {
+        const int kc0 = cb * KP;
         if (cb == 0) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 locate(first_tile + cg * NTW + t, c_part[t], c_nt[t]);
                 // requested now, needed only by the epilogue after the last batch
-                bias[t] = ((glb_f *)packed)[pick_part(parts, c_part[t]).b_off + c_nt[t] * 16 + m];
+                bias[t] = *(glb_f4 *)(packed + pick_part(parts, c_part[t]).b_off + c_nt[t] * 16 + 4 * (lane >> 4));
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < MT; ++mt) acc_hi[t][mt] = acc_lo[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        // The A operands run one k-step ahead of the MFMAs that consume them (xc: current,
-        // xn: next; the sequence wraps to k = 0 at the end of a tile group), so their LDS
-        // latency and, for ChildRows, the vector work forming them hide behind the MFMAs.
+        // The B operands run one chunk ahead of the MFMAs that consume them (xh/xl: current,
+        // nh/nl: next; the sequence wraps to chunk 0 at the end of a tile group), so their LDS
+        // latency hides behind the MFMAs.
 #pragma unroll
-        for (int j = 0; j < KP; ++j) {
-            // steps past the end of K (last batch of a group) skip their MFMAs only; the
+        for (int k = 0; k < KP; ++k) {
+            // chunks past the end of K (last batch of a group) skip their MFMAs only; the
             // operand pipeline advances unconditionally so that it is pure register renaming
-            const bool valid = kt0 + j < KT;
-            const int kn = (kt0 + j + 1 < KT) ? kt0 + j + 1 : 0;
-            // every LDS read of the next k-step is issued before this k-step's MFMAs ...
-            f32x4 xn[MT];
-            const f32x4 sh = rows.shared(m, kn * 16 + 4 * kq);
+            const bool valid = kc0 + k < KC;
+            const int kn = (kc0 + k + 1 < KC) ? kc0 + k + 1 : 0;
+            f32x4 nh[MT], nl[MT];
+            read_x(kn, nh, nl);
+            if (valid) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xn[mt] = rows.raw(mt, m, kn * 16 + 4 * kq);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (valid) {
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].x, w[t][j].x, acc[t][mt], 0, 0, 0);
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].y, w[t][j].y, acc[t][mt], 0, 0, 0);
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].z, w[t][j].z, acc[t][mt], 0, 0, 0);
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[mt].w, w[t][j].w, acc[t][mt], 0, 0, 0);
+                        const h8 wh = __builtin_bit_cast(h8, w[t][k][0]), wl = __builtin_bit_cast(h8, w[t][k][1]);
+                        const h8 ah = __builtin_bit_cast(h8, xh[mt]), al = __builtin_bit_cast(h8, xl[mt]);
+                        acc_hi[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc_hi[t][mt], 0, 0, 0);
+                        acc_lo[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, acc_lo[t][mt], 0, 0, 0);
+                        acc_lo[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, acc_lo[t][mt], 0, 0, 0);
                     }
                 }
-                // ... and formed into operands behind the MFMAs of one row tile each
-                xn[mt] = Rows::form(sh, xn[mt]);
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xc[mt] = xn[mt];
+            for (int mt = 0; mt < MT; ++mt) xh[mt] = nh[mt], xl[mt] = nl[mt];
         }
         if (++cb == nb) {
             cb = 0;
             ++cg;
-            if (cg == ngroups) { MZ_TL(6) }
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                store_tile<MT>(acc[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
-            }
+            for (int t = 0; t < NTW; ++t)
+                store_tile<MT>(acc_hi[t], acc_lo[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
         }
     };
-    // NS register sets rotate: NS - 1 batches are in flight while one is consumed.  Two is the measured
-    // optimum: a third set for the short row tiles (-DMZ_WEIGHT_SETS=3) left the search 1.4 % slower --
-    // the weight stream is bound by what a compute unit gets from L2, not by the latency one wave sees.
-    constexpr int NS = MT >= 4 ? 2 : kWeightSets;
-    f32x4 w[NS][NTW][KP];
-    MZ_TL(1)
+    // NS register sets rotate: NS - 1 batches are in flight while one is consumed.
+    constexpr int NS = kWeightSets;
+    f32x4 w[NS][NTW][KP][2];
     // the weights have the longest way: requested before the operand pipeline is primed
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u) fetch(w[u]);
-    MZ_TL(2)
-    {
-        const f32x4 sh = rows.shared(m, 4 * kq);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xc[mt] = Rows::form(sh, rows.raw(mt, m, 4 * kq));
-    }
+    read_x(0, xh, xl);
     for (int i = 0; i < total; i += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             fetch(w[(u + NS - 1) % NS]);
             if (i + u < total) compute(w[u]);
         }
-        if (i == 0) { MZ_TL(3) }
     }
-    MZ_TL(5)
 }
 
 // Entry points (not inlined: own register allocation).  Kp is shared by all parts.  No
 // trailing barrier.
-template <int MT, int NPARTS, typename Rows>
-__device__ __forceinline__ void dense_group_body(const Rows &rows, const float *packed, int Kp,
+template <int MT, int NPARTS>
+__device__ __forceinline__ void dense_group_body(const lds_f *xs, int x_tile, const float *packed, int Kp,
                                                  const DensePart (&parts)[NPARTS], int wave0, int nwaves) {
     const int wave = uni(threadIdx.x >> 6) - wave0;
-    const int KT = Kp >> 4;
+    const int KC = Kp >> 5;
     int total = 0;
 #pragma unroll
     for (int i = 0; i < NPARTS; ++i) total += parts[i].Np >> 4;
@@ -478,46 +462,48 @@ __device__ __forceinline__ void dense_group_body(const Rows &rows, const float *
     const int first = wave * share + min(wave, extra);
     const int count = share + (wave < extra ? 1 : 0);
     if (count <= 0) return;
-    const int pairs = count >> 1;
-    if (pairs > 0) stream_tiles<MT, 2, NPARTS>(rows, packed, parts, KT, first, pairs);
-    if (count & 1) stream_tiles<MT, 1, NPARTS>(rows, packed, parts, KT, first + 2 * pairs, 1);
+    if constexpr (MT >= 4) {  // tall row tiles: the accumulators and operands of one column tile fill the registers
+        stream_tiles<MT, 1, NPARTS>(xs, x_tile, KC, packed, parts, first, count);
+    } else {
+        const int pairs = count >> 1;
+        if (pairs > 0) stream_tiles<MT, 2, NPARTS>(xs, x_tile, KC, packed, parts, first, pairs);
+        if (count & 1) stream_tiles<MT, 1, NPARTS>(xs, x_tile, KC, packed, parts, first + 2 * pairs, 1);
+    }
 }
 // Out-of-line entry points.  Every argument is a scalar: aggregates would be passed through
 // per-lane stack memory (written 64 times per wave and eventually to HBM), scalars travel in
-// registers.  `Rows` is rebuilt from four scalars (see LdsRows / ChildRows ::from).
-template <int MT, typename Rows>
-__device__ __noinline__ void dense_group1_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const lds_i *r4,
-                                               const float *packed, int Kp, int w_off, int b_off, int N, int Np, int act,
-                                               lds_f *Ys, int ldy, const lds_f *row_add, int row_add_ld,
-                                               const lds_i *row_sel, int dot_w, lds_f *dot_out, int wave0, int nwaves) {
+// registers.
+template <int MT>
+__device__ MZ_DENSE_CALL void dense_group1_impl(const lds_f *xs, int x_tile, const float *packed, int Kp, int w_off, int b_off,
+                                                int N, int Np, int act, lds_f *Ys, int ldy, lds_f *Ss, int s_tile, int s_kc,
+                                                const lds_f *row_add, int row_add_ld, const lds_i *row_sel, int dot_w,
+                                                lds_f *dot_out, int wave0, int nwaves) {
     const DensePart parts[1] = {
-        DensePart{w_off, b_off, N, Np, act, Ys, ldy, row_add, row_add_ld, row_sel, dot_w, dot_out}.uniform()};
-    dense_group_body<MT, 1>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3), uni_lds(r4)), uni_ptr(packed), uni(Kp),
-                            parts, uni(wave0), uni(nwaves));
+        DensePart{w_off, b_off, N, Np, act, Ys, ldy, Ss, s_tile, s_kc, row_add, row_add_ld, row_sel, dot_w, dot_out}.uniform()};
+    dense_group_body<MT, 1>(uni_lds(xs), uni(x_tile), uni_ptr(packed), uni(Kp), parts, uni(wave0), uni(nwaves));
 }
-template <int MT, typename Rows>
-__device__ __noinline__ void dense_group2_impl(const lds_f *r0, int r1, const lds_f *r2, int r3, const lds_i *r4,
-                                               const float *packed, int Kp, int w0, int b0, int N0, int Np0, int act0,
-                                               lds_f *Y0, int ldy0, int dw0, lds_f *do0, int w1, int b1, int N1, int Np1,
-                                               int act1, lds_f *Y1, int ldy1, int dw1, lds_f *do1, int wave0, int nwaves) {
-    const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, nullptr, 0, nullptr, dw0, do0}.uniform(),
-                                DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, nullptr, 0, nullptr, dw1, do1}.uniform()};
-    dense_group_body<MT, 2>(Rows::from(uni_lds(r0), uni(r1), uni_lds(r2), uni(r3), uni_lds(r4)), uni_ptr(packed), uni(Kp),
-                            parts, uni(wave0), uni(nwaves));
+template <int MT>
+__device__ MZ_DENSE_CALL void dense_group2_impl(const lds_f *xs, int x_tile, const float *packed, int Kp, int w0, int b0, int N0,
+                                                int Np0, int act0, lds_f *Y0, int ldy0, lds_f *S0, int st0, int sk0, int dw0,
+                                                lds_f *do0, int w1, int b1, int N1, int Np1, int act1, lds_f *Y1, int ldy1,
+                                                lds_f *S1, int st1, int sk1, int dw1, lds_f *do1, int wave0, int nwaves) {
+    const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, S0, st0, sk0, nullptr, 0, nullptr, dw0, do0}.uniform(),
+                                DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, S1, st1, sk1, nullptr, 0, nullptr, dw1, do1}.uniform()};
+    dense_group_body<MT, 2>(uni_lds(xs), uni(x_tile), uni_ptr(packed), uni(Kp), parts, uni(wave0), uni(nwaves));
 }
-template <int MT, typename Rows>
-__device__ __forceinline__ void dense_group1(const Rows &rows, const float *packed, int Kp, const DensePart &p,
+// xs / ldx: the split image of the input rows in a buffer of row stride ldx (tiles 16 * ldx floats apart).
+template <int MT>
+__device__ __forceinline__ void dense_group1(const lds_f *xs, int ldx, const float *packed, int Kp, const DensePart &p,
                                              const Team &tm = whole_workgroup()) {
-    dense_group1_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), rows.s4(), packed, Kp, p.w_off, p.b_off, p.N,
-                                p.Np, p.act, p.Ys, p.ldy, p.row_add, p.row_add_ld, p.row_sel, p.dot_w_off, p.dot_out,
-                                tm.wave0, tm.nwaves);
+    dense_group1_impl<MT>(xs, 16 * ldx, packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act, p.Ys, p.ldy, p.Ss, p.s_tile, p.s_kc,
+                          p.row_add, p.row_add_ld, p.row_sel, p.dot_w_off, p.dot_out, tm.wave0, tm.nwaves);
 }
-template <int MT, typename Rows>
-__device__ __forceinline__ void dense_group2(const Rows &rows, const float *packed, int Kp, const DensePart &p,
+template <int MT>
+__device__ __forceinline__ void dense_group2(const lds_f *xs, int ldx, const float *packed, int Kp, const DensePart &p,
                                              const DensePart &q, const Team &tm = whole_workgroup()) {
-    dense_group2_impl<MT, Rows>(rows.s0(), rows.s1(), rows.s2(), rows.s3(), rows.s4(), packed, Kp, p.w_off, p.b_off, p.N,
-                                p.Np, p.act, p.Ys, p.ldy, p.dot_w_off, p.dot_out, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys,
-                                q.ldy, q.dot_w_off, q.dot_out, tm.wave0, tm.nwaves);
+    dense_group2_impl<MT>(xs, 16 * ldx, packed, Kp, p.w_off, p.b_off, p.N, p.Np, p.act, p.Ys, p.ldy, p.Ss, p.s_tile, p.s_kc,
+                          p.dot_w_off, p.dot_out, q.w_off, q.b_off, q.N, q.Np, q.act, q.Ys, q.ldy, q.Ss, q.s_tile, q.s_kc,
+                          q.dot_w_off, q.dot_out, tm.wave0, tm.nwaves);
 }
 
 // Second half of a folded scalar layer: out[row * out_ld] = act(bias + sum over the tiles of
@@ -532,7 +518,27 @@ __device__ __forceinline__ void finish_dot(const lds_f *dot, int tiles, int rows
     }
 }
 
-// Weight sources of dense_narrow: chunk q (4 consecutive k) of output column `col`.
+// fp32 rows [16*tiles][ld] -> their split image in `dst` (tile stride 16*ld_dst floats); columns >= valid
+// (a multiple of 4) are taken as zero.  One operand (8 consecutive k of one row) per lane and pass.  No sync.
+__device__ __forceinline__ void rows_to_split(const lds_f *src, int ld, lds_f *dst, int ld_dst, int tiles, int KC, int valid,
+                                              const Team &tm) {
+    const int n = tiles * KC * 64;
+    for (int i = tm.tid(); i < n; i += tm.nthreads()) {
+        const int l = i & 63, c = (i >> 6) % KC, mt = (i >> 6) / KC;
+        const int k0 = 32 * c + 8 * (l >> 4);
+        const lds_f *p = src + (mt * 16 + (l & 15)) * ld + k0;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 hi, lo;
+        split8(k0 < valid ? *reinterpret_cast<const lds_f4 *>(p) : zero, k0 + 4 < valid ? *reinterpret_cast<const lds_f4 *>(p + 4) : zero,
+               hi, lo);
+        lds_f *q = dst + mt * 16 * ld_dst + c * kChunkFloats + l * 4;
+        *reinterpret_cast<lds_f4 *>(q) = hi;
+        *reinterpret_cast<lds_f4 *>(q + KC * kChunkFloats) = lo;
+    }
+}
+
+// Weight sources of dense_narrow: chunk q (4 consecutive k) of output column `col`, from the fp32
+// tiles of a narrow layer: tile kt is 64 float4, lane l, element j = W[l & 15][16 kt + 4 (l >> 4) + j].
 struct PackedNarrowWeights {  // straight from the packed blob in global memory
     const float *wp, *bias;
     static __device__ __forceinline__ PackedNarrowWeights from(const float *w, const float *b, const lds_f *, int, int) {
@@ -554,7 +560,7 @@ struct LdsNarrowWeights {  // compact copy [Kp/4][N] of float4 + 8 bias floats s
 };
 
 // Narrow layers (N <= 8: value/reward scalars, policy logits): a 16-wide MFMA tile would idle
-// all but one wave, so these run on the vector ALU instead.  Four adjacent lanes share one
+// all but one wave, so these run on the vector ALU in plain fp32.  Four adjacent lanes share one
 // output (row, col), each summing a quarter of K as float4 dot products, then a lane
 // exchange adds the quarters.  The summation order is fixed by this function alone, so the
 // result does not depend on where the weights are fetched from.  No trailing barrier.
@@ -614,17 +620,24 @@ __device__ __forceinline__ void stage_narrow(const float *__restrict__ packed, c
     for (int i = threadIdx.x; i < 8; i += blockDim.x) dst[quads * L.N * 4 + i] = (i < L.N) ? packed[L.b_off + i] : 0.0f;
 }
 
-// One dense layer over the workgroup's row tile.  Xs: LDS [16*MT][ldx], columns [K, Kp)
-// must be zero.  Ys: LDS [16*MT][ldy]; columns [N, Np) are written as zero.
+// A layer runs on the matrix cores (reads a split image) or on the vector ALU (reads fp32 rows):
+// decided at pack time (mz_packed_layer::fmt).
+template <typename LayerRef>
+__host__ __device__ inline bool is_matrix_layer(const LayerRef &L) { return L.fmt != 0; }
+
+// One dense layer over the workgroup's row tile.  Xs: LDS buffer of row stride ldx holding the
+// input in the form the layer reads (split image for a matrix layer, fp32 rows with columns
+// [K, Kp) zero for a narrow one).  Ys: LDS buffer of row stride ldy that receives the output as a
+// split image (`split_out`, matrix layers only) or as fp32 rows with columns [N, Np) zero.
 // `row_add` (optional, LDS): per-row additive table row_add[row_sel[r]][n] added before the
 // activation (the action-embedding contribution of the dynamics merge layer).
 // `narrow_lds` (optional): LDS copy of a narrow layer's weights made by stage_narrow.
 // Ends with a team sync: Ys is complete and Xs may be overwritten afterwards.
 template <int MT>
 __device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float *__restrict__ packed,
-                                           const mz_packed_layer &L, lds_f *Ys, int ldy, const lds_f *row_add,
+                                           const mz_packed_layer &L, lds_f *Ys, int ldy, bool split_out, const lds_f *row_add,
                                            int row_add_ld, const lds_i *row_sel, const lds_f *narrow_lds, Team &tm) {
-    if (L.N <= 8 && row_add == nullptr) {
+    if (!is_matrix_layer(L)) {
         if (narrow_lds)
             dense_narrow<LdsNarrowWeights>(Xs, ldx, 16 * MT, nullptr, nullptr, narrow_lds, L.Kp, L.N, L.act, Ys, ldy,
                                            tm.wave0, tm.nwaves);
@@ -634,16 +647,8 @@ __device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float
         tm.sync();
         return;
     }
-    dense_group1<MT>(LdsRows{Xs, ldx}, packed, L.Kp, make_part(L, Ys, ldy, L.act, row_add, row_add_ld, row_sel), tm);
+    dense_group1<MT>(Xs, ldx, packed, L.Kp, make_part(L, Ys, ldy, L.act, split_out, row_add, row_add_ld, row_sel), tm);
     tm.sync();
-}
-template <int MT>
-__device__ __forceinline__ void dense_tile(const lds_f *Xs, int ldx, const float *__restrict__ packed,
-                                           const mz_packed_layer &L, lds_f *Ys, int ldy, const lds_f *row_add = nullptr,
-                                           int row_add_ld = 0, const lds_i *row_sel = nullptr,
-                                           const lds_f *narrow_lds = nullptr) {
-    Team tm = whole_workgroup();
-    dense_tile<MT>(Xs, ldx, packed, L, Ys, ldy, row_add, row_add_ld, row_sel, narrow_lds, tm);
 }
 
 // In-place softmax over the first N columns of each of `rows` LDS rows, applied `times`
@@ -702,13 +707,13 @@ __device__ __forceinline__ mz_packed_layer load_layer(const LayerRef &s) {
     L.Kp = uni(s.Kp);
     L.Np = uni(s.Np);
     L.act = uni(s.act);
-    L._pad = 0;
+    L.fmt = uni(s.fmt);
     L.w_off = uni((int)s.w_off);
     L.b_off = uni((int)s.b_off);
     return L;
 }
 
-// A head that ends in [wide layer, one-output layer] has that pair folded: the wide layer's
+// A head that ends in [matrix layer, one-output layer] has that pair folded: the matrix layer's
 // epilogue forms the dot products with the output layer's weights (DensePart::dot_out).
 template <typename MLP>
 __host__ __device__ inline bool tail_foldable(const MLP &M) {
@@ -716,33 +721,45 @@ __host__ __device__ inline bool tail_foldable(const MLP &M) {
     return n >= 2 && M.layer[n - 1].N == 1 && M.layer[n - 2].N > 8 && M.layer[n - 1].K == M.layer[n - 2].N;
 }
 
-// Runs layers [first, n) of `M` over the team's row tile (input `src`, row stride `ld`),
-// ping-ponging between two LDS buffers.  Returns the buffer that holds the output, row stride
-// *out_ld.  A MZ_ACT_SOFTMAX layer is a linear layer followed by softmax_rows.  `narrow`
-// (optional): byte offsets into `smem` of LDS copies of narrow layers' weights, or -1.
-// Every layer ends with a team sync.
+// Runs layers [first, n) of `M` over the team's row tile, ping-ponging between two LDS buffers.
+// The input of layer `first` is expected in `src` (row stride ld) in the form that layer reads --
+// see dense_tile; a caller whose input exists in both forms passes the other one as `src_alt`
+// (`src` = split image, `src_alt` = fp32 rows) and the layer picks.  Returns the buffer that holds
+// the output as fp32 rows, row stride *out_ld.  A MZ_ACT_SOFTMAX layer is a linear layer followed
+// by softmax_rows.  `narrow` (optional): byte offsets into `smem` of LDS copies of narrow layers'
+// weights, or -1.  Every layer ends with a team sync.
 template <int MT, typename MLP, typename NarrowPtr = const int *>
 __device__ __forceinline__ lds_f *mlp_tile(Team &tm, const MLP &M, int first, const float *__restrict__ packed,
-                                           lds_f *src, int ld, lds_f *buf_a, lds_f *buf_b, int *out_ld,
+                                           lds_f *src, lds_f *src_alt, int ld, lds_f *buf_a, lds_f *buf_b, int *out_ld,
                                            unsigned char *smem = nullptr, NarrowPtr narrow = nullptr) {
     const int n = uni(M.n_layers);
     const bool fold = uni((int)tail_foldable(M)) && first <= n - 2;
     const int plain_end = fold ? n - 2 : n;
+    if (src_alt != nullptr && first < n && !uni((int)is_matrix_layer(M.layer[first]))) src = src_alt;
     for (int i = first; i < plain_end; ++i) {
         const mz_packed_layer L = load_layer(M.layer[i]);
         lds_f *dst = (src == buf_a) ? buf_b : buf_a;
         const int ldo = lds_stride(L.N);
         const int nwo = narrow ? uni(narrow[i]) : -1;
         const lds_f *nw = nwo >= 0 ? to_lds(smem + nwo) : nullptr;
-        dense_tile<MT>(src, ld, packed, L, dst, ldo, nullptr, 0, nullptr, nw, tm);
+        // the output takes the form its reader wants: the next layer if it is a matrix layer, fp32 rows otherwise
+        const bool split_out = i + 1 < n && uni((int)is_matrix_layer(M.layer[i + 1]));
+        dense_tile<MT>(src, ld, packed, L, dst, ldo, split_out, nullptr, 0, nullptr, nw, tm);
         if (L.act == MZ_ACT_SOFTMAX) softmax_rows(dst, ldo, 16 * MT, L.N, 1, tm);
+        if (!is_matrix_layer(L) && i + 1 < n && uni((int)is_matrix_layer(M.layer[i + 1]))) {
+            // fp32 rows of a narrow layer feed a matrix layer: their image goes to the other buffer
+            lds_f *img = (dst == buf_a) ? buf_b : buf_a;
+            rows_to_split(dst, ldo, img, ldo, MT, ceil32(L.N) >> 5, ceil16(L.N), tm);
+            tm.sync();
+            dst = img;
+        }
         src = dst;
         ld = ldo;
     }
     if (fold) {
         const mz_packed_layer L = load_layer(M.layer[n - 2]), L1 = load_layer(M.layer[n - 1]);
         lds_f *dst = (src == buf_a) ? buf_b : buf_a;
-        dense_group1<MT>(LdsRows{src, ld}, packed, L.Kp, make_dot_part(L, L1, dst), tm);
+        dense_group1<MT>(src, ld, packed, L.Kp, make_dot_part(L, L1, dst), tm);
         tm.sync();
         finish_dot(dst, L.Np >> 4, 16 * MT, packed, L1, dst, 1, tm);  // in place: row r ends in dst[r]
         tm.sync();
@@ -752,17 +769,11 @@ __device__ __forceinline__ lds_f *mlp_tile(Team &tm, const MLP &M, int first, co
     *out_ld = ld;
     return src;
 }
-template <int MT>
-__device__ __forceinline__ lds_f *mlp_tile(const mz_packed_mlp &M, const float *__restrict__ packed, lds_f *in_buf,
-                                           int in_ld, lds_f *buf_a, lds_f *buf_b, int *out_ld) {
-    Team tm = whole_workgroup();
-    return mlp_tile<MT>(tm, M, 0, packed, in_buf, in_ld, buf_a, buf_b, out_ld);
-}
 
 // Cooperative load of up to `rows` global rows (row r from row_ptr(r), NULL: zeros) into an LDS tile
-// [TM][ld], zero-filling columns [K, ld) and rows >= rows.  Two round trips to memory, not one per
-// element: a wave takes whole rows, asks for the row's address once (wave-uniform, so it lives in scalar
-// registers) and requests all of the row's values before the first is stored.
+// [TM][ld] of fp32 rows, zero-filling columns [K, ld) and rows >= rows.  Two round trips to memory, not
+// one per element: a wave takes whole rows, asks for the row's address once (wave-uniform, so it lives in
+// scalar registers) and requests all of the row's values before the first is stored.  Ends with a barrier.
 template <typename RowPtr>
 __device__ __forceinline__ void load_rows(lds_f *Xs, int ld, int TM, int rows, int K, RowPtr row_ptr) {
     const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
@@ -793,6 +804,13 @@ __device__ __forceinline__ void load_rows(lds_f *Xs, int ld, int TM, int rows, i
                 }
         }
     }
+    __syncthreads();
+}
+// load_rows followed by the rows' split image in Ss (same row stride); ends with a barrier.
+template <typename RowPtr>
+__device__ __forceinline__ void load_rows_split(lds_f *Xs, lds_f *Ss, int ld, int MT, int rows, int K, RowPtr row_ptr) {
+    load_rows(Xs, ld, 16 * MT, rows, K, row_ptr);
+    rows_to_split(Xs, ld, Ss, ld, MT, ceil32(K) >> 5, ld, whole_workgroup());
     __syncthreads();
 }
 

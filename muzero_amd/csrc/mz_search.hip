@@ -14,8 +14,9 @@
 //     simulation  depth x {policy -> first-max action -> merge -> reward}, then value, the
 //                 rollout latents read on the fly as relu(z + table[action])
 //   backup        the recorded path is updated by independent lanes
-// Weights are read from L2 in the packed MFMA layout (mz_mlp_device.h); activations, priors,
-// rewards and rollouts stay in LDS; the node pool in HBM receives exactly the records the
+// Weights are read from L2 in the packed MFMA layout (mz_mlp_device.h: matrix layers as two fp16
+// planes per fp32 weight, three v_mfma_f32_16x16x32_f16 per product block); activations (fp32 rows or
+// the split operand images the matrix layers read), priors, rewards and rollouts stay in LDS; the node pool in HBM receives exactly the records the
 // stand-alone kernels would write, so both paths are interchangeable and comparable bit for bit.
 //
 // Compiled with -ffp-contract=off (every rounding is part of the contract).
@@ -41,12 +42,13 @@ namespace {
 #define MZ_SKIP(bit) 0
 #endif
 
-// Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2.
+// Layers [first, n) of an MLP over the team's 16 rows, ping-ponging h1/h2 (src: the input in the form layer
+// `first` reads; src_alt: its fp32 rows where src is the split image and both exist).
 template <typename MLP>
 __device__ __forceinline__ lds_f *mlp16(Team &tm, const MLP &M, int first, const float *__restrict__ blob, lds_f *src,
-                                        int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
+                                        lds_f *src_alt, int ld, lds_f *h1, lds_f *h2, int *out_ld, unsigned char *smem,
                                         const lds_i *narrow) {
-    return mlp_tile<1>(tm, M, first, blob, src, ld, h1, h2, out_ld, smem, narrow);
+    return mlp_tile<1>(tm, M, first, blob, src, src_alt, ld, h1, h2, out_ld, smem, narrow);
 }
 
 // After the leaf's first layers, a simulation round splits the workgroup into two teams of
@@ -66,7 +68,10 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
          double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
          int32_t *__restrict__ visits) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    lds_f *X = to_lds(smem_raw + L.x);
+    lds_f *X32 = to_lds(smem_raw + L.x32);  // leaf latents, fp32 rows (as gathered)
+    lds_f *X = to_lds(smem_raw + L.x);      // their split image
+    lds_f *XS = X32;                        // the simulation's current latent, split image (X32 is dead by then)
+    lds_f *XS32 = L.need_x32 ? to_lds(smem_raw + L.xs32) : nullptr;  // and as fp32 rows where a narrow layer reads it
     lds_f *Z = to_lds(smem_raw + L.z);
     lds_f *Zs = to_lds(smem_raw + L.zs);
     lds_f *Tab = to_lds(smem_raw + L.tab);
@@ -74,9 +79,10 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
     lds_f *He2 = to_lds(smem_raw + L.he2);
     lds_f *Hs1 = to_lds(smem_raw + L.hs1);
     lds_f *Hs2 = to_lds(smem_raw + L.hs2);
-    lds_f *R1 = to_lds(smem_raw + L.r1);
-    lds_f *R2 = to_lds(smem_raw + L.r2);
-    lds_f *Rout = to_lds(smem_raw + L.rout);
+    lds_f *R = to_lds(smem_raw + L.r);      // the children's latents, split image (over X | He1 | He2)
+    lds_f *R32 = to_lds(smem_raw + L.r32);
+    lds_f *Ra = to_lds(smem_raw + L.ra);
+    lds_f *Rb = to_lds(smem_raw + L.rb);
     lds_f *DotE = to_lds(smem_raw + L.dot);
     lds_f *DotS = to_lds(smem_raw + L.dots);
     lds_f *DotV = to_lds(smem_raw + L.dotv);
@@ -130,10 +136,15 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
     // the LDS copy where the layer runs
     const int pol_layers = Pk.policy.n_layers, val_layers = Pk.value.n_layers, rew_layers = Pk.reward.n_layers;
     const bool pol0_softmax_only = Pk.policy.layer[0].act == MZ_ACT_SOFTMAX && pol_layers == 1;
-    const bool rew0_wide = Pk.reward.layer[0].N > 8;
-    const bool grouped_first = Pk.policy.layer[0].N > 8 && Pk.policy.layer[0].Kp == Pk.merge.layer[0].Kp;
+    const bool rew0_matrix = is_matrix_layer(Pk.reward.layer[0]);
+    const bool grouped_first = is_matrix_layer(Pk.policy.layer[0]) && Pk.policy.layer[0].Kp == Pk.merge.layer[0].Kp;
+    // the output of the policy head's first layer takes the form its reader wants (mlp_tile's rule)
+    const bool pol0_split = pol_layers >= 2 && is_matrix_layer(Pk.policy.layer[1]);
+    const bool val0_split = val_layers >= 2 && is_matrix_layer(Pk.value.layer[1]);
+    const int Dp16 = Pk.merge.layer[0].Np;  // columns of a merge pre-activation row that were written
+    const int KCd = Pk.merge.layer[0].Kp >> 5;  // k-chunks of a latent's split image
     const bool fold_value2 = val_layers == 2 && tail_foldable(Pk.value);
-    const bool grouped_last = L.fold_reward && val_layers >= 2 && Pk.value.layer[0].N > 8 &&
+    const bool grouped_last = L.fold_reward && val_layers >= 2 && is_matrix_layer(Pk.value.layer[0]) &&
                               Pk.value.layer[0].Kp == Pk.reward.layer[0].Kp;
     (void)val_layers;
     const int ld_d = L.ld_d;
@@ -145,30 +156,66 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
     const int half = uni(tid >> 6) >= kWaves / 2 ? 1 : 0;
     int team_arrived = 0;  // arrivals this wave's team counter shows after the wave's latest team sync
 
-    // policy layer 1 -> h_out and merge pre-activation W[:, :D] x -> z_out, from the same
-    // input rows; ends with a barrier.  (The merge layer's stored epilogue is a relu for the
-    // stand-alone kernel; here its pre-activation is kept and the per-action table is added
-    // where a child latent is formed.)
-    auto first_layers = [&](Team &tm, const auto &rows, const lds_f *in, lds_f *h_out, lds_f *z_out) {
+    // policy layer 1 -> h_out and merge pre-activation W[:, :D] x -> z_out (fp32 rows), from the same
+    // input rows (xs: their split image, x32: their fp32 rows where a narrow first layer reads them);
+    // ends with a team sync.  Returns the buffer that holds policy layer 1's output in the form layer 2
+    // reads (h_out, or h_alt after a conversion).  (The merge layer's stored epilogue is a relu for the
+    // stand-alone kernel; here its pre-activation is kept and the per-action table is added where a child
+    // latent is formed.)
+    auto first_layers = [&](Team &tm, const lds_f *xs, const lds_f *x32, lds_f *h_out, lds_f *h_alt, lds_f *z_out) -> lds_f * {
         const mz_packed_layer Lp0 = load_layer(P.policy.layer[0]), Lm0 = load_layer(P.merge.layer[0]);
         if (grouped_first) {
-            dense_group2<1>(rows, blob, Lm0.Kp, make_part(Lp0, h_out, ld_p1, Lp0.act), make_part(Lm0, z_out, ld_d, MZ_ACT_NONE), tm);
+            dense_group2<1>(xs, ld_d, blob, Lm0.Kp, make_part(Lp0, h_out, ld_p1, Lp0.act, pol0_split),
+                            make_part(Lm0, z_out, ld_d, MZ_ACT_NONE), tm);
             tm.sync();
-        } else {  // `in`: the same rows materialised in LDS
-            const int nwo = uni(s_narrow[0]);
-            const lds_f *nw = nwo >= 0 ? to_lds(smem_raw + nwo) : nullptr;
-            dense_tile<1>(in, ld_d, blob, Lp0, h_out, ld_p1, nullptr, 0, nullptr, nw, tm);
-            dense_group1<1>(LdsRows{in, ld_d}, blob, Lm0.Kp, make_part(Lm0, z_out, ld_d, MZ_ACT_NONE), tm);
-            tm.sync();
+            return h_out;
+        }
+        // a narrow first policy layer reads the fp32 rows
+        const int nwo = uni(s_narrow[0]);
+        const lds_f *nw = nwo >= 0 ? to_lds(smem_raw + nwo) : nullptr;
+        dense_tile<1>(is_matrix_layer(Lp0) ? xs : x32, ld_d, blob, Lp0, h_out, ld_p1, pol0_split && is_matrix_layer(Lp0), nullptr, 0,
+                      nullptr, nw, tm);
+        dense_group1<1>(xs, ld_d, blob, Lm0.Kp, make_part(Lm0, z_out, ld_d, MZ_ACT_NONE), tm);
+        lds_f *res = h_out;
+        if (!is_matrix_layer(Lp0) && pol0_split) {  // fp32 rows of a narrow layer feed a matrix layer
+            rows_to_split(h_out, ld_p1, h_alt, ld_p1, 1, ceil32(Lp0.N) >> 5, ceil16(Lp0.N), tm);
+            res = h_alt;
+        }
+        tm.sync();
+        return res;
+    };
+    // Sixteen rows relu(zsrc[t] + table[sel[t]]) -- the latents the dynamics network gives for the actions
+    // sel -- as a split image in `dst` (and as fp32 rows in dst32 when not NULL); no sync.
+    auto form_rows = [&](const Team &tm, const lds_f *zsrc, const lds_i *sel, lds_f *dst, lds_f *dst32) {
+        for (int i = tm.tid(); i < KCd * 64; i += tm.nthreads()) {
+            const int l = i & 63, c = i >> 6, t = l & 15;
+            const int k0 = 32 * c + 8 * (l >> 4);
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (k0 < Dp16) {
+                const lds_f *zr = zsrc + t * ld_d + k0, *tr = Tab + sel[t] * ld_d + k0;
+                const f32x4 z0 = *reinterpret_cast<const lds_f4 *>(zr), z1 = *reinterpret_cast<const lds_f4 *>(zr + 4);
+                const f32x4 b0 = *reinterpret_cast<const lds_f4 *>(tr), b1 = *reinterpret_cast<const lds_f4 *>(tr + 4);
+                v0 = f32x4{fmaxf(z0.x + b0.x, 0.f), fmaxf(z0.y + b0.y, 0.f), fmaxf(z0.z + b0.z, 0.f), fmaxf(z0.w + b0.w, 0.f)};
+                v1 = f32x4{fmaxf(z1.x + b1.x, 0.f), fmaxf(z1.y + b1.y, 0.f), fmaxf(z1.z + b1.z, 0.f), fmaxf(z1.w + b1.w, 0.f)};
+            }
+            f32x4 hi, lo;
+            split8(v0, v1, hi, lo);
+            lds_f *q = dst + c * kChunkFloats + l * 4;
+            *reinterpret_cast<lds_f4 *>(q) = hi;
+            *reinterpret_cast<lds_f4 *>(q + KCd * kChunkFloats) = lo;
+            if (dst32 != nullptr) {
+                *reinterpret_cast<lds_f4 *>(dst32 + t * ld_d + k0) = v0;
+                *reinterpret_cast<lds_f4 *>(dst32 + t * ld_d + k0 + 4) = v1;
+            }
         }
     };
 
     // ---- the expansion after the leaf's first layers (He1, Z valid) ---------------------------
-    auto expand_tail = [&](Team &tm, int e, int base) {
+    auto expand_tail = [&](Team &tm, int e, int base, lds_f *pol_in) {
         const int ttid = tm.tid(), tn = tm.nthreads();
         int ld_p = ld_p1;
-        lds_f *pol = He1;
-        if (!MZ_SKIP(6)) pol = mlp16(tm, P.policy, 1, blob, He1, ld_p1, He1, He2, &ld_p, smem_raw, s_narrow);
+        lds_f *pol = pol_in;
+        if (!MZ_SKIP(6)) pol = mlp16(tm, P.policy, 1, blob, pol_in, nullptr, ld_p1, He1, He2, &ld_p, smem_raw, s_narrow);
         MZ_STAMP(4)  // expand: remaining policy layers
         if (pol0_softmax_only) softmax_rows(pol, ld_p, kTrees, A, 1, tm);
         softmax_rows(pol, ld_p, kTrees, A, 1, tm);  // expand_node's extra softmax (expansion.py:27)
@@ -178,6 +225,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
             s_prior[i] = pr;
             if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + a] = pr;
         }
+        tm.sync();  // the children's image below overwrites the policy head's buffers
         MZ_STAMP(5)  // expand: softmax + priors
         // child latents -> pool (coalesced along the latent).  Written once, read back at most a
         // few times much later: streaming (non-temporal) stores keep them from displacing the
@@ -221,12 +269,35 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
             }
         }
         MZ_STAMP(6)  // expand: child latents to the pool
-        // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time
+        // reward MLP over the children, MTC actions (= MTC row tiles of 16 trees) at a time: row tile mt of a
+        // pass holds the children of action a0 + mt, relu(z[t] + table[a0 + mt]), as a split image
         for (int a0 = 0; a0 < A && !MZ_SKIP(8); a0 += MTC) {
+            for (int i = ttid; i < MTC * KCd * 64; i += tn) {
+                const int l = i & 63, c = (i >> 6) % KCd, mt = (i >> 6) / KCd, t = l & 15;
+                const int k0 = 32 * c + 8 * (l >> 4);
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (k0 < Dp16) {
+                    const lds_f *zr = Z + t * ld_d + k0, *tr = Tab + (a0 + mt) * ld_d + k0;
+                    const f32x4 z0 = *reinterpret_cast<const lds_f4 *>(zr), z1 = *reinterpret_cast<const lds_f4 *>(zr + 4);
+                    const f32x4 b0 = *reinterpret_cast<const lds_f4 *>(tr), b1 = *reinterpret_cast<const lds_f4 *>(tr + 4);
+                    v0 = f32x4{fmaxf(z0.x + b0.x, 0.f), fmaxf(z0.y + b0.y, 0.f), fmaxf(z0.z + b0.z, 0.f), fmaxf(z0.w + b0.w, 0.f)};
+                    v1 = f32x4{fmaxf(z1.x + b1.x, 0.f), fmaxf(z1.y + b1.y, 0.f), fmaxf(z1.z + b1.z, 0.f), fmaxf(z1.w + b1.w, 0.f)};
+                }
+                f32x4 hi, lo;
+                split8(v0, v1, hi, lo);
+                lds_f *qd = R + mt * 16 * ld_d + c * kChunkFloats + l * 4;
+                *reinterpret_cast<lds_f4 *>(qd) = hi;
+                *reinterpret_cast<lds_f4 *>(qd + KCd * kChunkFloats) = lo;
+                if (!rew0_matrix) {
+                    *reinterpret_cast<lds_f4 *>(R32 + (mt * 16 + t) * ld_d + k0) = v0;
+                    *reinterpret_cast<lds_f4 *>(R32 + (mt * 16 + t) * ld_d + k0 + 4) = v1;
+                }
+            }
+            tm.sync();
             if (L.fold_reward) {
                 // hidden layer over the children with the output layer folded into its epilogue
                 const mz_packed_layer L0 = load_layer(P.reward.layer[0]), L1 = load_layer(P.reward.layer[1]);
-                dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp, make_dot_part(L0, L1, DotE), tm);
+                dense_group1<MTC>(R, ld_d, blob, L0.Kp, make_dot_part(L0, L1, DotE), tm);
                 tm.sync();
                 MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
                 const float b2 = blob[L1.b_off];
@@ -239,29 +310,9 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                 tm.sync();
                 continue;
             }
-            lds_f *src;
-            int ld, first;
-            if (rew0_wide) {
-                const mz_packed_layer L0 = load_layer(P.reward.layer[0]);
-                dense_group1<MTC>(ChildRows{Z, ld_d, Tab + a0 * ld_d, ld_d}, blob, L0.Kp,
-                                  make_part(L0, R1, lds_stride(L0.N), L0.act), tm);
-                tm.sync();
-                MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
-                src = R1, ld = lds_stride(L0.N), first = 1;
-            } else {  // a reward head without hidden layers: materialise the child rows
-                for (int i = ttid; i < kTrees * MTC * ld_d; i += tn) {
-                    const int r = i / ld_d, c = i - r * ld_d;
-                    R1[r * L.ld_r + c] = fmaxf(Z[(r % kTrees) * ld_d + c] + Tab[(a0 + r / kTrees) * ld_d + c], 0.0f);
-                }
-                tm.sync();
-                src = R1, ld = L.ld_r, first = 0;
-            }
-            {
-                int ldo;
-                src = mlp_tile<MTC>(tm, P.reward, first, blob, src, ld, R1, rew_layers >= 3 ? R2 : Rout, &ldo, smem_raw,
-                                    s_narrow + 2 * MZ_MAX_LAYERS);
-                ld = ldo;
-            }
+            int ld;
+            const lds_f *src = mlp_tile<MTC>(tm, P.reward, 0, blob, R, rew0_matrix ? nullptr : R32, ld_d, Ra, Rb, &ld, smem_raw,
+                                             s_narrow + 2 * MZ_MAX_LAYERS);
             for (int i = ttid; i < kTrees * MTC; i += tn) {
                 const int al = i / kTrees, t = i % kTrees;
                 s_rew[t * L.tab_rows + a0 + al] = src[i * ld];
@@ -281,46 +332,27 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         MZ_STAMP(9)  // commit
     };
 
-    // ---- the simulation from the drawn child (Z, s_act valid; writes X, Zs, Hs1, Hs2) ---------
+    // ---- the simulation from the drawn child (Z, s_act valid; writes XS, Zs, Hs1, Hs2) --------
     // A latent along the rollout is relu(z + table[action]) with z the merge pre-activation of
-    // the previous latent (Z for the drawn child, Zs afterwards).  Where the layers that consume
-    // it are wide, they read it through PickedRows and it is never materialised; otherwise it is
-    // formed in X first.
+    // the previous latent (Z for the drawn child, Zs afterwards), formed as the split image the
+    // matrix layers read (form_rows).
     auto simulate = [&](Team &tm, int e, int base) {
         const int ttid = tm.tid();
-        auto form_x = [&](const lds_f *zsrc) {
-            const int q4 = ld_d >> 2, dp4 = Dp >> 2;
-            const int wv = uni(ttid >> 6), lane = ttid & 63;
-            for (int t = wv; t < kTrees; t += tm.nwaves) {
-                const lds_f *trow = Tab + s_act[t] * ld_d;
-                for (int c4 = lane; c4 < q4; c4 += 64) {
-                    const f32x4 z = *reinterpret_cast<const lds_f4 *>(zsrc + t * ld_d + 4 * c4);
-                    const f32x4 b = *reinterpret_cast<const lds_f4 *>(trow + 4 * c4);
-                    f32x4 v = {fmaxf(z.x + b.x, 0.f), fmaxf(z.y + b.y, 0.f), fmaxf(z.z + b.z, 0.f), fmaxf(z.w + b.w, 0.f)};
-                    if (c4 >= dp4) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<lds_f4 *>(X + t * ld_d + 4 * c4) = v;
-                }
-            }
-            tm.sync();
-        };
         for (int d = 0; d < depth; ++d) {
-            if (d == 0 && grouped_first) {
-                first_layers(tm, PickedRows::from(Z, ld_d, Tab, ld_d, s_act), X, Hs1, Zs);
-            } else {
-                form_x(d == 0 ? Z : Zs);
-                MZ_STAMP(16)  // simulate: next latent
-                if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
-                    int ld_o;
-                    const lds_f *r = mlp16(tm, P.reward, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + 2 * MZ_MAX_LAYERS);
-                    if (ttid < kTrees) s_roll[ttid * (depth + 1) + (d - 1)] = r[ttid * ld_o];
-                    tm.sync();
-                    MZ_STAMP(17)  // simulate: reward head
-                }
-                first_layers(tm, LdsRows{X, ld_d}, X, Hs1, Zs);
+            form_rows(tm, d == 0 ? Z : Zs, s_act, XS, XS32);
+            tm.sync();
+            MZ_STAMP(16)  // simulate: next latent
+            if (d > 0) {  // reward of the step just taken (src/search/simulation.py:37-38)
+                int ld_o;
+                const lds_f *r = mlp16(tm, P.reward, 0, blob, XS, XS32, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + 2 * MZ_MAX_LAYERS);
+                if (ttid < kTrees) s_roll[ttid * (depth + 1) + (d - 1)] = r[ttid * ld_o];
+                tm.sync();
+                MZ_STAMP(17)  // simulate: reward head
             }
+            lds_f *pol_in = first_layers(tm, XS, XS32, Hs1, Hs2, Zs);
             MZ_STAMP(18)  // simulate: policy layer 1 | merge
             int ld_q;
-            lds_f *pq = mlp16(tm, P.policy, 1, blob, Hs1, ld_p1, Hs1, Hs2, &ld_q, smem_raw, s_narrow);
+            lds_f *pq = mlp16(tm, P.policy, 1, blob, pol_in, nullptr, ld_p1, Hs1, Hs2, &ld_q, smem_raw, s_narrow);
             MZ_STAMP(19)  // simulate: remaining policy layers
             if (pol0_softmax_only) softmax_rows(pq, ld_q, kTrees, A, 1, tm);
             if (ttid < kTrees) {  // first maximum of the network's policy (simulation.py:36)
@@ -334,7 +366,9 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
             MZ_STAMP(20)  // simulate: argmax
         }
         // the last latent: reward of the last step (depth >= 1) and value
-        const lds_f *zfin = depth == 0 ? Z : Zs;
+        form_rows(tm, depth == 0 ? Z : Zs, s_act, XS, XS32);
+        tm.sync();
+        MZ_STAMP(16)  // simulate: next latent
         if (depth >= 1 && grouped_last) {
             const mz_packed_layer R0 = load_layer(P.reward.layer[0]), R1l = load_layer(P.reward.layer[1]),
                                   V0 = load_layer(P.value.layer[0]);
@@ -342,8 +376,8 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
             // a two-layer value head is folded like the reward head (as every kernel does)
             const bool fold_v = fold_value2;
             const mz_packed_layer V1l = load_layer(P.value.layer[1]);
-            dense_group2<1>(PickedRows::from(zfin, ld_d, Tab, ld_d, s_act), blob, V0.Kp,
-                            fold_v ? make_dot_part(V0, V1l, DotV) : make_part(V0, Hs1, ld_v, V0.act),
+            dense_group2<1>(XS, ld_d, blob, V0.Kp,
+                            fold_v ? make_dot_part(V0, V1l, DotV) : make_part(V0, Hs1, ld_v, V0.act, val0_split),
                             make_dot_part(R0, R1l, DotS), tm);
             tm.sync();
             finish_dot(DotS, R0.Np >> 4, kTrees, blob, R1l, s_roll + (depth - 1), depth + 1, tm);
@@ -352,22 +386,20 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                 finish_dot(DotV, V0.Np >> 4, kTrees, blob, V1l, s_roll + depth, depth + 1, tm);
             } else {
                 int ld_o;
-                const lds_f *v = mlp16(tm, P.value, 1, blob, Hs1, ld_v, Hs1, Hs2, &ld_o, smem_raw, s_narrow + MZ_MAX_LAYERS);
+                const lds_f *v = mlp16(tm, P.value, 1, blob, Hs1, nullptr, ld_v, Hs1, Hs2, &ld_o, smem_raw, s_narrow + MZ_MAX_LAYERS);
                 if (ttid < kTrees) s_roll[ttid * (depth + 1) + depth] = v[ttid * ld_o];
             }
             MZ_STAMP(21)  // simulate: value head
         } else {
-            form_x(zfin);
-            MZ_STAMP(16)  // simulate: next latent
             if (depth >= 1) {
                 int ld_o;
-                const lds_f *r = mlp16(tm, P.reward, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + 2 * MZ_MAX_LAYERS);
+                const lds_f *r = mlp16(tm, P.reward, 0, blob, XS, XS32, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + 2 * MZ_MAX_LAYERS);
                 if (ttid < kTrees) s_roll[ttid * (depth + 1) + (depth - 1)] = r[ttid * ld_o];
                 tm.sync();
                 MZ_STAMP(17)  // simulate: reward head
             }
             int ld_o;
-            const lds_f *v = mlp16(tm, P.value, 0, blob, X, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + MZ_MAX_LAYERS);
+            const lds_f *v = mlp16(tm, P.value, 0, blob, XS, XS32, ld_d, Hs1, Hs2, &ld_o, smem_raw, s_narrow + MZ_MAX_LAYERS);
             if (ttid < kTrees) s_roll[ttid * (depth + 1) + depth] = v[ttid * ld_o];
             MZ_STAMP(21)  // simulate: value head
         }
@@ -396,7 +428,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
             v = q.root_latent[(size_t)(g0 + t) * D + c];
             p.latent[((size_t)(g0 + t) * p.cap) * D + c] = v;
         }
-        X[i] = v;
+        X32[i] = v;
     }
     if (tid < kTrees) {
         int tp = 0;
@@ -465,13 +497,13 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                     for (int c4 = lane; c4 < q4; c4 += 64) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (t < trees && c4 < d4) v = src[c4];
-                        *reinterpret_cast<lds_f4 *>(X + t * ld_d + 4 * c4) = f32x4{v.x, v.y, v.z, v.w};
+                        *reinterpret_cast<lds_f4 *>(X32 + t * ld_d + 4 * c4) = f32x4{v.x, v.y, v.z, v.w};
                     }
                 }
             } else {
                 for (int i = tid; i < kTrees * ld_d; i += kThreads) {
                     const int t = i / ld_d, c = i - t * ld_d;
-                    X[i] = (t < trees && c < D) ? p.latent[((size_t)(g0 + t) * p.cap + s_leaf[t]) * D + c] : 0.0f;
+                    X32[i] = (t < trees && c < D) ? p.latent[((size_t)(g0 + t) * p.cap + s_leaf[t]) * D + c] : 0.0f;
                 }
             }
             __syncthreads();
@@ -480,7 +512,10 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
 
         // ---- the leaf's policy layer 1 and merge layer share the input: whole workgroup --------
         Team all = whole_workgroup();
-        if (!MZ_SKIP(3)) first_layers(all, LdsRows{X, ld_d}, X, He1, Z);
+        rows_to_split(X32, ld_d, X, ld_d, 1, KCd, ld_d, all);
+        __syncthreads();
+        lds_f *pol_in = He1;
+        if (!MZ_SKIP(3)) pol_in = first_layers(all, X, X32, He1, He2, Z);
         MZ_STAMP(3)  // expand: policy layer 1 | merge
 
         // the root expansion has no simulation: the whole workgroup expands
@@ -493,7 +528,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         }
         if (stamping && tid == kThreads / 2) t_prev = clock64();
         if (!sim || half == 0) {
-            if (!MZ_SKIP(1)) expand_tail(tm, e, base);
+            if (!MZ_SKIP(1)) expand_tail(tm, e, base, pol_in);
         } else {
             // the simulation is the longer chain: its waves issue first whenever both teams'
             // waves of a SIMD are ready
@@ -584,7 +619,7 @@ int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *
 #endif
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (pool->G + kTrees - 1) / kTrees;
-    const int candidates[4] = {7, 4, 2, 1};
+    const int candidates[5] = {7, 4, 3, 2, 1};
     for (int mtc : candidates) {
         if (mtc > pool->A && mtc != 1) continue;
         const Lds L = lds_layout(*plan, mtc, q.depth, q.tab_len);
@@ -602,6 +637,7 @@ int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *
         switch (mtc) {
             case 7: return launch(k_search<7>);
             case 4: return launch(k_search<4>);
+            case 3: return launch(k_search<3>);
             case 2: return launch(k_search<2>);
             default: return launch(k_search<1>);
         }

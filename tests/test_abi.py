@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_header():
     assert set(_declared()) <= set(_hip.exported_symbols())
     lib = _hip.lib()
-    assert lib.mz_abi_version() == 2  # 2: one 32-byte record per node
+    assert lib.mz_abi_version() == 3  # 2: one 32-byte record per node; 3: matrix layers packed as two fp16 planes (mz_packed_layer.fmt)
 
 
 def test_host_only_entry_points():
@@ -45,7 +45,10 @@ def test_host_only_entry_points():
     m.layer[1] = _hip.Dense(1, None, 256, 7, 4, 0)
     plan = _hip.PackedMlp()
     n = _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan))
-    assert n == 176 * 256 + 256 + 256 * 16 + 16 + 1024  # tiles + padded bias per layer, 4 KiB read slack
+    # tiles + padded bias per layer, 4 KiB read slack: the 256-output layer runs on the matrix cores (K padded to
+    # 32, two fp16 planes = 4 bytes per weight), the 7-output layer on the vector ALU from fp32 tiles (K padded to 16)
+    assert n == 192 * 256 + 256 + 256 * 16 + 16 + 1024
+    assert (plan.layer[0].fmt, plan.layer[0].Kp, plan.layer[1].fmt, plan.layer[1].Kp) == (1, 192, 0, 256)
     assert (plan.in_features, plan.out_features, plan.max_width) == (168, 7, 256)
     m.layer[1].in_features = 255  # chain mismatch must be rejected with a message
     assert _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan)) < 0
