@@ -292,6 +292,9 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--store-latents", action="store_true",
+                    help="keep every node's latent in the pool (the drop-in MCTS.run's form) instead of one merge row per "
+                         "expansion (self-play's form; bit-identical trees)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selfplay-moves", type=int, default=8, help="timed self-play moves per game (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=1.5,
@@ -328,7 +331,7 @@ def main():
     cfg, h, g, f = build_networks()
     G, S = args.games, args.sims
     nets = PackedNetworks(g, f, device=dev)
-    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev)
+    mcts = BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev, keep_latents=args.store_latents)
     latent, to_play = synthetic_roots(h, G, seed=100 + rank, device=dev)
     eta = torch.from_numpy(np.random.default_rng(7 + rank).dirichlet(np.full(A, 0.3), size=G).astype(np.float32)).to(dev)
     rand = torch.from_numpy(child_choice_streams(G, S, base_seed=shard.first_game)).to(dev)

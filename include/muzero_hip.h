@@ -530,10 +530,18 @@ typedef struct mz_search_params {
     float *prior_trace;         /* optional f32[G][S+1][A]: priors written by each expansion   */
     unsigned long long *stamps; /* optional u64[32]: shader-clock cycles workgroup 0 spent per
                                    stage (diagnostics; leave NULL in production)               */
+    float *z_pool;              /* f32[G][S+1][D], required when pool->latent is NULL: per tree
+                                   and expansion the ONE row z = fc_merge.weight[:, :D] latent
+                                   from which the A children's latents are relu(z + table[a])  */
 } mz_search_params;
 
-/* Requires pool->latent, pool->cap >= 1 + (S+1)*A, A <= 32.  policy f64[G][A], policy32
- * f32[G][A], value f64[G], visits i32[G][A] as in mz_tree_result (any may be NULL). */
+/* Requires pool->cap >= 1 + (S+1)*A, A <= 32, and either pool->latent (every node's latent is
+ * stored, as Node.latent_state holds it: src/search/expansion.py:25-33) or prm->z_pool with
+ * pool->latent == NULL (implicit child latents: an expansion stores one row instead of A, and a
+ * selected leaf's latent is formed from its parent's row when it is expanded -- the same float32
+ * values, so both forms leave bit-identical trees and results; only the drop-in MCTS.run, whose
+ * callers read node latents, needs the first).  policy f64[G][A], policy32 f32[G][A], value
+ * f64[G], visits i32[G][A] as in mz_tree_result (any may be NULL). */
 int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob,
                   const mz_search_params *prm, double *policy, float *policy32, double *value,
                   int32_t *visits, void *stream);

@@ -71,7 +71,7 @@ class SearchParams(C.Structure):
                 ("log_tab", C.c_void_p), ("root_latent", C.c_void_p), ("root_to_play", C.c_void_p),
                 ("eta", C.c_void_p), ("rand_child", C.c_void_p), ("leaf_trace", C.c_void_p),
                 ("child_trace", C.c_void_p), ("rollout_trace", C.c_void_p), ("prior_trace", C.c_void_p),
-                ("stamps", C.c_void_p)]
+                ("stamps", C.c_void_p), ("z_pool", C.c_void_p)]
 
 
 MAX_BLOCKS = 4

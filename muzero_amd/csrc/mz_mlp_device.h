@@ -49,6 +49,14 @@
 
 #include "muzero_hip.h"
 
+#ifdef MZ_DENSE_TIMELINE
+// diagnostic build: shader-clock stamps of the most recent matrix-layer call of each wave
+__shared__ unsigned long long mz_tl[8][8];
+#define MZ_TL(slot) if ((threadIdx.x & 63) == 0) mz_tl[threadIdx.x >> 6][slot] = clock64();
+#else
+#define MZ_TL(slot)
+#endif
+
 namespace mzd {
 
 constexpr int kWaves = 8;
@@ -57,6 +65,10 @@ constexpr int kThreads = kWaves * 64;
 #define MZ_PREFETCH 2
 #endif
 constexpr int kPrefetch = MZ_PREFETCH;  // k-chunks of weights per batch held in registers ahead of the MFMAs
+#ifndef MZ_PREFETCH_TALL
+#define MZ_PREFETCH_TALL 3
+#endif
+constexpr int kPrefetchTall = MZ_PREFETCH_TALL;  // the same for row tiles of 64 rows and more (one column tile at a time)
 #ifndef MZ_WEIGHT_SETS
 #define MZ_WEIGHT_SETS 2
 #endif
@@ -191,9 +203,9 @@ struct DensePart {
     int row_add_ld;
     const lds_i *row_sel;
     // Optional folded scalar layer: instead of storing Y, the epilogue multiplies act(Y) by the
-    // weights of a following one-output layer (fp32 tiles at dot_w_off) and leaves the sum
-    // over this tile's 16 columns in dot_out[tile][row] (row stride 16*MT); finish_dot() adds
-    // the tiles.  dot_w_off < 0: plain layer.
+    // weights of a following one-output layer (fp32 tiles at dot_w_off) and leaves the sums over
+    // the four quarters of this tile's 16 columns in dot_out[4 tile + quarter][row] (row stride
+    // 16*MT); finish_dot() adds them.  dot_w_off < 0: plain layer.
     int dot_w_off;
     lds_f *dot_out;
     __device__ __forceinline__ DensePart uniform() const {
@@ -264,9 +276,8 @@ __device__ __forceinline__ void store_tile(const f32x4 (&hi)[MT], const f32x4 (&
             s += __fmul_rn(v.y, w2.y);
             s += __fmul_rn(v.z, w2.z);
             s += __fmul_rn(v.w, w2.w);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (rq == 0) P.dot_out[nt * (16 * MT) + row] = s;
+            // one partial sum per (tile, quarter of its columns, row): no lane exchange; finish_dot adds them
+            P.dot_out[(nt * 4 + rq) * (16 * MT) + row] = s;
             continue;
         }
         if (P.Ys != nullptr) *reinterpret_cast<lds_f4 *>(P.Ys + row * P.ldy + col0) = v;
@@ -314,7 +325,7 @@ __device__ __forceinline__ DensePart pick_part(const DensePart (&parts)[NPARTS],
 template <int MT, int NTW, int NPARTS>
 __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC, const float *__restrict__ packed,
                                              const DensePart (&parts)[NPARTS], int first_tile, int ngroups) {
-    constexpr int KP = MT >= 4 ? 1 : kPrefetch;
+    constexpr int KP = MT >= 4 ? kPrefetchTall : kPrefetch;
     const int lane = threadIdx.x & 63;
     const int nb = (KC + KP - 1) / KP;  // batches per tile group
     const int total = ngroups * nb;
@@ -424,6 +435,7 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
         if (++cb == nb) {
             cb = 0;
             ++cg;
+            if (cg == ngroups) { MZ_TL(4) }
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
                 store_tile<MT>(acc_hi[t], acc_lo[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
@@ -432,17 +444,21 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
     // NS register sets rotate: NS - 1 batches are in flight while one is consumed.
     constexpr int NS = kWeightSets;
     f32x4 w[NS][NTW][KP][2];
+    MZ_TL(1)
     // the weights have the longest way: requested before the operand pipeline is primed
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u) fetch(w[u]);
     read_x(0, xh, xl);
+    MZ_TL(2)
     for (int i = 0; i < total; i += NS) {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             fetch(w[(u + NS - 1) % NS]);
             if (i + u < total) compute(w[u]);
+            if (i == 0 && u == 0) { MZ_TL(3) }
         }
     }
+    MZ_TL(5)
 }
 
 // Entry points (not inlined: own register allocation).  Kp is shared by all parts.  No
@@ -478,6 +494,7 @@ __device__ MZ_DENSE_CALL void dense_group1_impl(const lds_f *xs, int x_tile, con
                                                 int N, int Np, int act, lds_f *Ys, int ldy, lds_f *Ss, int s_tile, int s_kc,
                                                 const lds_f *row_add, int row_add_ld, const lds_i *row_sel, int dot_w,
                                                 lds_f *dot_out, int wave0, int nwaves) {
+    MZ_TL(0)
     const DensePart parts[1] = {
         DensePart{w_off, b_off, N, Np, act, Ys, ldy, Ss, s_tile, s_kc, row_add, row_add_ld, row_sel, dot_w, dot_out}.uniform()};
     dense_group_body<MT, 1>(uni_lds(xs), uni(x_tile), uni_ptr(packed), uni(Kp), parts, uni(wave0), uni(nwaves));
@@ -487,6 +504,7 @@ __device__ MZ_DENSE_CALL void dense_group2_impl(const lds_f *xs, int x_tile, con
                                                 int Np0, int act0, lds_f *Y0, int ldy0, lds_f *S0, int st0, int sk0, int dw0,
                                                 lds_f *do0, int w1, int b1, int N1, int Np1, int act1, lds_f *Y1, int ldy1,
                                                 lds_f *S1, int st1, int sk1, int dw1, lds_f *do1, int wave0, int nwaves) {
+    MZ_TL(0)
     const DensePart parts[2] = {DensePart{w0, b0, N0, Np0, act0, Y0, ldy0, S0, st0, sk0, nullptr, 0, nullptr, dw0, do0}.uniform(),
                                 DensePart{w1, b1, N1, Np1, act1, Y1, ldy1, S1, st1, sk1, nullptr, 0, nullptr, dw1, do1}.uniform()};
     dense_group_body<MT, 2>(uni_lds(xs), uni(x_tile), uni_ptr(packed), uni(Kp), parts, uni(wave0), uni(nwaves));
@@ -506,14 +524,16 @@ __device__ __forceinline__ void dense_group2(const lds_f *xs, int ldx, const flo
                           q.dot_w_off, q.dot_out, tm.wave0, tm.nwaves);
 }
 
-// Second half of a folded scalar layer: out[row * out_ld] = act(bias + sum over the tiles of
-// dot[tile][row]), tiles in ascending order.  `rows` = 16*MT of the producing call.  No sync.
+// Floats of the partial-sum buffer of a folded layer with `tiles` column tiles over `rows` rows.
+__host__ __device__ inline int dot_floats(int tiles, int rows) { return 4 * tiles * rows; }
+// Second half of a folded scalar layer: out[row * out_ld] = act(bias + sum over the tiles' quarter sums
+// dot[4 tile + quarter][row] in ascending order).  `rows` = 16*MT of the producing call.  No sync.
 __device__ __forceinline__ void finish_dot(const lds_f *dot, int tiles, int rows, const float *__restrict__ packed,
                                            const mz_packed_layer &L1, lds_f *out, int out_ld, const Team &tm) {
     const float b = packed[L1.b_off];
     for (int r = tm.tid(); r < rows; r += tm.nthreads()) {
         float s = 0.0f;
-        for (int t = 0; t < tiles; ++t) s += dot[t * rows + r];
+        for (int t = 0; t < 4 * tiles; ++t) s += dot[t * rows + r];
         out[r * out_ld] = activate(s + b, L1.act);
     }
 }

@@ -148,6 +148,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                               Pk.value.layer[0].Kp == Pk.reward.layer[0].Kp;
     (void)val_layers;
     const int ld_d = L.ld_d;
+    const bool implicit = p.latent == nullptr;  // children kept as their parent's merge row (q.z_pool)
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * kTrees;
     const int trees = min(kTrees, p.G - g0);
@@ -231,6 +232,12 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         // few times much later: streaming (non-temporal) stores keep them from displacing the
         // weights and tree statistics in L2
         if (MZ_SKIP(7)) {
+        } else if (implicit) {
+            // one row per tree instead of A: the children's latents are relu(z + table[a]) of it
+            for (int i = ttid; i < trees * D; i += tn) {
+                const int t = i / D, c = i - t * D;
+                q.z_pool[((size_t)(g0 + t) * (S + 1) + e) * D + c] = Z[t * ld_d + c];
+            }
         } else if ((D & 3) == 0) {
             // one (tree, action) row per wave and pass, lanes along the latent: the row index is
             // wave-uniform, so the index arithmetic stays on the scalar unit
@@ -299,12 +306,13 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                 const mz_packed_layer L0 = load_layer(P.reward.layer[0]), L1 = load_layer(P.reward.layer[1]);
                 dense_group1<MTC>(R, ld_d, blob, L0.Kp, make_dot_part(L0, L1, DotE), tm);
                 tm.sync();
+                MZ_TL(6)
                 MZ_STAMP(7)  // expand: reward layer 1 over 16*A children
                 const float b2 = blob[L1.b_off];
                 const int tiles = L0.Np >> 4;
-                for (int r = ttid; r < kTrees * MTC; r += tn) {
+                for (int r = ttid; r < kTrees * MTC; r += tn) {  // as finish_dot
                     float sum = 0.0f;
-                    for (int k = 0; k < tiles; ++k) sum += DotE[k * (kTrees * MTC) + r];
+                    for (int k = 0; k < 4 * tiles; ++k) sum += DotE[k * (kTrees * MTC) + r];
                     s_rew[(r % kTrees) * L.tab_rows + a0 + r / kTrees] = activate(sum + b2, L1.act);
                 }
                 tm.sync();
@@ -381,6 +389,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                             make_dot_part(R0, R1l, DotS), tm);
             tm.sync();
             finish_dot(DotS, R0.Np >> 4, kTrees, blob, R1l, s_roll + (depth - 1), depth + 1, tm);
+            MZ_TL(6)
             MZ_STAMP(17)  // simulate: reward head | value layer 1
             if (fold_v) {
                 finish_dot(DotV, V0.Np >> 4, kTrees, blob, V1l, s_roll + depth, depth + 1, tm);
@@ -426,7 +435,7 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
         float v = 0.0f;
         if (t < trees && c < D) {
             v = q.root_latent[(size_t)(g0 + t) * D + c];
-            p.latent[((size_t)(g0 + t) * p.cap) * D + c] = v;
+            if (!implicit) p.latent[((size_t)(g0 + t) * p.cap) * D + c] = v;
         }
         X32[i] = v;
     }
@@ -489,6 +498,39 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
                 if (q.child_trace && t < trees) q.child_trace[(size_t)(g0 + t) * S + (e - 1)] = base + rc;
             }
             if (MZ_SKIP(5)) {
+            } else if (implicit) {
+                // node n >= 1 is child a = (n - 1) % A of expansion (n - 1) / A (lock step: every expansion adds A
+                // nodes): its latent is relu(z_pool[expansion] + table[a]), formed straight into the split image
+                for (int i = tid; i < KCd * 64; i += kThreads) {
+                    const int l = i & 63, c = i >> 6, t = l & 15;
+                    const int k0 = 32 * c + 8 * (l >> 4);
+                    const int n = max(s_leaf[t] - 1, 0), ex = n / A, a = n - ex * A;
+                    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                    if (t < trees && k0 < Dp16) {
+                        const float *zr = q.z_pool + ((size_t)(g0 + t) * (S + 1) + ex) * D + k0;
+                        const lds_f *tr = Tab + a * ld_d + k0;
+                        float z[8];
+                        if ((D & 3) == 0) {
+                            const float4 z0 = k0 < D ? *reinterpret_cast<const float4 *>(zr) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float4 z1 = k0 + 4 < D ? *reinterpret_cast<const float4 *>(zr + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            z[0] = z0.x, z[1] = z0.y, z[2] = z0.z, z[3] = z0.w, z[4] = z1.x, z[5] = z1.y, z[6] = z1.z, z[7] = z1.w;
+                        } else {
+                            for (int j = 0; j < 8; ++j) z[j] = k0 + j < D ? zr[j] : 0.0f;
+                        }
+                        // columns D .. Dp16 of a merge pre-activation are zero, as is the table there
+                        v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
+                        v1 = f32x4{fmaxf(z[4] + tr[4], 0.f), fmaxf(z[5] + tr[5], 0.f), fmaxf(z[6] + tr[6], 0.f), fmaxf(z[7] + tr[7], 0.f)};
+                    }
+                    f32x4 hi, lo;
+                    split8(v0, v1, hi, lo);
+                    lds_f *qd = X + c * kChunkFloats + l * 4;
+                    *reinterpret_cast<lds_f4 *>(qd) = hi;
+                    *reinterpret_cast<lds_f4 *>(qd + KCd * kChunkFloats) = lo;
+                    if (L.need_x32) {
+                        *reinterpret_cast<lds_f4 *>(X32 + t * ld_d + k0) = v0;
+                        *reinterpret_cast<lds_f4 *>(X32 + t * ld_d + k0 + 4) = v1;
+                    }
+                }
             } else if ((D & 3) == 0) {  // 16-byte rows: one tree per wave and pass, one float4 per lane
                 const int q4 = ld_d >> 2, d4 = D >> 2;
                 const int wv = uni(tid >> 6), lane = tid & 63;
@@ -512,8 +554,10 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
 
         // ---- the leaf's policy layer 1 and merge layer share the input: whole workgroup --------
         Team all = whole_workgroup();
-        rows_to_split(X32, ld_d, X, ld_d, 1, KCd, ld_d, all);
-        __syncthreads();
+        if (e == 0 || !implicit) {  // (the implicit gather wrote the image itself)
+            rows_to_split(X32, ld_d, X, ld_d, 1, KCd, ld_d, all);
+            __syncthreads();
+        }
         lds_f *pol_in = He1;
         if (!MZ_SKIP(3)) pol_in = first_layers(all, X, X32, He1, He2, Z);
         MZ_STAMP(3)  // expand: policy layer 1 | merge
@@ -588,6 +632,9 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
     if (stamping) {
         __syncthreads();
         if (threadIdx.x < 32) q.stamps[threadIdx.x] = s_stamp[threadIdx.x];
+#ifdef MZ_DENSE_TIMELINE
+        if (threadIdx.x < 64) q.stamps[32 + threadIdx.x] = mz_tl[threadIdx.x >> 3][threadIdx.x & 7];
+#endif
     }
 #undef MZ_STAMP
 }
@@ -598,8 +645,10 @@ extern "C" {
 
 int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
                   double *policy, float *policy32, double *value, int32_t *visits, void *stream) {
-    MZ_TRY(mz::check_pool(pool, true));
+    MZ_TRY(mz::check_pool(pool, false));
     if (!plan || !blob || !prm) return mz::fail(MZ_ERR_ARG, "mz_search_run: NULL argument");
+    if (pool->D <= 0 || (!pool->latent && !prm->z_pool))
+        return mz::fail(MZ_ERR_ARG, "mz_search_run: the pool has no latent storage (D=%d) and no z_pool is given", pool->D);
     if (plan->D != pool->D || plan->A != pool->A)
         return mz::fail(MZ_ERR_ARG, "mz_search_run: pool (D=%d, A=%d) and networks (D=%d, A=%d) disagree", pool->D,
                         pool->A, plan->D, plan->A);

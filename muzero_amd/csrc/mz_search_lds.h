@@ -61,9 +61,9 @@ __host__ __device__ inline Lds lds_layout(const mz_packed_nets &P, int mtc, int 
     L.fold_reward = (P.reward.n_layers == 2 && tail_foldable(P.reward)) ? 1 : 0;
     L.ra = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * L.ld_r);
     L.rb = take(L.fold_reward ? 0 : sizeof(float) * L.rows_r * L.ld_r);
-    L.dot = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * L.rows_r : 0);
-    L.dots = take(L.fold_reward ? sizeof(float) * (P.reward.layer[0].Np >> 4) * kTrees : 0);
-    L.dotv = take(P.value.n_layers == 2 && tail_foldable(P.value) ? sizeof(float) * (P.value.layer[0].Np >> 4) * kTrees : 0);
+    L.dot = take(L.fold_reward ? sizeof(float) * dot_floats(P.reward.layer[0].Np >> 4, L.rows_r) : 0);
+    L.dots = take(L.fold_reward ? sizeof(float) * dot_floats(P.reward.layer[0].Np >> 4, kTrees) : 0);
+    L.dotv = take(P.value.n_layers == 2 && tail_foldable(P.value) ? sizeof(float) * dot_floats(P.value.layer[0].Np >> 4, kTrees) : 0);
     L.nets = take(sizeof(mz_packed_nets) + sizeof(int) * 3 * MZ_MAX_LAYERS);  // plan + narrow-layer offsets
     L.prior = take(sizeof(float) * kTrees * A);
     L.rew = take(sizeof(float) * kTrees * L.tab_rows);

@@ -260,12 +260,18 @@ class BatchedMCTS:
                  discount: float, noise_frac: float, device="cuda", keep_latents: bool = True):
         """keep_latents=False: with networks in bottleneck form (muzero_amd.towers) the non-root nodes'
         latents are kept only as their bottleneck values (`t_pool`); `pool.latent` then holds the
-        roots alone.  The search result does not depend on it."""
+        roots alone.  With the MLP networks (`PackedNetworks`) the single-launch search keeps, per
+        expansion, the one merge pre-activation row its A children's latents are formed from
+        (`z_pool`) and the pool holds no latents at all (`implicit`); such an engine runs fused searches
+        only.  The search result does not depend on it: the trees are bit-identical."""
         self.nets = nets
         self.G, self.S, self.depth = G, num_simulations, model_look_ahead
         self.discount, self.noise_frac = discount, noise_frac
         self.A, self.D = nets.A, nets.D
-        self.pool = TreePool(G, self.A, num_simulations, self.D, device=device)
+        self.implicit = (not keep_latents) and isinstance(nets, PackedNetworks) and self.A <= 32
+        self.pool = TreePool(G, self.A, num_simulations, self.D, device=device, with_latent=not self.implicit)
+        self.z_pool = (torch.empty((G, num_simulations + 1, self.D), dtype=torch.float32, device=self.pool.device)
+                       if self.implicit else None)
         dev = self.pool.device
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -577,6 +583,9 @@ class BatchedMCTS:
         if fused and not fusable:
             raise NotImplementedError("the single-launch search covers the MLP-only networks; "
                                       "these networks run in lock step (fused=False)")
+        if self.implicit and not fused:
+            raise NotImplementedError("an engine built with keep_latents=False stores no node latents: the lock-step "
+                                      "kernels need them (fused=True, or keep_latents=True)")
         if fused:
             return self.run_fused(root_latent, root_to_play, eta, rand_child, trace)
         if trace is None and self._replay_whole(root_to_play, eta, rand_child, root_t):
@@ -634,7 +643,7 @@ class BatchedMCTS:
         prm = _hip.SearchParams(S, self.depth, pool.tab_len, 0, float(self.discount), float(self.noise_frac),
                                 ptr(pool.sqrt_tab), ptr(pool.log_tab), ptr(root_latent), ptr(root_to_play), ptr(eta),
                                 ptr(rand_child), ptr(t_leaf), ptr(t_child), ptr(t_roll), ptr(t_prior),
-                                ptr(self.stamps))
+                                ptr(self.stamps), ptr(self.z_pool))
         policy = torch.empty((G, A), dtype=torch.float64, device=dev)
         policy32 = torch.empty((G, A), dtype=torch.float32, device=dev)
         value = torch.empty(G, dtype=torch.float64, device=dev)

@@ -312,3 +312,52 @@ def test_ragged_and_minimal_batches(G, S, depth):
     for name in ("visit", "value_sum", "prior", "reward", "latent"):
         assert torch.equal(getattr(pools[0][0].pool, name), getattr(pools[1][0].pool, name)), name
     assert torch.equal(pools[0][1].policy32, pools[1][1].policy32)
+
+
+@pytest.mark.parametrize("which,G,S,depth", [("c4", 100, 50, 1), ("c4", 4100, 6, 2), ("tiny", 33, 25, 2), ("odd", 21, 12, 1),
+                                             ("wide", 19, 6, 0)])
+def test_implicit_child_latents_leave_identical_trees(which, G, S, depth):
+    """keep_latents=False (one merge pre-activation row per expansion instead of A child latents; a leaf's
+    latent is formed from its parent's row when it is expanded, src/search/expansion.py:25-33): every tree
+    statistic and every result equals the run that stores all latents, bit for bit, and the search's own
+    network outputs replay through the oracle."""
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    if which == "c4":
+        _, g, f = _c4_nets(2)
+        latent_shape = (4, 6, 7)
+    elif which == "tiny":
+        g, f = _custom_nets((2, 3, 3), 5, [16], [16], [16])
+        latent_shape = (2, 3, 3)
+    elif which == "odd":
+        g, f = _custom_nets((1, 1, 8), 3, [], [33], [17, 9, 40], ("tanh", "sigmoid", "relu"))
+        latent_shape = (1, 1, 8)
+    else:
+        g, f = _custom_nets((2, 4, 4), 18, [24, 12], [8], [24], ("relu",))
+        latent_shape = (2, 4, 4)
+    A, D = g.num_actions, int(np.prod(latent_shape))
+    nets = PackedNetworks(g, f)
+    lat, eta, rand, to_play = _inputs(G, A, S, D, seed=11 * G + S)
+    args = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
+    a = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25)
+    b = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25, keep_latents=False)
+    assert b.implicit and b.pool.latent is None and not a.implicit
+    ra = a.run(*args)
+    trace = {}
+    rb = b.run(*args, trace=trace)
+    torch.cuda.synchronize()
+    for name in ("visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes"):
+        assert torch.equal(getattr(a.pool, name), getattr(b.pool, name)), name
+    assert torch.equal(ra.policy, rb.policy) and torch.equal(ra.value, rb.value) and torch.equal(ra.visits, rb.visits)
+    assert torch.equal(ra.policy32, rb.policy32)
+    _replay_through_oracle(b, nets, rb, trace, lat, eta, rand, to_play, depth, 0.25, 0.997)
+    # the rows it kept are the merge pre-activations the explicit run formed its children from
+    zp = b.z_pool.cpu()
+    lat_a = a.pool.latent.cpu()
+    with torch.no_grad():
+        table = g.fc_merge.weight[:, D:] @ g.action_embedding.weight.t() + g.fc_merge.bias[:, None]   # [D, A]
+    for e in (0, S):
+        kids = lat_a[:, 1 + e * A:1 + (e + 1) * A]                                                     # [G, A, D]
+        want = torch.relu(zp[:, e, None, :] + table.t()[None])
+        np.testing.assert_allclose(kids.numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        b.run(*args, fused=False)

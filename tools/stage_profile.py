@@ -20,7 +20,7 @@ def main():
     rand = torch.from_numpy(bench.child_choice_streams(G, S, 0)).cuda()
     for _ in range(2):
         mcts.run(latent, to_play, eta, rand)
-    mcts.stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
+    mcts.stamps = torch.zeros(96, dtype=torch.int64, device="cuda")
     mcts.run(latent, to_play, eta, rand)
     torch.cuda.synchronize()
     st = mcts.stamps.cpu().numpy()
@@ -29,6 +29,12 @@ def main():
         v = st[k]
         print(f"{NAMES[k]:28s} {v:12d} cycles  {100*v/tot:5.1f}%   {v/(S+1):9.0f} /round")
     print("total (thread 0)", tot)
+    tl = st[32:].reshape(8, 8)
+    if tl.any():  # diagnostic build (-DMZ_DENSE_TIMELINE): the last matrix-layer call of each wave
+        print("wave: entry->issue, ->first fetch issued, ->first batch consumed, ->last batch consumed, ->epilogue done, ->after sync")
+        for w in range(8):
+            t = tl[w]
+            print(w, [int(t[i + 1] - t[i]) for i in range(6)], "(slots 0..6)")
 
 
 main()
