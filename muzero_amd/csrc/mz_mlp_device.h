@@ -66,9 +66,14 @@ constexpr int kThreads = kWaves * 64;
 #endif
 constexpr int kPrefetch = MZ_PREFETCH;  // k-chunks of weights per batch held in registers ahead of the MFMAs
 #ifndef MZ_PREFETCH_TALL
-#define MZ_PREFETCH_TALL 3
+#define MZ_PREFETCH_TALL 1
 #endif
 constexpr int kPrefetchTall = MZ_PREFETCH_TALL;  // the same for row tiles of 64 rows and more (one column tile at a time)
+constexpr int kTallTiles = 3;  // row tiles of 16 * kTallTiles rows and more take the "tall" form of the matrix routine
+#ifndef MZ_WEIGHT_SETS_TALL
+#define MZ_WEIGHT_SETS_TALL 4
+#endif
+constexpr int kWeightSetsTall = MZ_WEIGHT_SETS_TALL;
 #ifndef MZ_WEIGHT_SETS
 #define MZ_WEIGHT_SETS 2
 #endif
@@ -322,10 +327,12 @@ __device__ __forceinline__ DensePart pick_part(const DensePart (&parts)[NPARTS],
 // Per accumulator the instruction sequence is fixed -- chunks ascending; per chunk hi_w*hi_x,
 // then hi_w*lo_x and lo_w*hi_x into the cross-term accumulator -- whatever MT, NTW or the caller:
 // every kernel built on this routine produces the same bits.
+// The wave's tiles are first_tile .. first_tile + ntiles - 1, walked in ngroups = ceil(ntiles / NTW) groups; a last
+// group that is not full repeats the wave's last tile in its unused places (fetched and multiplied, not stored).
 template <int MT, int NTW, int NPARTS>
 __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC, const float *__restrict__ packed,
-                                             const DensePart (&parts)[NPARTS], int first_tile, int ngroups) {
-    constexpr int KP = MT >= 4 ? kPrefetchTall : kPrefetch;
+                                             const DensePart (&parts)[NPARTS], int first_tile, int ngroups, int ntiles) {
+    constexpr int KP = MT >= kTallTiles ? kPrefetchTall : kPrefetch;
     const int lane = threadIdx.x & 63;
     const int nb = (KC + KP - 1) / KP;  // batches per tile group
     const int total = ngroups * nb;
@@ -348,7 +355,7 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             int part, nt;
-            locate(first_tile + fg * NTW + t, part, nt);
+            locate(first_tile + min(fg * NTW + t, ntiles - 1), part, nt);
             fbase[t] = (glb_f4 *)(packed + pick_part(parts, part).w_off) + (size_t)nt * KC * 128;
         }
     };
@@ -398,7 +405,7 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
         if (cb == 0) {
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                locate(first_tile + cg * NTW + t, c_part[t], c_nt[t]);
+                locate(first_tile + min(cg * NTW + t, ntiles - 1), c_part[t], c_nt[t]);
                 // requested now, needed only by the epilogue after the last batch
                 bias[t] = *(glb_f4 *)(packed + pick_part(parts, c_part[t]).b_off + c_nt[t] * 16 + 4 * (lane >> 4));
 #pragma unroll
@@ -415,7 +422,14 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
             const bool valid = kc0 + k < KC;
             const int kn = (kc0 + k + 1 < KC) ? kc0 + k + 1 : 0;
             f32x4 nh[MT], nl[MT];
-            read_x(kn, nh, nl);
+            if constexpr (MT >= kTallTiles) {  // tall row tiles: no room for two sets of operands; the other wave of the SIMD covers the read
+                if (valid) read_x(kc0 + k, xh, xl);
+            } else {
+                read_x(kn, nh, nl);
+            }
+            // every operand read of the step is issued before its matrix instructions (left to itself the
+            // scheduler re-uses one register set and waits for each read in turn)
+            if constexpr (MT <= 4) __builtin_amdgcn_sched_barrier(0);
             if (valid) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -429,8 +443,10 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
                     }
                 }
             }
+            if constexpr (MT < 4) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xh[mt] = nh[mt], xl[mt] = nl[mt];
+                for (int mt = 0; mt < MT; ++mt) xh[mt] = nh[mt], xl[mt] = nl[mt];
+            }
         }
         if (++cb == nb) {
             cb = 0;
@@ -438,17 +454,18 @@ __device__ __forceinline__ void stream_tiles(const lds_f *xs, int x_tile, int KC
             if (cg == ngroups) { MZ_TL(4) }
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
-                store_tile<MT>(acc_hi[t], acc_lo[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
+                if ((cg - 1) * NTW + t < ntiles)
+                    store_tile<MT>(acc_hi[t], acc_lo[t], c_nt[t], bias[t], pick_part(parts, c_part[t]), (glb_f *)packed);
         }
     };
     // NS register sets rotate: NS - 1 batches are in flight while one is consumed.
-    constexpr int NS = kWeightSets;
+    constexpr int NS = MT >= kTallTiles ? kWeightSetsTall : kWeightSets;
     f32x4 w[NS][NTW][KP][2];
     MZ_TL(1)
     // the weights have the longest way: requested before the operand pipeline is primed
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u) fetch(w[u]);
-    read_x(0, xh, xl);
+    if constexpr (MT < kTallTiles) read_x(0, xh, xl);
     MZ_TL(2)
     for (int i = 0; i < total; i += NS) {
 #pragma unroll
@@ -471,20 +488,18 @@ __device__ __forceinline__ void dense_group_body(const lds_f *xs, int x_tile, co
     int total = 0;
 #pragma unroll
     for (int i = 0; i < NPARTS; ++i) total += parts[i].Np >> 4;
-    // tiles are dealt as evenly as possible: waves w and w+4 usually share a SIMD, so the
-    // larger shares go to the first waves and every SIMD ends up with nearly the same count
+    // Tiles are dealt as evenly as possible (waves w and w+4 usually share a SIMD, so the larger shares go to
+    // the first waves and every SIMD ends up with nearly the same count) -- in units of what a wave walks at a
+    // time, so that every wave makes ONE pass over its share: a second pass would pay the start of a weight
+    // stream (a round trip to L2) again.
     const int lg = 31 - __builtin_clz(nwaves);
-    const int share = total >> lg, extra = total - (share << lg);
-    const int first = wave * share + min(wave, extra);
-    const int count = share + (wave < extra ? 1 : 0);
-    if (count <= 0) return;
-    if constexpr (MT >= 4) {  // tall row tiles: the accumulators and operands of one column tile fill the registers
-        stream_tiles<MT, 1, NPARTS>(xs, x_tile, KC, packed, parts, first, count);
-    } else {
-        const int pairs = count >> 1;
-        if (pairs > 0) stream_tiles<MT, 2, NPARTS>(xs, x_tile, KC, packed, parts, first, pairs);
-        if (count & 1) stream_tiles<MT, 1, NPARTS>(xs, x_tile, KC, packed, parts, first + 2 * pairs, 1);
-    }
+    constexpr int NTW = MT >= kTallTiles ? 1 : 2;  // tall row tiles: the accumulators and operands of one column tile fill the registers
+    const int units = (total + NTW - 1) / NTW;
+    const int share = units >> lg, extra = units - (share << lg);
+    const int first = (wave * share + min(wave, extra)) * NTW;
+    const int groups = share + (wave < extra ? 1 : 0);
+    if (groups <= 0) return;
+    stream_tiles<MT, NTW, NPARTS>(xs, x_tile, KC, packed, parts, first, groups, min(groups * NTW, total - first));
 }
 // Out-of-line entry points.  Every argument is a scalar: aggregates would be passed through
 // per-lane stack memory (written 64 times per wave and eventually to HBM), scalars travel in
