@@ -232,16 +232,14 @@ __device__ __forceinline__ DensePart make_dot_part(const mz_packed_layer &L, con
 
 // Epilogue of one 16-column tile.  C layout of the transposed product: row = lane & 15, columns
 // 16 nt + 4 (lane >> 4) + r for the lane's four values r.
+// w2: for a folded layer (P.dot_w_off >= 0) the one-output layer's weights of this lane's four columns.
 template <int MT>
-__device__ __forceinline__ void store_tile(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, const DensePart &P,
-                                           glb_f *packed_f) {
+__device__ __forceinline__ void store_tile_core(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, const DensePart &P,
+                                                const f32x4 &w2) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, rq = lane >> 4;
     const int col0 = nt * 16 + 4 * rq;
     const bool plain = P.act == MZ_ACT_RELU || P.act == MZ_ACT_NONE;  // act(0) = 0: padded columns need no select
-    f32x4 w2 = {0.f, 0.f, 0.f, 0.f};
-    if (P.dot_w_off >= 0)  // weights of columns col0 .. col0+3 in the fp32 tiles of the one-output layer (zero beyond N)
-        w2 = *(glb_f4 *)(packed_f + P.dot_w_off + (nt * 64 + 16 * rq) * 4);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + j;
@@ -300,6 +298,15 @@ __device__ __forceinline__ void store_tile(const f32x4 (&hi)[MT], const f32x4 (&
             }
         }
     }
+}
+
+template <int MT>
+__device__ __forceinline__ void store_tile(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, const DensePart &P,
+                                           glb_f *packed_f) {
+    f32x4 w2 = {0.f, 0.f, 0.f, 0.f};
+    if (P.dot_w_off >= 0)  // weights of columns 16 nt + 4 rq .. +3 in the fp32 tiles of the one-output layer (zero beyond N)
+        w2 = *(glb_f4 *)(packed_f + P.dot_w_off + (nt * 64 + 16 * ((threadIdx.x & 63) >> 4)) * 4);
+    store_tile_core<MT>(hi, lo, nt, b, P, w2);
 }
 
 // parts[part] without indexing the array by a run-time value (which would force the array

@@ -641,6 +641,9 @@ k_search(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search
 
 }  // namespace
 
+int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
+                      double *policy, float *policy32, double *value, int32_t *visits, void *stream);  // mz_search_seq.hip
+
 extern "C" {
 
 int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
@@ -667,6 +670,9 @@ int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *
     if (const char *e = getenv("MZ_SEARCH_SKIP")) q.lanes_per_tree |= atoi(e) << 8;
 #endif
     hipStream_t st = (hipStream_t)stream;
+    // the sequential-program form where it applies (same results), else the two-team kernel below
+    if (const int handled = mz_search_seq_try(pool, plan, blob, &q, policy, policy32, value, visits, stream))
+        return handled < 0 ? handled : MZ_OK;
     const int blocks = (pool->G + kTrees - 1) / kTrees;
     const int candidates[5] = {7, 4, 3, 2, 1};
     for (int mtc : candidates) {

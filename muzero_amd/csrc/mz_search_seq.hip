@@ -1,0 +1,724 @@
+// Second form of the single-launch search (src/search/mcts.py:44-74 for G trees): the same
+// arithmetic as k_search (mz_search.hip) for the network shape the benchmark configuration and
+// the reference's config.yaml heads have, organised around the resource that bounds that kernel.
+//
+// A 16-tree workgroup reads ~1.7 MB of packed weights per simulation round for 16 rows of work.
+// They come from L2 (the whole model is 1 MB) into registers at no more than ~60 bytes per clock
+// and compute unit, every matrix step starts with a round trip to L2, and with two teams of waves
+// running different chains the port idles through their start-ups, epilogues and syncs and is
+// saturated when both stream.  Here all eight waves run ONE sequential program per round:
+//
+//   select, leaf latent          (implicit child latents: formed from the parent's merge row)
+//   {policy 1 | merge}(leaf)
+//   {policy 1 | merge}(drawn child)
+//   policy 2 for leaf AND child as one 32-row pass      (its weights are read once, not twice)
+//   policy 3 (narrow, vector ALU) for the 32 rows, softmax; priors of the leaf, greedy action of the child
+//   value 1 (rollout latent)
+//   value 2 | reward 1 over the A children AND the rollout latent, in passes of four row tiles with
+//   the wave's reward-1 weights held in registers across the passes           (read once per round)
+//   child records, backup
+//
+// Weights flow through a ring of two register slots per wave, a whole column tile (all its
+// k-chunks, 12-16 KiB per wave) per slot: while one tile is multiplied the next is in flight, and
+// the ring runs on ACROSS steps -- the first tile of the next step is requested before the current
+// step's epilogue, barrier and the vector work between the steps, so no step starts with an
+// exposed round trip.  Biases and the folded one-output layers' weights are staged in LDS once:
+// inside a round the only global loads are the ring's (a small load issued behind a tile fetch
+// would wait for the whole tile).  Steps are separated by workgroup barriers (no wave teams).
+//
+// Per accumulator the instruction sequence is the one stream_tiles (mz_mlp_device.h) issues and
+// the epilogues are store_tile_core: node records, priors, rewards and rollouts equal k_search's
+// and the per-stage kernels' bit for bit (tests/test_gpu_search.py).
+//
+// Covers: implicit child latents (pool->latent == NULL), model_look_ahead = 1, policy head
+// [matrix, matrix, narrow softmax], value head [matrix, matrix, 1] and reward head [matrix, 1]
+// with the last two layers folded, relu after every matrix layer, at most 8 column tiles in value 2 and reward 1, k-chunk counts
+// matching an instantiation below.  mz_search_run falls back to k_search for everything else.
+//
+// Compiled with -ffp-contract=off (every rounding is part of the contract).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "mz_common.h"
+#include "mz_mlp_device.h"
+#include "mz_search_lds.h"
+#include "mz_tree_device.h"
+
+using namespace mzd;
+using namespace mzs;
+
+namespace {
+
+constexpr int kPassTiles = 4;  // row tiles per pass of reward 1 over {children, rollout latent}
+
+struct SeqLds {
+    int ld_d, ld_p, ld_q, ld_v, ld_l, tab_rows;
+    // byte offsets.  xi: split image of the current input latents (leaf, drawn child, rollout latent in turn);
+    // z / zs: merge pre-activations of the leaf / of the drawn child (fp32 rows); h1: policy layer 1 of leaf
+    // (tile 0) and child (tile 1), split image; h2: policy layer 2 of the 32 rows (fp32 rows); r: split images
+    // of a pass's row tiles, over h1 | h2 (dead by then); hv: value layer 1 (split image); lg: logits / policies
+    // of the 32 rows; dote / dotv: partial sums of the folded layers; bias*: padded biases; dw*: the folded
+    // one-output layers' weights by k; nw: LDS copy of the narrow policy layer's weights
+    size_t xi, z, zs, tab, h1, h2, r, hv, lg, dote, dotv, b_p0, b_m, b_p1, b_v0, b_v1, b_r0, dw_v, dw_r, nw, prior, rew, roll, ints, path,
+        tabs, total;
+};
+
+__host__ __device__ inline SeqLds seq_layout(const mz_packed_nets &P, int tab_len) {
+    SeqLds L;
+    const int A = P.A;
+    L.ld_d = lds_stride(P.D);
+    L.ld_p = lds_stride(P.policy.layer[0].N);
+    L.ld_q = lds_stride(P.policy.layer[1].N);
+    L.ld_v = lds_stride(P.value.layer[0].N);
+    L.ld_l = lds_stride(A);
+    L.tab_rows = A;
+    size_t off = sizeof(float) * kLdsReserve;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t tile_d = sizeof(float) * kTrees * L.ld_d;
+    L.xi = take(tile_d);
+    L.z = take(tile_d);
+    L.zs = take(tile_d);
+    L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
+    L.h1 = take(sizeof(float) * 2 * kTrees * L.ld_p);
+    L.h2 = take(sizeof(float) * 2 * kTrees * L.ld_q);
+    L.r = L.h1;
+    if (off < L.r + tile_d * kPassTiles) off = align16(L.r + tile_d * kPassTiles);
+    L.hv = take(sizeof(float) * kTrees * L.ld_v);
+    L.lg = take(sizeof(float) * 2 * kTrees * L.ld_l);
+    L.dote = take(sizeof(float) * dot_floats(P.reward.layer[0].Np >> 4, kTrees * kPassTiles));
+    L.dotv = take(sizeof(float) * dot_floats(P.value.layer[1].Np >> 4, kTrees));
+    L.b_p0 = take(sizeof(float) * P.policy.layer[0].Np);
+    L.b_m = take(sizeof(float) * P.merge.layer[0].Np);
+    L.b_p1 = take(sizeof(float) * P.policy.layer[1].Np);
+    L.b_v0 = take(sizeof(float) * P.value.layer[0].Np);
+    L.b_v1 = take(sizeof(float) * (P.value.layer[1].Np + 4));   // + the one-output layer's bias
+    L.b_r0 = take(sizeof(float) * (P.reward.layer[0].Np + 4));
+    L.dw_v = take(sizeof(float) * P.value.layer[1].Np);
+    L.dw_r = take(sizeof(float) * P.reward.layer[0].Np);
+    L.nw = take(sizeof(float) * narrow_lds_floats(P.policy.layer[2]));
+    L.prior = take(sizeof(float) * kTrees * A);
+    L.rew = take(sizeof(float) * kTrees * (A + 1));
+    L.roll = take(sizeof(float) * kTrees * 2);
+    L.ints = take(sizeof(int) * kTrees * 8);
+    L.path = take(sizeof(int) * kTrees * kPathCap);
+    L.tabs = take(sizeof(double) * 2 * tab_len);
+    L.total = off;
+    return L;
+}
+
+// One ring slot: a whole column tile of a matrix layer (up to KMAX k-chunks x two planes of 16 bytes per lane).
+template <int KMAX>
+struct Slot {
+    f32x4 w[KMAX][2];
+};
+
+template <int KC, int KMAX>
+__device__ __forceinline__ void fetch_tile(Slot<KMAX> &s, const float *tile, int lane) {
+    glb_f4 *b = (glb_f4 *)tile + lane;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        s.w[c][0] = b[(2 * c) * 64];
+        s.w[c][1] = b[(2 * c + 1) * 64];
+    }
+}
+
+// acc = tile x rows, the rows' split image at img (this lane's 16 bytes of chunk 0 of row tile 0), row tiles
+// x_tile floats apart.  Same instruction sequence per accumulator as stream_tiles.
+template <int KC, int MT, int KMAX>
+__device__ __forceinline__ void mma_tile(const Slot<KMAX> &s, const lds_f *img, int x_tile, f32x4 (&hi)[MT], f32x4 (&lo)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) hi[mt] = lo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const h8 wh = __builtin_bit_cast(h8, s.w[c][0]), wl = __builtin_bit_cast(h8, s.w[c][1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const lds_f *p = img + mt * x_tile + c * kChunkFloats;
+            const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p));
+            const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p + KC * kChunkFloats));
+            hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, hi[mt], 0, 0, 0);
+            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, lo[mt], 0, 0, 0);
+            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, lo[mt], 0, 0, 0);
+        }
+    }
+}
+
+// A float4 of an LDS array as a register value.
+__device__ __forceinline__ f32x4 lds4(const lds_f *p) { return *reinterpret_cast<const lds_f4 *>(p); }
+
+// Epilogues of one 16-column tile for layers whose activation is relu (RELU) or none: the arithmetic of
+// store_tile_core, step for step, without its run-time choices.  C layout: row = lane & 15, columns
+// 16 nt + 4 (lane >> 4) + r.
+template <bool RELU>
+__device__ __forceinline__ f32x4 epi_value(const f32x4 &hi, const f32x4 &lo, const f32x4 &b) {
+    f32x4 v;
+    v.x = (hi.x + __fmul_rn(lo.x, kLoUnscale)) + b.x;
+    v.y = (hi.y + __fmul_rn(lo.y, kLoUnscale)) + b.y;
+    v.z = (hi.z + __fmul_rn(lo.z, kLoUnscale)) + b.z;
+    v.w = (hi.w + __fmul_rn(lo.w, kLoUnscale)) + b.w;
+    if (RELU) {
+        v.x = v.x > 0.0f ? v.x : 0.0f;
+        v.y = v.y > 0.0f ? v.y : 0.0f;
+        v.z = v.z > 0.0f ? v.z : 0.0f;
+        v.w = v.w > 0.0f ? v.w : 0.0f;
+    }
+    return v;
+}
+// fp32 rows: Ys[row][16 nt + ..]
+template <int MT, bool RELU>
+__device__ __forceinline__ void epi_rows(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, lds_f *Ys, int ldy, int lane) {
+    const int j = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<lds_f4 *>(Ys + (mt * 16 + j) * ldy + nt * 16 + 4 * rq) = epi_value<RELU>(hi[mt], lo[mt], b);
+}
+// split image of the next layer's operand (row tiles s_tile floats apart, s_kc chunks per plane, nt_count column tiles)
+template <int MT, bool RELU>
+__device__ __forceinline__ void epi_split(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, lds_f *Ss, int s_tile,
+                                          int s_kc, int nt_count, int lane) {
+    const int j = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x2 h, l;
+        split4(epi_value<RELU>(hi[mt], lo[mt], b), h, l);
+        lds_f *img = Ss + mt * s_tile + (nt >> 1) * kChunkFloats + (2 * (nt & 1) + (rq >> 1)) * 64 + j * 4 + 2 * (rq & 1);
+        *reinterpret_cast<lds_f2 *>(img) = h;
+        *reinterpret_cast<lds_f2 *>(img + s_kc * kChunkFloats) = l;
+        if ((nt & 1) == 0 && nt + 1 == nt_count) {
+            const f32x2 z = {0.f, 0.f};
+            *reinterpret_cast<lds_f2 *>(img + 128) = z;
+            *reinterpret_cast<lds_f2 *>(img + 128 + s_kc * kChunkFloats) = z;
+        }
+    }
+}
+// folded one-output layer: partial sums dot[(4 nt + quarter) * 16 MT + row]
+template <int MT, bool RELU>
+__device__ __forceinline__ void epi_dot(const f32x4 (&hi)[MT], const f32x4 (&lo)[MT], int nt, const f32x4 &b, const f32x4 &w2, lds_f *dot,
+                                        int lane) {
+    const int j = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 v = epi_value<RELU>(hi[mt], lo[mt], b);
+        float s = __fmul_rn(v.x, w2.x);
+        s += __fmul_rn(v.y, w2.y);
+        s += __fmul_rn(v.z, w2.z);
+        s += __fmul_rn(v.w, w2.w);
+        dot[(nt * 4 + rq) * (16 * MT) + mt * 16 + j] = s;
+    }
+}
+
+// This wave's share of `total` column tiles, dealt in pairs (as dense_group_body): first tile and count.
+__device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int &count) {
+    const int units = (total + 1) >> 1;
+    const int share = units >> 3, extra = units - (share << 3);
+    first = (wave * share + min(wave, extra)) * 2;
+    const int groups = share + (wave < extra ? 1 : 0);
+    count = max(0, min(groups * 2, total - first));
+}
+
+template <int KCD, int KCP, int KCV>
+__global__ void __launch_bounds__(kThreads)
+k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q, SeqLds L,
+             double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
+             int32_t *__restrict__ visits) {
+    constexpr int KMAX = KCD > KCP ? (KCD > KCV ? KCD : KCV) : (KCP > KCV ? KCP : KCV);
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    lds_f *XI = to_lds(smem_raw + L.xi);
+    lds_f *Z = to_lds(smem_raw + L.z);
+    lds_f *Zs = to_lds(smem_raw + L.zs);
+    lds_f *Tab = to_lds(smem_raw + L.tab);
+    lds_f *H1 = to_lds(smem_raw + L.h1);
+    lds_f *H2 = to_lds(smem_raw + L.h2);
+    lds_f *R = to_lds(smem_raw + L.r);
+    lds_f *Hv = to_lds(smem_raw + L.hv);
+    lds_f *Lg = to_lds(smem_raw + L.lg);
+    lds_f *DotE = to_lds(smem_raw + L.dote);
+    lds_f *DotV = to_lds(smem_raw + L.dotv);
+    lds_f *Bp0 = to_lds(smem_raw + L.b_p0), *Bm = to_lds(smem_raw + L.b_m), *Bp1 = to_lds(smem_raw + L.b_p1);
+    lds_f *Bv0 = to_lds(smem_raw + L.b_v0), *Bv1 = to_lds(smem_raw + L.b_v1), *Br0 = to_lds(smem_raw + L.b_r0);
+    lds_f *DwV = to_lds(smem_raw + L.dw_v), *DwR = to_lds(smem_raw + L.dw_r);
+    lds_f *Nw = to_lds(smem_raw + L.nw);
+    lds_f *s_prior = to_lds(smem_raw + L.prior);
+    lds_f *s_rew = to_lds(smem_raw + L.rew);
+    lds_f *s_roll = to_lds(smem_raw + L.roll);
+    lds_i *s_leaf = to_lds_i(smem_raw + L.ints);
+    lds_i *s_child = s_leaf + kTrees;
+    lds_i *s_act = s_child + kTrees;    // action of the drawn child
+    lds_i *s_act2 = s_act + kTrees;     // greedy action of the rollout step
+    lds_i *s_leaf_tp = s_act2 + kTrees;
+    lds_i *s_depth = s_leaf_tp + kTrees;
+    lds_i *s_root = s_depth + kTrees;
+    int *s_path = reinterpret_cast<int *>(smem_raw + L.path);
+    double *s_tab = reinterpret_cast<double *>(smem_raw + L.tabs);
+
+    __shared__ unsigned long long s_stamp[32];
+    unsigned long long t_prev = 0;
+    const bool stamping = q.stamps != nullptr && blockIdx.x == 0;
+    if (stamping && threadIdx.x < 32) s_stamp[threadIdx.x] = 0;
+    if (stamping && threadIdx.x == 0) t_prev = clock64();
+#define MZ_STAMP(slot)                                       \
+    if (stamping && threadIdx.x == 0) {                      \
+        const unsigned long long t_now = clock64();          \
+        s_stamp[slot] += t_now - t_prev;                     \
+        t_prev = t_now;                                      \
+    }
+
+    const int A = Pk.A, D = Pk.D, S = q.S;
+    const int ld_d = L.ld_d, ld_p = L.ld_p, ld_q = L.ld_q, ld_v = L.ld_v, ld_l = L.ld_l;
+    const int wave = uni(threadIdx.x >> 6);
+    int tid = threadIdx.x, lane = tid & 63;  // (re-derived every round: see the round loop)
+    const int g0 = blockIdx.x * kTrees;
+    const int trees = min(kTrees, p.G - g0);
+    const int lpt = q.lanes_per_tree & 0xff;
+    const int Dp16 = Pk.merge.layer[0].Np;
+    // layers, as wave-uniform values
+    const mz_packed_layer Lp0 = Pk.policy.layer[0], Lp1 = Pk.policy.layer[1], Lp2 = Pk.policy.layer[2], Lm0 = Pk.merge.layer[0];
+    const mz_packed_layer Lv0 = Pk.value.layer[0], Lv1 = Pk.value.layer[1], Lv2 = Pk.value.layer[2];
+    const mz_packed_layer Lr0 = Pk.reward.layer[0], Lr1 = Pk.reward.layer[1];
+    const int np0 = Lp0.Np >> 4, nm0 = Lm0.Np >> 4, np1 = Lp1.Np >> 4, nv0 = Lv0.Np >> 4, nv1 = Lv1.Np >> 4, nr0 = Lr0.Np >> 4;
+    auto tile_of = [&](const mz_packed_layer &Ly, int KC, int nt) { return blob + Ly.w_off + (size_t)nt * KC * 512; };
+
+    // ---- one-time staging ----------------------------------------------------------------------
+    for (int i = tid; i < q.tab_len; i += kThreads) {
+        s_tab[i] = q.sqrt_tab[i];
+        s_tab[q.tab_len + i] = q.log_tab[i];
+    }
+    for (int i = tid; i < L.tab_rows * ld_d; i += kThreads) {
+        const int a = i / ld_d, c = i - a * ld_d;
+        Tab[i] = (a < A && c < Pk.Dp) ? blob[Pk.action_table_off + (size_t)a * Pk.Dp + c] : 0.0f;
+    }
+    stage_narrow(blob, Lp2, Nw);
+    auto stage_bias = [&](lds_f *dst, const mz_packed_layer &Ly) {
+        for (int i = tid; i < Ly.Np; i += kThreads) dst[i] = blob[Ly.b_off + i];
+    };
+    stage_bias(Bp0, Lp0), stage_bias(Bm, Lm0), stage_bias(Bp1, Lp1), stage_bias(Bv0, Lv0), stage_bias(Bv1, Lv1), stage_bias(Br0, Lr0);
+    if (tid == 0) {
+        Bv1[Lv1.Np] = blob[Lv2.b_off];
+        Br0[Lr0.Np] = blob[Lr1.b_off];
+    }
+    // the one-output layers' weights by k: fp32 tile kt holds W[0][16 kt + 4 q + j] in lane 16 q, element j
+    for (int k = tid; k < Lv1.Np; k += kThreads) DwV[k] = blob[Lv2.w_off + ((k >> 4) * 64 + 16 * ((k >> 2) & 3)) * 4 + (k & 3)];
+    for (int k = tid; k < Lr0.Np; k += kThreads) DwR[k] = blob[Lr1.w_off + ((k >> 4) * 64 + 16 * ((k >> 2) & 3)) * 4 + (k & 3)];
+    for (int i = tid; i < kTrees * ld_d; i += kThreads) {  // root latents as fp32 rows (Z is free until the first merge)
+        const int t = i / ld_d, c = i - t * ld_d;
+        Z[i] = (t < trees && c < D) ? q.root_latent[(size_t)(g0 + t) * D + c] : 0.0f;
+    }
+    if (tid < kTrees) {
+        int tp = 0;
+        if (tid < trees) {
+            const size_t o = (size_t)(g0 + tid) * p.cap;
+            tp = q.root_to_play[g0 + tid];
+            mzt::write_node(p, o, -1, tp, 0.0, 0.0f);
+        }
+        s_leaf[tid] = 0;
+        s_leaf_tp[tid] = tp;
+        s_root[tid] = tp;
+        s_depth[tid] = 0;
+        s_act[tid] = 0;
+        s_act2[tid] = 0;
+    }
+    __syncthreads();
+    rows_to_split(Z, ld_d, XI, ld_d, 1, KCD, ld_d, whole_workgroup());
+    __syncthreads();
+    MZ_STAMP(0)  // staging
+
+    // ---- this wave's tiles in every step (static over the search) -----------------------------------
+    int fl_first, fl_n, p1_first, p1_n, v0_first, v0_n;
+    deal_pairs(np0 + nm0, wave, fl_first, fl_n);
+    deal_pairs(np1, wave, p1_first, p1_n);
+    deal_pairs(nv0, wave, v0_first, v0_n);
+    auto fl_tile = [&](int t) {  // tile t of {policy 1 | merge}
+        t = min(t, np0 + nm0 - 1);
+        return t < np0 ? tile_of(Lp0, KCD, t) : tile_of(Lm0, KCD, t - np0);
+    };
+    const float *fl_tile0 = fl_tile(fl_first);
+    const float *p1_tile0 = tile_of(Lp1, KCP, min(p1_first, np1 - 1));
+    const float *v0_tile0 = tile_of(Lv0, KCD, min(v0_first, nv0 - 1));
+    const float *v1_tile = tile_of(Lv1, KCV, min(wave, nv1 - 1));   // value 2 and reward 1: tile `wave` each
+    const float *r0_tile = tile_of(Lr0, KCD, min(wave, nr0 - 1));
+
+    Slot<KMAX> s0, s1;
+
+    // Runs a step: `n` tiles of KC chunks for this wave through the ring.  Slot 0 holds the step's first tile on
+    // entry (requested ahead by the caller: a whole inter-step phase earlier).  ptr(j): address of the wave's j-th
+    // tile (j clamped by the callee); work(slot, j): multiply and store it.  Inside the loop every path issues its
+    // fetches unconditionally, so that the waits in front of the matrix instructions count the loads in flight
+    // behind the tile they need instead of draining the queue.  MULTI = false: at most two tiles per wave.
+    auto run_step = [&](auto kc_tag, auto multi_tag, int n, auto &&ptr, auto &&work) {
+        constexpr int KC = decltype(kc_tag)::value;
+        constexpr bool MULTI = decltype(multi_tag)::value;
+        const int pairs = max(1, (n + 1) >> 1);
+        int j = 0;
+        if constexpr (MULTI) {
+            for (int pr = 0; pr + 1 < pairs; ++pr, j += 2) {
+                fetch_tile<KC>(s1, ptr(j + 1), lane);
+                work(s0, j);
+                fetch_tile<KC>(s0, ptr(j + 2), lane);
+                work(s1, j + 1);
+            }
+        }
+        fetch_tile<KC>(s1, ptr(min(j + 1, max(n - 1, 0))), lane);  // (an odd share repeats its last tile here)
+        if (j < n) work(s0, j);
+        if (j + 1 < n) work(s1, j + 1);
+    };
+    // Requests the first tile (kcn chunks) of the step that follows the phase about to begin.
+    auto prefetch = [&](const float *tile, int kcn) {
+        if (kcn == KCD) fetch_tile<KCD>(s0, tile, lane);
+        else if (kcn == KCP) fetch_tile<KCP>(s0, tile, lane);
+        else fetch_tile<KCV>(s0, tile, lane);
+    };
+    using MultiPair = std::true_type;
+    using OnePair = std::false_type;
+
+    // {policy 1 | merge} of the rows whose image is in XI: policy 1 -> row tile `h_tile` of H1 (split image),
+    // merge pre-activation -> z_out (fp32 rows)
+    auto first_layers = [&](int h_tile, lds_f *z_out) {
+        lds_f *h_out = H1 + h_tile * 16 * ld_p;
+        run_step(std::integral_constant<int, KCD>{}, MultiPair{}, fl_n, [&](int j) { return fl_tile(fl_first + j); },
+                 [&](Slot<KMAX> &s, int j) {
+                     const int t = fl_first + j;
+                     f32x4 hi[1], lo[1];
+                     mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
+                     if (t < np0) epi_split<1, true>(hi, lo, t, lds4(Bp0 + t * 16 + 4 * (lane >> 4)), h_out, 16 * ld_p, KCP, np0, lane);
+                     else epi_rows<1, false>(hi, lo, t - np0, lds4(Bm + (t - np0) * 16 + 4 * (lane >> 4)), z_out, ld_d, lane);
+                 });
+    };
+    // split image of sixteen rows relu(zsrc[t] + table[action of tree t]) -> dst (a 16-row tile); act_fixed >= 0:
+    // the same action for every tree (the children of one action), else the trees' own actions `sel`
+    auto form_item = [&](int i, const lds_f *zsrc, int act_fixed, const lds_i *sel, lds_f *dst) {
+        const int l = i & 63, c = i >> 6, t = l & 15;
+        const int k0 = 32 * c + 8 * (l >> 4);
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (k0 < Dp16) {
+            const int a = act_fixed >= 0 ? act_fixed : sel[t];
+            const lds_f *zr = zsrc + t * ld_d + k0, *tr = Tab + a * ld_d + k0;
+            const f32x4 z0 = *reinterpret_cast<const lds_f4 *>(zr), z1 = *reinterpret_cast<const lds_f4 *>(zr + 4);
+            const f32x4 b0 = *reinterpret_cast<const lds_f4 *>(tr), b1 = *reinterpret_cast<const lds_f4 *>(tr + 4);
+            v0 = f32x4{fmaxf(z0.x + b0.x, 0.f), fmaxf(z0.y + b0.y, 0.f), fmaxf(z0.z + b0.z, 0.f), fmaxf(z0.w + b0.w, 0.f)};
+            v1 = f32x4{fmaxf(z1.x + b1.x, 0.f), fmaxf(z1.y + b1.y, 0.f), fmaxf(z1.z + b1.z, 0.f), fmaxf(z1.w + b1.w, 0.f)};
+        }
+        f32x4 hi, lo;
+        split8(v0, v1, hi, lo);
+        lds_f *qd = dst + c * kChunkFloats + l * 4;
+        *reinterpret_cast<lds_f4 *>(qd) = hi;
+        *reinterpret_cast<lds_f4 *>(qd + KCD * kChunkFloats) = lo;
+    };
+    // row tiles [p0, p0 + kPassTiles) of {children of action 0 .. A-1, rollout latent} -> R (skipping tiles past them)
+    auto form_pass = [&](int p0, bool sim) {
+        for (int i = tid; i < kPassTiles * KCD * 64; i += kThreads) {
+            const int tl = i / (KCD * 64), a = p0 + tl;
+            if (a < A) form_item(i - tl * (KCD * 64), Z, a, nullptr, R + tl * 16 * ld_d);
+            else if (a == A && sim) form_item(i - tl * (KCD * 64), Zs, -1, s_act2, R + tl * 16 * ld_d);
+        }
+    };
+    // reward 1 over the pass's row tiles with the weights held in `s` -> partial sums in DotE
+    auto reward_pass = [&](const Slot<KMAX> &s) {
+        if (wave < nr0) {
+            f32x4 hi[kPassTiles], lo[kPassTiles];
+            mma_tile<KCD, kPassTiles>(s, R + lane * 4, 16 * ld_d, hi, lo);
+            epi_dot<kPassTiles, true>(hi, lo, wave, lds4(Br0 + wave * 16 + 4 * (lane >> 4)), lds4(DwR + wave * 16 + 4 * (lane >> 4)), DotE, lane);
+        }
+    };
+    // rewards of a finished pass: children -> s_rew, rollout latent -> s_roll[t][0]
+    auto finish_pass = [&](int p0, bool sim) {
+        const float b2 = Br0[Lr0.Np];
+        for (int r = tid; r < kTrees * kPassTiles; r += kThreads) {
+            const int a = p0 + r / kTrees, t = r % kTrees;
+            if (a < A || (a == A && sim)) {
+                float sum = 0.0f;
+                for (int k = 0; k < 4 * nr0; ++k) sum += DotE[k * (kTrees * kPassTiles) + r];
+                const float rv = activate(sum + b2, Lr1.act);
+                if (a < A) s_rew[t * (A + 1) + a] = rv;
+                else s_roll[t * 2] = rv;
+            }
+        }
+    };
+
+    // expansion e = 0 is the root expansion (no simulation / backup follows it);
+    // expansion e >= 1 belongs to simulation s = e - 1
+    for (int e = 0; e <= S; ++e) {
+        const int base = 1 + e * A;
+        const bool sim = e > 0;
+        // Thread-dependent addresses are re-derived every round from an opaque copy of the thread index: hoisted out
+        // of the loop they stay live through the whole kernel, spill, and every reload from scratch waits for ALL
+        // outstanding loads -- the ring's tiles in flight included.
+        tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+
+        if (sim) {
+            // ---- select, draw, leaf latent -----------------------------------------------------
+            if (tid < kTrees * lpt) {
+                const int t = tid / lpt, a = tid % lpt;
+                int leaf = 0, dep = 0;
+                if (t < trees) {
+                    const size_t o = (size_t)(g0 + t) * p.cap;
+                    switch (lpt) {
+                        case 2: leaf = mzt::select_leaf<2>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        case 4: leaf = mzt::select_leaf<4>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        case 8: leaf = mzt::select_leaf<8>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        case 16: leaf = mzt::select_leaf<16>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                        default: leaf = mzt::select_leaf<32>(p, o, a, s_tab, q.tab_len, true, &dep, 1, e - 1, s_path + t * kPathCap, kPathCap); break;
+                    }
+                    if (a == 0) {
+                        leaf = max(leaf, 0);
+                        s_leaf[t] = leaf;
+                        s_depth[t] = dep;
+                        s_leaf_tp[t] = (dep & 1) ? -s_root[t] : s_root[t];
+                        if (q.leaf_trace) q.leaf_trace[(size_t)(g0 + t) * S + (e - 1)] = leaf;
+                    }
+                }
+            }
+            if (tid >= kThreads - kTrees) {  // the child each simulation starts from (src/search/mcts.py:64-66)
+                const int t = tid - (kThreads - kTrees);
+                int rc = 0;
+                if (t < trees) rc = q.rand_child[(size_t)(g0 + t) * (S + 1) + e];
+                rc = min(max(rc, 0), A - 1);
+                s_act[t] = rc;
+                s_child[t] = base + rc;
+                if (q.child_trace && t < trees) q.child_trace[(size_t)(g0 + t) * S + (e - 1)] = base + rc;
+            }
+            __syncthreads();
+            MZ_STAMP(1)  // select
+            prefetch(fl_tile0, KCD);  // in flight while the leaf's latent is formed
+            // node n >= 1 is child a = (n - 1) % A of expansion (n - 1) / A: its latent is relu(z_pool[expansion] +
+            // table[a]), formed straight into the split image
+            for (int i = tid; i < KCD * 64; i += kThreads) {
+                const int l = i & 63, c = i >> 6, t = l & 15;
+                const int k0 = 32 * c + 8 * (l >> 4);
+                const int n = max(s_leaf[t] - 1, 0), ex = n / A, a = n - ex * A;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (t < trees && k0 < Dp16) {
+                    const float *zr = q.z_pool + ((size_t)(g0 + t) * (S + 1) + ex) * D + k0;
+                    const lds_f *tr = Tab + a * ld_d + k0;
+                    float z[8];
+                    if ((D & 3) == 0) {
+                        const float4 z0 = k0 < D ? *reinterpret_cast<const float4 *>(zr) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 z1 = k0 + 4 < D ? *reinterpret_cast<const float4 *>(zr + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        z[0] = z0.x, z[1] = z0.y, z[2] = z0.z, z[3] = z0.w, z[4] = z1.x, z[5] = z1.y, z[6] = z1.z, z[7] = z1.w;
+                    } else {
+                        for (int j = 0; j < 8; ++j) z[j] = k0 + j < D ? zr[j] : 0.0f;
+                    }
+                    v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
+                    v1 = f32x4{fmaxf(z[4] + tr[4], 0.f), fmaxf(z[5] + tr[5], 0.f), fmaxf(z[6] + tr[6], 0.f), fmaxf(z[7] + tr[7], 0.f)};
+                }
+                f32x4 hi, lo;
+                split8(v0, v1, hi, lo);
+                lds_f *qd = XI + c * kChunkFloats + l * 4;
+                *reinterpret_cast<lds_f4 *>(qd) = hi;
+                *reinterpret_cast<lds_f4 *>(qd + KCD * kChunkFloats) = lo;
+            }
+            __syncthreads();
+            MZ_STAMP(2)  // leaf latent
+        }
+
+        // ---- {policy 1 | merge} of the leaf, then of the drawn child ------------------------------------
+        for (int rep_i = 0; rep_i < (sim ? 2 : 1); ++rep_i) {
+            if (rep_i == 1) {  // the drawn child's latent
+                for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Z, -1, s_act, XI);
+                __syncthreads();
+                MZ_STAMP(16)  // child latent
+            }
+            if (!sim) prefetch(fl_tile0, KCD);  // (root expansion: nothing to hide it behind)
+            const bool again = sim && rep_i == 0;  // the same step follows once more
+            first_layers(rep_i, rep_i == 0 ? Z : Zs);
+            prefetch(again ? fl_tile0 : p1_tile0, again ? KCD : KCP);  // in flight through the epilogue, the barrier and what lies between the steps
+            __syncthreads();
+            if (rep_i == 0) {
+                MZ_STAMP(3)  // policy 1 | merge (leaf)
+                // the leaf's merge row is all that is kept of its children's latents
+                for (int i = tid; i < trees * D; i += kThreads) {
+                    const int t = i / D, c = i - t * D;
+                    q.z_pool[((size_t)(g0 + t) * (S + 1) + e) * D + c] = Z[t * ld_d + c];
+                }
+            } else {
+                MZ_STAMP(18)  // policy 1 | merge (child)
+            }
+        }
+
+        // ---- policy 2 of leaf and child: one pass over two row tiles ---------------------------------
+        {
+            auto work = [&](Slot<KMAX> &s, int j) {
+                const int t = p1_first + j;
+                f32x4 hi[2], lo[2];
+                mma_tile<KCP, 2>(s, H1 + lane * 4, 16 * ld_p, hi, lo);
+                epi_rows<2, true>(hi, lo, t, lds4(Bp1 + t * 16 + 4 * (lane >> 4)), H2, ld_q, lane);
+            };
+            auto ptr = [&](int j) { return tile_of(Lp1, KCP, min(p1_first + j, np1 - 1)); };
+            run_step(std::integral_constant<int, KCP>{}, OnePair{}, p1_n, ptr, work);
+        }
+        __syncthreads();
+        MZ_STAMP(4)  // policy 2 (leaf + child)
+
+        // ---- policy 3 (narrow), softmax; priors of the leaf, greedy action of the child ----------------------
+        {
+            Team all = whole_workgroup();
+            dense_narrow<LdsNarrowWeights>(H2, ld_q, 2 * kTrees, nullptr, nullptr, Nw, Lp2.Kp, Lp2.N, Lp2.act, Lg, ld_l, 0, kWaves);
+            __syncthreads();
+            softmax_rows(Lg, ld_l, 2 * kTrees, A, 1, all);   // the network's own softmax (both row tiles)
+            if (tid >= kThreads - kTrees) {  // first maximum of the child's policy (src/search/simulation.py:36)
+                const int t = tid - (kThreads - kTrees);
+                const lds_f *row = Lg + (kTrees + t) * ld_l;
+                int best = 0;
+                for (int a = 1; a < A; ++a)
+                    if (row[a] > row[best]) best = a;
+                s_act2[t] = best;
+            }
+            softmax_rows(Lg, ld_l, kTrees, A, 1, all);       // expand_node's extra softmax (src/search/expansion.py:27)
+            for (int i = tid; i < kTrees * A; i += kThreads) {
+                const int t = i / A, a = i - t * A;
+                const float pr = Lg[t * ld_l + a];
+                s_prior[i] = pr;
+                if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + a] = pr;
+            }
+        }
+        MZ_STAMP(5)  // policy 3, softmax, priors, greedy action
+        if (sim) prefetch(v0_tile0, KCD);  // value 1's first tile, in flight while the latents below are formed
+        // ---- rollout latent; first pass of row tiles for reward 1 ---------------------------------------
+        if (sim)
+            for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
+        form_pass(0, sim);
+        __syncthreads();
+        MZ_STAMP(6)  // rollout latent, children of the first pass
+        if (sim) {
+            // ---- value 1 of the rollout latent -> Hv (split image) -------------------------------------------
+            run_step(std::integral_constant<int, KCD>{}, OnePair{}, v0_n, [&](int j) { return tile_of(Lv0, KCD, min(v0_first + j, nv0 - 1)); },
+                     [&](Slot<KMAX> &s, int j) {
+                         const int t = v0_first + j;
+                         f32x4 hi[1], lo[1];
+                         mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
+                         epi_split<1, true>(hi, lo, t, lds4(Bv0 + t * 16 + 4 * (lane >> 4)), Hv, 16 * ld_v, KCV, nv0, lane);
+                     });
+            prefetch(v1_tile, KCV);  // value 2
+            __syncthreads();
+            MZ_STAMP(7)  // value 1
+        }
+        // ---- value 2 (slot 0) | reward 1 over the first pass (slot 1, kept for the later passes) ------------------
+        fetch_tile<KCD>(s1, r0_tile, lane);
+        if (sim && wave < nv1) {
+            f32x4 hi[1], lo[1];
+            mma_tile<KCV, 1>(s0, Hv + lane * 4, 0, hi, lo);
+            epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
+        }
+        reward_pass(s1);
+        __syncthreads();
+        MZ_STAMP(8)  // value 2 | reward 1, first pass
+        for (int p0 = kPassTiles; p0 < A + 1; p0 += kPassTiles) {
+            finish_pass(p0 - kPassTiles, sim);
+            form_pass(p0, sim);
+            __syncthreads();
+            reward_pass(s1);
+            __syncthreads();
+        }
+        finish_pass(((A + 1 - 1) / kPassTiles) * kPassTiles, sim);
+        if (sim && tid < kTrees) {  // value of the rollout latent (as finish_dot)
+            float sum = 0.0f;
+            for (int k = 0; k < 4 * nv1; ++k) sum += DotV[k * kTrees + tid];
+            s_roll[tid * 2 + 1] = activate(sum + Bv1[Lv1.Np], Lv2.act);
+        }
+        __syncthreads();
+        MZ_STAMP(9)  // remaining passes, rewards, value
+
+        // ---- child records ---------------------------------------------------------------------------
+        for (int i = tid; i < trees * A; i += kThreads) {
+            const int t = i / A, a = i - t * A;
+            const size_t o = (size_t)(g0 + t) * p.cap;
+            float pr = s_prior[t * A + a];
+            if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
+            mzt::write_child(p, o, base, a, s_leaf[t], pr, s_rew[t * (A + 1) + a], (int8_t)s_leaf_tp[t]);
+            if (a == 0) p.node[o + s_leaf[t]].first_child = base;
+        }
+        __syncthreads();  // the drawn child's record exists before the backup updates it
+        if (!sim) continue;
+        // ---- backup: the recorded path is updated by independent lanes (see k_search) --------------------------
+        if (tid >= kThreads / 2 && tid < kThreads / 2 + kTrees * kPathCap) {
+            const int t = (tid - kThreads / 2) / kPathCap, i = (tid - kThreads / 2) % kPathCap;
+            if (t < trees) {
+                const size_t o = (size_t)(g0 + t) * p.cap;
+                float roll[2] = {s_roll[t * 2], s_roll[t * 2 + 1]};
+                const int dl = s_depth[t];
+                const double ret = mzt::discounted_return(roll, 2, q.discount);
+                if (i == 0 && q.rollout_trace) {
+                    q.rollout_trace[((size_t)(g0 + t) * S + (e - 1)) * 2] = roll[0];
+                    q.rollout_trace[((size_t)(g0 + t) * S + (e - 1)) * 2 + 1] = roll[1];
+                }
+                if (dl + 1 <= kPathCap - 1) {
+                    if (i <= dl + 1) {
+                        const int node = (i == 0) ? s_child[t] : s_path[t * kPathCap + (dl - (i - 1))];
+                        const bool same = s_root[t] == 0 || (i >= 1 && ((i - 1) & 1) == 0);
+                        const size_t c = o + node;
+                        mzt::NodeStat st = mzt::load_stat(p, c);
+                        st.visit += 1;
+                        const double add = same ? ret : -ret;
+                        st.value_sum = st.value_sum + add;
+                        mzt::store_stat(p, c, st);
+                    }
+                } else if (i == 0) {
+                    mzt::backup_path(p, o, s_child[t], (int8_t)s_leaf_tp[t], ret);
+                }
+            }
+        }
+        __syncthreads();
+        MZ_STAMP(11)  // child records, backup
+    }
+
+    // ---- result -------------------------------------------------------------------------------
+    if (tid < trees) {
+        p.n_nodes[g0 + tid] = 1 + (S + 1) * A;
+        mzt::tree_result(p, g0 + tid, policy, policy32, value, visits);
+    }
+    if (stamping) {
+        __syncthreads();
+        if (threadIdx.x < 32) q.stamps[threadIdx.x] = s_stamp[threadIdx.x];
+    }
+#undef MZ_STAMP
+}
+
+template <int KCD, int KCP, int KCV>
+int launch_seq(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params &q, const SeqLds &L,
+               double *policy, float *policy32, double *value, int32_t *visits, hipStream_t st) {
+    auto kernel = k_search_seq<KCD, KCP, KCV>;
+    if (L.total > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_search_seq: cannot enable %zu bytes of LDS: %s", L.total, hipGetErrorString(e));
+    }
+    const int blocks = (pool->G + kTrees - 1) / kTrees;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), L.total, st, *pool, *plan, blob, q, L, policy, policy32, value, visits);
+    return mz::check_launch("k_search_seq");
+}
+
+}  // namespace
+
+// The sequential-program form of mz_search_run for the searches it covers: returns 1 after launching it,
+// 0 when the search needs k_search, a negative code on a failed launch.  Arguments are validated by the caller.
+int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params *prm,
+                      double *policy, float *policy32, double *value, int32_t *visits, void *stream) {
+    static const bool off = [] { const char *e = getenv("MZ_SEARCH_SEQ"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    const mz_packed_nets &P = *plan;
+    if (pool->latent != nullptr || prm->z_pool == nullptr || prm->depth != 1 || P.A > 32) return 0;
+    if (P.policy.n_layers != 3 || P.value.n_layers != 3 || P.reward.n_layers != 2) return 0;
+    if (!is_matrix_layer(P.policy.layer[0]) || !is_matrix_layer(P.policy.layer[1]) || is_matrix_layer(P.policy.layer[2]) ||
+        P.policy.layer[2].act != MZ_ACT_SOFTMAX || P.policy.layer[2].N != P.A || P.A > 8)
+        return 0;
+    if (!is_matrix_layer(P.value.layer[0]) || !tail_foldable(P.value) || !is_matrix_layer(P.reward.layer[0]) || !tail_foldable(P.reward))
+        return 0;
+    if (P.policy.layer[0].act != MZ_ACT_RELU || P.policy.layer[1].act != MZ_ACT_RELU || P.value.layer[0].act != MZ_ACT_RELU ||
+        P.value.layer[1].act != MZ_ACT_RELU || P.reward.layer[0].act != MZ_ACT_RELU)
+        return 0;
+    if ((P.value.layer[1].Np >> 4) > kWaves || (P.reward.layer[0].Np >> 4) > kWaves) return 0;
+    if ((P.policy.layer[1].Np >> 4) > 2 * kWaves || (P.value.layer[0].Np >> 4) > 2 * kWaves) return 0;
+    const int kcd = P.merge.layer[0].Kp >> 5, kcp = P.policy.layer[1].Kp >> 5, kcv = P.value.layer[1].Kp >> 5;
+    if (P.policy.layer[0].Kp != P.merge.layer[0].Kp || P.value.layer[0].Kp != P.merge.layer[0].Kp ||
+        P.reward.layer[0].Kp != P.merge.layer[0].Kp)
+        return 0;
+    const SeqLds L = seq_layout(P, prm->tab_len);
+    if (L.total > 160 * 1024) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (kcd == 6 && kcp == 8 && kcv == 8) rc = launch_seq<6, 8, 8>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st);
+    else if (kcd == 2 && kcp == 4 && kcv == 4) rc = launch_seq<2, 4, 4>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st);
+    else return 0;
+    return rc == MZ_OK ? 1 : rc;
+}

@@ -9,12 +9,23 @@ NAMES = {0: "staging", 1: "select", 2: "leaf gather", 3: "policy1|merge (all wav
          12: "result", 16: "S next latent", 17: "S reward head", 18: "S policy1|merge", 19: "S policy rest", 20: "S argmax",
          21: "S value head", 22: "S wait for E"}
 
+# the sequential-program kernel (implicit child latents) stamps its own steps
+SEQ_NAMES = {0: "staging", 1: "select + draw", 2: "leaf latent", 3: "policy1|merge (leaf)", 16: "child latent",
+             18: "policy1|merge (child)", 4: "policy 2 (leaf + child)", 5: "policy 3, softmax, priors, argmax",
+             6: "rollout latent + children pass 1", 7: "value 1", 8: "value 2 | reward 1 pass 1", 9: "later passes, rewards, value",
+             11: "child records, backup"}
+
+
 def main():
     from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    global NAMES
     cfg, h, g, f = bench.build_networks()
     G, S = 4096, 50
     nets = PackedNetworks(g, f)
-    mcts = BatchedMCTS(nets, G, S, 1, 0.998, 0.25)
+    stored = "--store-latents" in sys.argv
+    if not stored and os.environ.get("MZ_SEARCH_SEQ", "1") != "0":
+        NAMES = SEQ_NAMES
+    mcts = BatchedMCTS(nets, G, S, 1, 0.998, 0.25, keep_latents=stored)
     latent, to_play = bench.synthetic_roots(h, G, 100, torch.device("cuda"))
     eta = torch.from_numpy(np.random.default_rng(7).dirichlet(np.full(7, 0.3), size=G).astype(np.float32)).cuda()
     rand = torch.from_numpy(bench.child_choice_streams(G, S, 0)).cuda()
