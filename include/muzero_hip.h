@@ -185,7 +185,8 @@ typedef struct mz_mlp {
 /* Layout of one MLP inside a packed weight blob (offsets in floats from the blob start).
  * fmt 1: a layer evaluated on the matrix cores -- Kp = K rounded up to 32, weights stored as two fp16
  * planes (value and scaled residual, 4 bytes per weight); fmt 0: fp32 tiles, Kp = K rounded up to 16
- * (layers with at most 8 outputs, evaluated on the vector ALU; every layer of mz_wide_plan). */
+ * (a final one-output layer that is folded into the epilogue of the wide layer before it; every
+ * layer of mz_wide_plan). */
 typedef struct mz_packed_layer {
     int32_t K, N, Kp, Np, act, fmt;
     int64_t w_off, b_off;

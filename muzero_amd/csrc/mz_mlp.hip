@@ -342,7 +342,11 @@ int64_t plan_mlp(const mz_mlp *h_mlp, int64_t base_off, mz_packed_mlp *h_out, bo
         mz_packed_layer &L = h_out->layer[i];
         L.K = d.in_features;
         L.N = d.out_features;
-        L.fmt = (all_matrix || L.N > 8) ? 1 : 0;
+        // every layer runs on the matrix cores, except a final one-output layer behind a wide layer: that pair is
+        // folded (tail_foldable), the epilogue of the wide layer reads the output layer's weights as fp32
+        const bool folded_tail = !all_matrix && i == h_mlp->n_layers - 1 && i >= 1 && d.out_features == 1 &&
+                                 h_mlp->layer[i - 1].out_features > 8 && d.in_features == h_mlp->layer[i - 1].out_features;
+        L.fmt = folded_tail ? 0 : 1;
         L.Kp = L.fmt ? ceil32(L.K) : ceil16(L.K);
         L.Np = ceil16(L.N);
         L.act = d.activation;

@@ -12,7 +12,7 @@
 //   {policy 1 | merge}(leaf)
 //   {policy 1 | merge}(drawn child)
 //   policy 2 for leaf AND child as one 32-row pass      (its weights are read once, not twice)
-//   policy 3 (narrow, vector ALU) for the 32 rows, softmax; priors of the leaf, greedy action of the child
+//   policy 3 for the 32 rows (one column tile: one wave), softmax; priors of the leaf, greedy action of the child
 //   value 1 (rollout latent)
 //   value 2 | reward 1 over the A children AND the rollout latent, in passes of four row tiles with
 //   the wave's reward-1 weights held in registers across the passes           (read once per round)
@@ -31,7 +31,7 @@
 // and the per-stage kernels' bit for bit (tests/test_gpu_search.py).
 //
 // Covers: implicit child latents (pool->latent == NULL), model_look_ahead = 1, policy head
-// [matrix, matrix, narrow softmax], value head [matrix, matrix, 1] and reward head [matrix, 1]
+// [matrix, matrix, softmax layer of at most 8 actions, its hidden widths in as many k-chunks], value head [matrix, matrix, 1] and reward head [matrix, 1]
 // with the last two layers folded, relu after every matrix layer, at most 8 column tiles in value 2 and reward 1, k-chunk counts
 // matching an instantiation below.  mz_search_run falls back to k_search for everything else.
 //
@@ -56,11 +56,11 @@ struct SeqLds {
     int ld_d, ld_p, ld_q, ld_v, ld_l, tab_rows;
     // byte offsets.  xi: split image of the current input latents (leaf, drawn child, rollout latent in turn);
     // z / zs: merge pre-activations of the leaf / of the drawn child (fp32 rows); h1: policy layer 1 of leaf
-    // (tile 0) and child (tile 1), split image; h2: policy layer 2 of the 32 rows (fp32 rows); r: split images
+    // (tile 0) and child (tile 1), split image; h2: policy layer 2 of leaf and child, likewise; r: split images
     // of a pass's row tiles, over h1 | h2 (dead by then); hv: value layer 1 (split image); lg: logits / policies
     // of the 32 rows; dote / dotv: partial sums of the folded layers; bias*: padded biases; dw*: the folded
-    // one-output layers' weights by k; nw: LDS copy of the narrow policy layer's weights
-    size_t xi, z, zs, tab, h1, h2, r, hv, lg, dote, dotv, b_p0, b_m, b_p1, b_v0, b_v1, b_r0, dw_v, dw_r, nw, prior, rew, roll, ints, path,
+    // one-output layers' weights by k
+    size_t xi, z, zs, tab, h1, h2, r, hv, lg, dote, dotv, b_p0, b_m, b_p1, b_v0, b_v1, b_r0, dw_v, dw_r, b_p2, prior, rew, roll, ints, path,
         tabs, total;
 };
 
@@ -96,7 +96,7 @@ __host__ __device__ inline SeqLds seq_layout(const mz_packed_nets &P, int tab_le
     L.b_r0 = take(sizeof(float) * (P.reward.layer[0].Np + 4));
     L.dw_v = take(sizeof(float) * P.value.layer[1].Np);
     L.dw_r = take(sizeof(float) * P.reward.layer[0].Np);
-    L.nw = take(sizeof(float) * narrow_lds_floats(P.policy.layer[2]));
+    L.b_p2 = take(sizeof(float) * P.policy.layer[2].Np);
     L.prior = take(sizeof(float) * kTrees * A);
     L.rew = take(sizeof(float) * kTrees * (A + 1));
     L.roll = take(sizeof(float) * kTrees * 2);
@@ -208,6 +208,21 @@ __device__ __forceinline__ void epi_dot(const f32x4 (&hi)[MT], const f32x4 (&lo)
     }
 }
 
+// Sum of n (<= 32) partial sums p[0], p[stride], ... in ascending order (the order of finish_dot), with the
+// loads issued eight at a time instead of one per addition.
+__device__ __forceinline__ float ordered_sum(const lds_f *p, int stride, int n) {
+    float s = 0.0f;
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[min(k0 + i, n - 1) * stride];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (k0 + i < n) s += v[i];
+    }
+    return s;
+}
+
 // This wave's share of `total` column tiles, dealt in pairs (as dense_group_body): first tile and count.
 __device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int &count) {
     const int units = (total + 1) >> 1;
@@ -238,7 +253,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     lds_f *Bp0 = to_lds(smem_raw + L.b_p0), *Bm = to_lds(smem_raw + L.b_m), *Bp1 = to_lds(smem_raw + L.b_p1);
     lds_f *Bv0 = to_lds(smem_raw + L.b_v0), *Bv1 = to_lds(smem_raw + L.b_v1), *Br0 = to_lds(smem_raw + L.b_r0);
     lds_f *DwV = to_lds(smem_raw + L.dw_v), *DwR = to_lds(smem_raw + L.dw_r);
-    lds_f *Nw = to_lds(smem_raw + L.nw);
+    lds_f *Bp2 = to_lds(smem_raw + L.b_p2);
     lds_f *s_prior = to_lds(smem_raw + L.prior);
     lds_f *s_rew = to_lds(smem_raw + L.rew);
     lds_f *s_roll = to_lds(smem_raw + L.roll);
@@ -288,11 +303,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         const int a = i / ld_d, c = i - a * ld_d;
         Tab[i] = (a < A && c < Pk.Dp) ? blob[Pk.action_table_off + (size_t)a * Pk.Dp + c] : 0.0f;
     }
-    stage_narrow(blob, Lp2, Nw);
     auto stage_bias = [&](lds_f *dst, const mz_packed_layer &Ly) {
         for (int i = tid; i < Ly.Np; i += kThreads) dst[i] = blob[Ly.b_off + i];
     };
-    stage_bias(Bp0, Lp0), stage_bias(Bm, Lm0), stage_bias(Bp1, Lp1), stage_bias(Bv0, Lv0), stage_bias(Bv1, Lv1), stage_bias(Br0, Lr0);
+    stage_bias(Bp0, Lp0), stage_bias(Bm, Lm0), stage_bias(Bp1, Lp1), stage_bias(Bv0, Lv0), stage_bias(Bv1, Lv1), stage_bias(Br0, Lr0), stage_bias(Bp2, Lp2);
     if (tid == 0) {
         Bv1[Lv1.Np] = blob[Lv2.b_off];
         Br0[Lr0.Np] = blob[Lr1.b_off];
@@ -332,41 +346,42 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         t = min(t, np0 + nm0 - 1);
         return t < np0 ? tile_of(Lp0, KCD, t) : tile_of(Lm0, KCD, t - np0);
     };
-    const float *fl_tile0 = fl_tile(fl_first);
-    const float *p1_tile0 = tile_of(Lp1, KCP, min(p1_first, np1 - 1));
-    const float *v0_tile0 = tile_of(Lv0, KCD, min(v0_first, nv0 - 1));
+    const float *fl_tile0 = fl_tile(fl_first), *fl_tile1 = fl_tile(fl_first + min(1, max(fl_n - 1, 0)));
+    const float *p1_tile0 = tile_of(Lp1, KCP, min(p1_first, np1 - 1)), *p1_tile1 = tile_of(Lp1, KCP, min(p1_first + 1, np1 - 1));
+    const float *v0_tile0 = tile_of(Lv0, KCD, min(v0_first, nv0 - 1)), *v0_tile1 = tile_of(Lv0, KCD, min(v0_first + 1, nv0 - 1));
     const float *v1_tile = tile_of(Lv1, KCV, min(wave, nv1 - 1));   // value 2 and reward 1: tile `wave` each
     const float *r0_tile = tile_of(Lr0, KCD, min(wave, nr0 - 1));
 
     Slot<KMAX> s0, s1;
 
-    // Runs a step: `n` tiles of KC chunks for this wave through the ring.  Slot 0 holds the step's first tile on
-    // entry (requested ahead by the caller: a whole inter-step phase earlier).  ptr(j): address of the wave's j-th
-    // tile (j clamped by the callee); work(slot, j): multiply and store it.  Inside the loop every path issues its
+    // Runs a step: `n` tiles of KC chunks for this wave through the ring.  On entry slot 0 and slot 1 hold the
+    // step's first two tiles (requested ahead by the caller, a whole inter-step phase earlier: prefetch2); the
+    // step requests tile j + 2 as soon as tile j has been multiplied.  ptr(j): address of the wave's j-th tile
+    // (j clamped by the callee); work(slot, j): multiply and store it.  Inside the loop every path issues its
     // fetches unconditionally, so that the waits in front of the matrix instructions count the loads in flight
     // behind the tile they need instead of draining the queue.  MULTI = false: at most two tiles per wave.
-    auto run_step = [&](auto kc_tag, auto multi_tag, int n, auto &&ptr, auto &&work) {
+    auto run_step = [&](auto kc_tag, auto multi_tag, int n, auto &&ptr, auto &&work, auto &&after_first) {
         constexpr int KC = decltype(kc_tag)::value;
         constexpr bool MULTI = decltype(multi_tag)::value;
-        const int pairs = max(1, (n + 1) >> 1);
         int j = 0;
         if constexpr (MULTI) {
-            for (int pr = 0; pr + 1 < pairs; ++pr, j += 2) {
-                fetch_tile<KC>(s1, ptr(j + 1), lane);
+            for (; j + 2 < n; j += 2) {
                 work(s0, j);
                 fetch_tile<KC>(s0, ptr(j + 2), lane);
                 work(s1, j + 1);
+                fetch_tile<KC>(s1, ptr(j + 3), lane);  // (an odd share repeats its last tile here)
             }
         }
-        fetch_tile<KC>(s1, ptr(min(j + 1, max(n - 1, 0))), lane);  // (an odd share repeats its last tile here)
         if (j < n) work(s0, j);
+        after_first();  // slot 0 is free from here on
         if (j + 1 < n) work(s1, j + 1);
     };
-    // Requests the first tile (kcn chunks) of the step that follows the phase about to begin.
-    auto prefetch = [&](const float *tile, int kcn) {
-        if (kcn == KCD) fetch_tile<KCD>(s0, tile, lane);
-        else if (kcn == KCP) fetch_tile<KCP>(s0, tile, lane);
-        else fetch_tile<KCV>(s0, tile, lane);
+    auto nothing = [] {};
+    // Requests the first two tiles (kcn chunks each) of the step that follows the phase about to begin.
+    auto prefetch2 = [&](const float *tile0, const float *tile1, int kcn) {
+        if (kcn == KCD) fetch_tile<KCD>(s0, tile0, lane), fetch_tile<KCD>(s1, tile1, lane);
+        else if (kcn == KCP) fetch_tile<KCP>(s0, tile0, lane), fetch_tile<KCP>(s1, tile1, lane);
+        else fetch_tile<KCV>(s0, tile0, lane), fetch_tile<KCV>(s1, tile1, lane);
     };
     using MultiPair = std::true_type;
     using OnePair = std::false_type;
@@ -382,7 +397,8 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                      mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
                      if (t < np0) epi_split<1, true>(hi, lo, t, lds4(Bp0 + t * 16 + 4 * (lane >> 4)), h_out, 16 * ld_p, KCP, np0, lane);
                      else epi_rows<1, false>(hi, lo, t - np0, lds4(Bm + (t - np0) * 16 + 4 * (lane >> 4)), z_out, ld_d, lane);
-                 });
+                 },
+                 nothing);
     };
     // split image of sixteen rows relu(zsrc[t] + table[action of tree t]) -> dst (a 16-row tile); act_fixed >= 0:
     // the same action for every tree (the children of one action), else the trees' own actions `sel`
@@ -426,9 +442,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         for (int r = tid; r < kTrees * kPassTiles; r += kThreads) {
             const int a = p0 + r / kTrees, t = r % kTrees;
             if (a < A || (a == A && sim)) {
-                float sum = 0.0f;
-                for (int k = 0; k < 4 * nr0; ++k) sum += DotE[k * (kTrees * kPassTiles) + r];
-                const float rv = activate(sum + b2, Lr1.act);
+                const float rv = activate(ordered_sum(DotE + r, kTrees * kPassTiles, 4 * nr0) + b2, Lr1.act);
                 if (a < A) s_rew[t * (A + 1) + a] = rv;
                 else s_roll[t * 2] = rv;
             }
@@ -481,18 +495,19 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             }
             __syncthreads();
             MZ_STAMP(1)  // select
-            prefetch(fl_tile0, KCD);  // in flight while the leaf's latent is formed
             // node n >= 1 is child a = (n - 1) % A of expansion (n - 1) / A: its latent is relu(z_pool[expansion] +
             // table[a]), formed straight into the split image
-            for (int i = tid; i < KCD * 64; i += kThreads) {
+            {   // (KCD * 64 <= 512 operands: at most one per thread)
+                const int i = tid;
                 const int l = i & 63, c = i >> 6, t = l & 15;
                 const int k0 = 32 * c + 8 * (l >> 4);
                 const int n = max(s_leaf[t] - 1, 0), ex = n / A, a = n - ex * A;
                 f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                if (t < trees && k0 < Dp16) {
+                const bool mine = i < KCD * 64;
+                const bool live = mine && t < trees && k0 < Dp16;
+                float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (live) {
                     const float *zr = q.z_pool + ((size_t)(g0 + t) * (S + 1) + ex) * D + k0;
-                    const lds_f *tr = Tab + a * ld_d + k0;
-                    float z[8];
                     if ((D & 3) == 0) {
                         const float4 z0 = k0 < D ? *reinterpret_cast<const float4 *>(zr) : make_float4(0.f, 0.f, 0.f, 0.f);
                         const float4 z1 = k0 + 4 < D ? *reinterpret_cast<const float4 *>(zr + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -500,14 +515,22 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                     } else {
                         for (int j = 0; j < 8; ++j) z[j] = k0 + j < D ? zr[j] : 0.0f;
                     }
+                }
+                // the first tiles of {policy 1 | merge} are requested behind the rows (loads return in order: in front of
+                // them they would hold the rows back) and are in flight while the image is formed
+                prefetch2(fl_tile0, fl_tile1, KCD);
+                if (live) {
+                    const lds_f *tr = Tab + a * ld_d + k0;
                     v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
                     v1 = f32x4{fmaxf(z[4] + tr[4], 0.f), fmaxf(z[5] + tr[5], 0.f), fmaxf(z[6] + tr[6], 0.f), fmaxf(z[7] + tr[7], 0.f)};
                 }
-                f32x4 hi, lo;
-                split8(v0, v1, hi, lo);
-                lds_f *qd = XI + c * kChunkFloats + l * 4;
-                *reinterpret_cast<lds_f4 *>(qd) = hi;
-                *reinterpret_cast<lds_f4 *>(qd + KCD * kChunkFloats) = lo;
+                if (mine) {
+                    f32x4 hi, lo;
+                    split8(v0, v1, hi, lo);
+                    lds_f *qd = XI + c * kChunkFloats + l * 4;
+                    *reinterpret_cast<lds_f4 *>(qd) = hi;
+                    *reinterpret_cast<lds_f4 *>(qd + KCD * kChunkFloats) = lo;
+                }
             }
             __syncthreads();
             MZ_STAMP(2)  // leaf latent
@@ -520,10 +543,11 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                 __syncthreads();
                 MZ_STAMP(16)  // child latent
             }
-            if (!sim) prefetch(fl_tile0, KCD);  // (root expansion: nothing to hide it behind)
+            if (!sim) prefetch2(fl_tile0, fl_tile1, KCD);  // (root expansion: nothing to hide it behind)
             const bool again = sim && rep_i == 0;  // the same step follows once more
             first_layers(rep_i, rep_i == 0 ? Z : Zs);
-            prefetch(again ? fl_tile0 : p1_tile0, again ? KCD : KCP);  // in flight through the epilogue, the barrier and what lies between the steps
+            // in flight through the epilogue, the barrier and what lies between the steps
+            prefetch2(again ? fl_tile0 : p1_tile0, again ? fl_tile1 : p1_tile1, again ? KCD : KCP);
             __syncthreads();
             if (rep_i == 0) {
                 MZ_STAMP(3)  // policy 1 | merge (leaf)
@@ -543,38 +567,78 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                 const int t = p1_first + j;
                 f32x4 hi[2], lo[2];
                 mma_tile<KCP, 2>(s, H1 + lane * 4, 16 * ld_p, hi, lo);
-                epi_rows<2, true>(hi, lo, t, lds4(Bp1 + t * 16 + 4 * (lane >> 4)), H2, ld_q, lane);
+                epi_split<2, true>(hi, lo, t, lds4(Bp1 + t * 16 + 4 * (lane >> 4)), H2, 16 * ld_q, KCP, np1, lane);
             };
             auto ptr = [&](int j) { return tile_of(Lp1, KCP, min(p1_first + j, np1 - 1)); };
-            run_step(std::integral_constant<int, KCP>{}, OnePair{}, p1_n, ptr, work);
+            // policy 3 is one column tile: the first wave multiplies it, and requests it as soon as its slot 0 is free
+            run_step(std::integral_constant<int, KCP>{}, OnePair{}, p1_n, ptr, work, [&] {
+                if (wave == 0) fetch_tile<KCP>(s0, tile_of(Lp2, KCP, 0), lane);
+            });
         }
         __syncthreads();
         MZ_STAMP(4)  // policy 2 (leaf + child)
 
         // ---- policy 3 (narrow), softmax; priors of the leaf, greedy action of the child ----------------------
         {
-            Team all = whole_workgroup();
-            dense_narrow<LdsNarrowWeights>(H2, ld_q, 2 * kTrees, nullptr, nullptr, Nw, Lp2.Kp, Lp2.N, Lp2.act, Lg, ld_l, 0, kWaves);
+            if (wave == 0) {  // policy 3 of the 32 rows -> logits (fp32 rows; the layer's own softmax follows)
+                f32x4 hi[2], lo[2];
+                mma_tile<KCP, 2>(s0, H2 + lane * 4, 16 * ld_q, hi, lo);
+                epi_rows<2, false>(hi, lo, 0, lds4(Bp2 + 4 * (lane >> 4)), Lg, ld_l, lane);
+            }
             __syncthreads();
-            softmax_rows(Lg, ld_l, 2 * kTrees, A, 1, all);   // the network's own softmax (both row tiles)
-            if (tid >= kThreads - kTrees) {  // first maximum of the child's policy (src/search/simulation.py:36)
-                const int t = tid - (kThreads - kTrees);
-                const lds_f *row = Lg + (kTrees + t) * ld_l;
-                int best = 0;
-                for (int a = 1; a < A; ++a)
-                    if (row[a] > row[best]) best = a;
-                s_act2[t] = best;
+            MZ_STAMP(19)  // policy 3
+            // softmax_rows' arithmetic for A <= 8 (row maximum and sum over the columns in ascending order) with the
+            // row's values exchanged through LDS instead of lane by lane: eight lanes per row, all 32 rows at once --
+            // the network's own softmax; then the first maximum of the child's policy (src/search/simulation.py:36)
+            // and expand_node's extra softmax for the leaf (src/search/expansion.py:27), without a barrier in between
+            // (a row's eight lanes sit in one wave)
+            if (tid < 2 * kTrees * 8) {
+                const int row = tid >> 3, jx = tid & 7;
+                lds_f *lr = Lg + row * ld_l;
+                auto softmax8 = [&](float v) {
+                    const f32x4 a0 = lds4(lr), a1 = lds4(lr + 4);
+                    const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    float mx = x[0];
+                    for (int i = 1; i < A; ++i) mx = fmaxf(mx, x[i]);
+                    const float ev = expf(v - mx);
+                    lr[8 + jx] = ev;  // columns 8 .. 15 of the row are free
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const f32x4 e0 = lds4(lr + 8), e1 = lds4(lr + 12);
+                    const float ex[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                    float sum = 0.0f;
+                    for (int i = 0; i < A; ++i) sum += ex[i];
+                    return ev / sum;
+                };
+                const bool live = jx < A;
+                float v = live ? lr[jx] : 0.0f;
+                v = softmax8(v);
+                __builtin_amdgcn_wave_barrier();
+                if (live) lr[jx] = v;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (row >= kTrees) {
+                    if (jx == 0) {
+                        int best = 0;
+                        for (int a = 1; a < A; ++a)
+                            if (lr[a] > lr[best]) best = a;
+                        s_act2[row - kTrees] = best;
+                    }
+                } else {
+                    v = softmax8(v);
+                    if (live) {
+                        const int t = row;
+                        s_prior[t * A + jx] = v;
+                        if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + jx] = v;
+                    }
+                }
             }
-            softmax_rows(Lg, ld_l, kTrees, A, 1, all);       // expand_node's extra softmax (src/search/expansion.py:27)
-            for (int i = tid; i < kTrees * A; i += kThreads) {
-                const int t = i / A, a = i - t * A;
-                const float pr = Lg[t * ld_l + a];
-                s_prior[i] = pr;
-                if (q.prior_trace && t < trees) q.prior_trace[((size_t)(g0 + t) * (S + 1) + e) * A + a] = pr;
-            }
+            __syncthreads();
         }
         MZ_STAMP(5)  // policy 3, softmax, priors, greedy action
-        if (sim) prefetch(v0_tile0, KCD);  // value 1's first tile, in flight while the latents below are formed
+        if (sim) prefetch2(v0_tile0, v0_tile1, KCD);  // value 1's tiles, in flight while the latents below are formed
         // ---- rollout latent; first pass of row tiles for reward 1 ---------------------------------------
         if (sim)
             for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
@@ -589,13 +653,15 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                          f32x4 hi[1], lo[1];
                          mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
                          epi_split<1, true>(hi, lo, t, lds4(Bv0 + t * 16 + 4 * (lane >> 4)), Hv, 16 * ld_v, KCV, nv0, lane);
-                     });
-            prefetch(v1_tile, KCV);  // value 2
+                     },
+                     nothing);
+            fetch_tile<KCV>(s0, v1_tile, lane);  // value 2 and
+            fetch_tile<KCD>(s1, r0_tile, lane);  // reward 1: in flight through the barrier
             __syncthreads();
             MZ_STAMP(7)  // value 1
         }
         // ---- value 2 (slot 0) | reward 1 over the first pass (slot 1, kept for the later passes) ------------------
-        fetch_tile<KCD>(s1, r0_tile, lane);
+        if (!sim) fetch_tile<KCD>(s1, r0_tile, lane);
         if (sim && wave < nv1) {
             f32x4 hi[1], lo[1];
             mma_tile<KCV, 1>(s0, Hv + lane * 4, 0, hi, lo);
@@ -606,16 +672,17 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         MZ_STAMP(8)  // value 2 | reward 1, first pass
         for (int p0 = kPassTiles; p0 < A + 1; p0 += kPassTiles) {
             finish_pass(p0 - kPassTiles, sim);
+            MZ_STAMP(12)  // rewards of the previous pass
             form_pass(p0, sim);
             __syncthreads();
+            MZ_STAMP(13)  // row tiles of the pass
             reward_pass(s1);
             __syncthreads();
+            MZ_STAMP(14)  // reward 1 over the pass
         }
         finish_pass(((A + 1 - 1) / kPassTiles) * kPassTiles, sim);
         if (sim && tid < kTrees) {  // value of the rollout latent (as finish_dot)
-            float sum = 0.0f;
-            for (int k = 0; k < 4 * nv1; ++k) sum += DotV[k * kTrees + tid];
-            s_roll[tid * 2 + 1] = activate(sum + Bv1[Lv1.Np], Lv2.act);
+            s_roll[tid * 2 + 1] = activate(ordered_sum(DotV + tid, kTrees, 4 * nv1) + Bv1[Lv1.Np], Lv2.act);
         }
         __syncthreads();
         MZ_STAMP(9)  // remaining passes, rewards, value
@@ -699,8 +766,8 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
     const mz_packed_nets &P = *plan;
     if (pool->latent != nullptr || prm->z_pool == nullptr || prm->depth != 1 || P.A > 32) return 0;
     if (P.policy.n_layers != 3 || P.value.n_layers != 3 || P.reward.n_layers != 2) return 0;
-    if (!is_matrix_layer(P.policy.layer[0]) || !is_matrix_layer(P.policy.layer[1]) || is_matrix_layer(P.policy.layer[2]) ||
-        P.policy.layer[2].act != MZ_ACT_SOFTMAX || P.policy.layer[2].N != P.A || P.A > 8)
+    if (!is_matrix_layer(P.policy.layer[0]) || !is_matrix_layer(P.policy.layer[1]) || !is_matrix_layer(P.policy.layer[2]) ||
+        P.policy.layer[2].act != MZ_ACT_SOFTMAX || P.policy.layer[2].N != P.A || P.A > 8 || P.policy.layer[2].Kp != P.policy.layer[1].Kp)
         return 0;
     if (!is_matrix_layer(P.value.layer[0]) || !tail_foldable(P.value) || !is_matrix_layer(P.reward.layer[0]) || !tail_foldable(P.reward))
         return 0;

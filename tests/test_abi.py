@@ -45,10 +45,18 @@ def test_host_only_entry_points():
     m.layer[1] = _hip.Dense(1, None, 256, 7, 4, 0)
     plan = _hip.PackedMlp()
     n = _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan))
-    # tiles + padded bias per layer, 4 KiB read slack: the 256-output layer runs on the matrix cores (K padded to
-    # 32, two fp16 planes = 4 bytes per weight), the 7-output layer on the vector ALU from fp32 tiles (K padded to 16)
+    # tiles + padded bias per layer, 4 KiB read slack: both layers run on the matrix cores (K padded to 32, two fp16
+    # planes = 4 bytes per weight)
     assert n == 192 * 256 + 256 + 256 * 16 + 16 + 1024
-    assert (plan.layer[0].fmt, plan.layer[0].Kp, plan.layer[1].fmt, plan.layer[1].Kp) == (1, 192, 0, 256)
+    assert (plan.layer[0].fmt, plan.layer[0].Kp, plan.layer[1].fmt, plan.layer[1].Kp) == (1, 192, 1, 256)
+    # a one-output layer behind a wide layer keeps fp32 tiles: it is folded into that layer's epilogue
+    m2 = _hip.Mlp()
+    m2.n_layers = 2
+    m2.layer[0] = _hip.Dense(1, None, 168, 128, 1, 0)
+    m2.layer[1] = _hip.Dense(1, None, 128, 1, 0, 0)
+    plan2 = _hip.PackedMlp()
+    assert _hip.lib().mz_mlp_plan(ctypes.byref(m2), 0, ctypes.byref(plan2)) > 0
+    assert (plan2.layer[0].fmt, plan2.layer[1].fmt, plan2.layer[1].Kp) == (1, 0, 128)
     assert (plan.in_features, plan.out_features, plan.max_width) == (168, 7, 256)
     m.layer[1].in_features = 255  # chain mismatch must be rejected with a message
     assert _hip.lib().mz_mlp_plan(ctypes.byref(m), 0, ctypes.byref(plan)) < 0
