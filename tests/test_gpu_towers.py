@@ -1113,3 +1113,141 @@ def nets_latent_from_t(nets, g, t64):
     b = fin.bias.double().cuda() if fin.bias is not None else torch.zeros(c, dtype=torch.float64, device="cuda")
     tt = t64.view(t64.shape[0], -1, hgt * wid)
     return (torch.einsum("ck,rkp->rcp", w, tt) + b[None, :, None]).reshape(t64.shape[0], -1)
+
+
+@pytest.mark.parametrize("G", [256, 4096])
+def test_tower_search_in_the_benchmarked_form(G):
+    """The tower search exactly as bench.py times it (bench.py: tower_search): roots given as the bottleneck values
+    of h's final convolution (`root_t`), no stored latents, fc_merge fused with the first convolution on bf16 planes,
+    50 simulations, at 256 and at 4096 trees:
+      (i)   launch by launch with tracing: the search's own network outputs replayed through the CPU tree oracle give
+            EVERY tree bit for bit; the whole-search graph replay leaves the same pool;
+      (ii)  against the separate fp32 kernels started from the full root latents: a tree either takes the same
+            descents with the same rollouts, or its first difference is a PROVEN near tie (tests.gpu_util.explain_divergence);
+      (iii) on 8 trees the prior / reward / rollout streams of the fused run equal the torch modules called one
+            reference call at a time (src/search/expansion.py:25-33, src/search/simulation.py:31-44) on the latents
+            its bottleneck values stand for, to 1e-5 of each output's scale."""
+    from muzero_amd.engine import BatchedMCTS
+    from muzero_amd.towers import TowerNetworks
+    from tests.gpu_util import explain_divergence
+    from tools.bench_towers import build_nets
+    shape, A, S, depth = (256, 6, 6), 5, 50, 1
+    D = 9216
+    g, f = build_nets(shape, A)
+    with torch.no_grad():
+        for m in list(g.modules()) + list(f.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    torch.manual_seed(1)
+    fin = torch.nn.Conv2d(3, shape[0], 1).cuda()
+    fused = TowerNetworks(g, f, root_final=fin)
+    plain = TowerNetworks(g, f, fuse_merge_conv=False)
+    assert fused.fused_g and fused.has_root_form and not plain.fused_g and G >= fused.fuse_min_rows
+    rng = np.random.default_rng(40 + G)
+    root_t = torch.from_numpy(rng.standard_normal((G, 3, shape[1], shape[2])).astype(np.float32)).cuda()
+    with torch.no_grad():
+        lat = fin(root_t).reshape(G, D).contiguous()
+    eta = rng.dirichlet(np.full(A, 0.3), size=G).astype(np.float32)
+    rand = rng.integers(0, A, size=(G, S + 1)).astype(np.int32)
+    to_play = np.zeros(G, np.int8)
+    d_tp, d_eta, d_rand = [torch.from_numpy(x).cuda() for x in (to_play, eta, rand)]
+
+    def searched(networks, rooted):
+        mcts = BatchedMCTS(networks, G, S, depth, discount=0.998, noise_frac=0.25, keep_latents=False)
+        kw = {"root_t": root_t} if rooted else {}
+        assert mcts.t_pool is not None and not mcts.keep_latents and mcts.root_form_ok(kw.get("root_t")) == rooted
+        trace = {}
+        res = mcts.run(None if rooted else lat, d_tp, d_eta, d_rand, trace=trace, **kw)   # launch by launch (tracing)
+        torch.cuda.synchronize()
+        pool = mcts.pool
+        prior_s = np.stack([p.cpu().numpy() for p in trace["prior"]], axis=1)
+        rollout = np.stack([r.cpu().numpy() for r in trace["rollout"]], axis=1)
+        leaf = np.stack([x.cpu().numpy() for x in trace["leaf"]], axis=1)
+        child = np.stack([x.cpu().numpy() for x in trace["child"]], axis=1)
+        reward_nodes = pool.reward.cpu().numpy()
+        root_prior = torch.empty(G, A, device="cuda")
+        rows0 = (torch.arange(G, device="cuda", dtype=torch.int32) * pool.cap).contiguous()
+        if rooted:   # the root's pre-noise priors, evaluated as the search evaluated them
+            networks.prediction(pool.latent, G, rows=rows0, softmax_times=1, policy=root_prior, t_in=(mcts.t_pool, rows0),
+                                root_form=True)
+        else:
+            networks.prediction(lat, G, softmax_times=1, policy=root_prior)
+        prior_stream = np.concatenate([root_prior.cpu().numpy()[:, None], prior_s], axis=1)
+        reward_stream = np.stack([reward_nodes[:, 1 + e * A:1 + (e + 1) * A] for e in range(S + 1)], axis=1)
+        ref = otree.run_batch(A, S, depth, to_play, prior_stream, reward_stream, rand, rollout, eta, 0.25, 0.998)
+        assert np.array_equal(leaf, ref["leaf"]) and np.array_equal(child, ref["child"])
+        for name in ("visit", "value_sum", "prior", "first_child", "parent"):
+            assert np.array_equal(getattr(pool, name).cpu().numpy(), ref[name]), name
+        assert np.array_equal(res.value.cpu().numpy(), ref["utility"])
+        np.testing.assert_allclose(res.policy.cpu().numpy(), ref["policy"], rtol=1e-12)
+        stats = {n: getattr(pool, n).clone() for n in ("visit", "value_sum", "prior", "reward", "parent", "first_child")}
+        for _ in range(2):   # the first records the graph (the whole search when it starts from root_t), both replay it
+            res2 = mcts.run(None if rooted else lat, d_tp, d_eta, d_rand, **kw)
+            torch.cuda.synchronize()
+            for n, want in stats.items():
+                assert torch.equal(getattr(pool, n), want), f"graph replay: {n}"
+            assert torch.equal(res2.policy32, res.policy32) and torch.equal(res2.value, res.value)
+        assert mcts.replays == 2, "the recorded graph was not used"
+        return dict(prior=prior_stream, reward=reward_stream, rollout=rollout, leaf=leaf, child=child, mcts=mcts)
+
+    a = searched(fused, True)       # the benchmarked form
+    b = searched(plain, False)      # separate fp32 kernels, full root latents
+    assert not np.array_equal(a["prior"], b["prior"]), "the two runs went through the same kernels"
+
+    # ---- (ii) every divergence a proven near tie
+    t_pool, cap = a["mcts"].t_pool, a["mcts"].pool.cap
+
+    def policy_of_child(gi, s):   # f's policy for the child simulation s started from, from the fused run's own values
+        row = torch.tensor([gi * cap + int(a["child"][gi, s])], dtype=torch.int32, device="cuda")
+        out = torch.empty(1, A, device="cuda")
+        fused.prediction(a["mcts"].pool.latent, 1, rows=row, softmax_times=0, policy=out, t_in=(t_pool, row))
+        return out[0].cpu().numpy()
+    flips = {"select": 0, "rollout": 0}
+    same = 0
+    for gi in range(G):
+        why = explain_divergence(a, b, gi, A, S, depth, to_play, eta, rand, 0.25, 0.998, policy_of_child)
+        if why is None:
+            same += 1
+            for n in ("prior", "reward", "rollout"):
+                np.testing.assert_allclose(a[n][gi], b[n][gi], rtol=1e-5, atol=max(1e-5 * float(np.abs(b[n][gi]).max()), TOL["atol"]),
+                                           err_msg=f"{n} tree {gi}")
+        else:
+            flips[why[0]] += 1
+    print(f"{G} trees: {same} identical descents, {flips['select']} proven selection near ties, "
+          f"{flips['rollout']} proven greedy-action near ties")
+    assert same + flips["select"] + flips["rollout"] == G and same >= 0.8 * G
+
+    # ---- (iii) the torch modules, one reference call at a time, on the fused run's own latents
+    gt, ft = g.cuda(), f.cuda()
+    acts = torch.arange(A, device="cuda")
+
+    def latent_of(gi, node):   # the latent a node's bottleneck values stand for (the root: h's final convolution of root_t)
+        if node == 0:
+            return lat[gi].reshape(1, *shape)
+        t64 = t_pool[gi * cap + node].double().reshape(1, -1)
+        return nets_latent_from_t(fused, g, t64).float().reshape(1, *shape)
+
+    def close(got, want, what):
+        want = want.detach().cpu().numpy()
+        np.testing.assert_allclose(np.asarray(got).reshape(want.shape), want, rtol=1e-5,
+                                   atol=max(1e-5 * float(np.abs(want).max()), TOL["atol"]), err_msg=what)
+    near_ties = 0
+    with torch.no_grad():
+        for gi in range(0, G, G // 8):
+            for s in list(range(0, S, 7)) + [S - 1]:
+                x = latent_of(gi, int(a["leaf"][gi, s]))
+                close(a["prior"][gi, s + 1], torch.softmax(ft(x)[0], dim=1)[0], f"prior tree {gi} sim {s}")
+                _, rew = gt(x.repeat(A, 1, 1, 1), acts)   # ONE call: batch statistics over the A children
+                close(a["reward"][gi, s + 1], rew[:, 0], f"reward tree {gi} sim {s}")
+                cur = latent_of(gi, int(a["child"][gi, s]))
+                pol = ft(cur)[0][0]
+                top2 = pol.topk(2).values
+                if float(top2[0] - top2[1]) <= 1e-5 * float(top2[0]):
+                    near_ties += 1
+                    continue
+                cur, r = gt(cur, pol.argmax().reshape(1))
+                v = ft(cur)[1]
+                close(a["rollout"][gi, s], torch.stack([r[0, 0], v[0, 0]]), f"rollout tree {gi} sim {s}")
+    assert near_ties <= 2
+    g.cpu(), f.cpu()
