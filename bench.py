@@ -27,7 +27,11 @@ if ROOT not in sys.path:
 
 A, D = 7, 168
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak
+F16_MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 matrix peak (v_mfma_f32_16x16x32_f16: 16384 flop per 16 cycles on 1024 SIMDs at 2.4 GHz)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak
+F16_PRODUCTS_PER_FP32_PRODUCT = 3  # operands as two fp16 planes: hi*hi, hi*lo, lo*hi
+ROOFLINE_SCHEMA = 3  # 1: achieved = algorithmic fp32 flops / fp32 peak; 2: achieved = executed fp32 matrix flops / fp32 peak;
+#                      3: achieved = algorithmic flops against the fp32-accurate rate of the fp16 pipe (fp16 peak / 3), executed beside it
 HBM_PEAK_GBS = 8000.0
 
 
@@ -101,6 +105,21 @@ def search_flop_per_tree(plan, S, depth):
     return (S + 1) * expand + S * simulate
 
 
+def mlp_f16_flop(p):
+    """fp16 matrix-instruction flops one row of an MLP costs: three products per padded (Kp x Np) weight block;
+    one-output tail layers folded into the previous layer's epilogue run on the vector ALUs and count nothing."""
+    return sum(F16_PRODUCTS_PER_FP32_PRODUCT * 2 * p.layer[i].Kp * p.layer[i].Np for i in range(p.n_layers) if p.layer[i].fmt == 1)
+
+
+def search_f16_flop_per_tree(plan, S, depth):
+    """What the matrix pipe executes per tree in the two-plane fp16 form (rows are whole 16-row tiles at the
+    benchmarked sizes: 16 trees per workgroup, 16 * A child rows)."""
+    merge = mlp_f16_flop(plan.merge)
+    expand = mlp_f16_flop(plan.policy) + merge + A * mlp_f16_flop(plan.reward)
+    simulate = depth * (mlp_f16_flop(plan.policy) + merge + mlp_f16_flop(plan.reward)) + mlp_f16_flop(plan.value)
+    return (S + 1) * expand + S * simulate
+
+
 def reference_flop_per_sim(plan, depth):
     """Network flops per simulation in the reference's own formulation (what a per-node
     implementation evaluates): (2 + depth) full f calls -- both heads each time -- and
@@ -113,16 +132,22 @@ def reference_flop_per_sim(plan, depth):
 
 
 TREE_BYTES_PER_SIM = 168 * 2 + 272          # select + child records + backup at A = 7, leaf depth 2
-LATENT_BYTES_PER_SIM = 4 * D * (A + 2)      # read the leaf, write A children, read the drawn child
+LATENT_BYTES_PER_SIM = 4 * D * (A + 2)      # stored latents: read the leaf, write A children, read the drawn child
+IMPLICIT_LATENT_BYTES_PER_SIM = 4 * D * 2   # one merge row per expansion: read the parent's row, write the leaf's
 
 
-def kernel_rooflines(mcts, plan, step):
+def kernel_rooflines(mcts, plan, step, stored, stored_step):
     """Times (HIP events on the launch stream) the fused search kernel, which is the whole
-    step, and the per-stage network kernels in the shapes the lock-step path launches them."""
-    nets, pool, G = mcts.nets, mcts.pool, mcts.G
+    step, and the per-stage network kernels in the shapes the lock-step path launches them
+    (`stored`: an engine that keeps every node's latent, which those kernels read)."""
+    nets, G = mcts.nets, mcts.G
     out = {}
-    out["k_search[fused MCTS.run]"] = dict(s=time_kernel(step, iters=5), flop=G * search_flop_per_tree(plan, mcts.S, mcts.depth),
+    out["k_search[fused MCTS.run]"] = dict(s=time_kernel(step, iters=20), flop=G * search_flop_per_tree(plan, mcts.S, mcts.depth),
                                            calls=1.0 / mcts.S)
+    out["k_search[fused MCTS.run, stored latents]"] = dict(s=time_kernel(stored_step, iters=10),
+                                                           flop=G * search_flop_per_tree(plan, mcts.S, mcts.depth), calls=0)
+    mcts = stored
+    pool = mcts.pool
     rows = (mcts.tree_base + 1).contiguous()
     rows_rep = rows.repeat_interleave(A)
     base = 1 + A
@@ -194,20 +219,22 @@ def cpu_baseline_all_cores(budget_s=10.0):
             "sample": f"{ok} processes x {budget_s:.0f}s of single-game MCTS.run calls, 1 torch thread each"}
 
 
-PMC_TRAFFIC_FILES = ("r2_search_pmc_traffic.json", "r1_f_pmc_traffic.json")  # newest first
+PMC_FILES = {"search": "r3_search_pmc.json", "search_stored": "r3_search_stored_pmc.json",
+             "towers_256": "r3_towers_256_pmc.json", "towers_4096": "r3_towers_4096_pmc.json"}
 
 
-def pmc_traffic(G, S):
-    """(HBM bytes per launch of the search kernel, file) from the newest committed counter passes
-    (FETCH_SIZE and WRITE_SIZE need separate profiler runs, so they cannot be collected inside
-    this process); (None, None) when the workload differs from the profiled one."""
-    if (G, S) != (4096, 50):
+def pmc_traffic(which, kernel):
+    """(HBM bytes per launch of `kernel`, file) from the committed counter passes (tools/r3_profiles.sh: FETCH_SIZE
+    and WRITE_SIZE need separate profiler runs, so they cannot be collected inside this process); (None, None) when
+    there is no such record."""
+    path = os.path.join(ROOT, "profiles", PMC_FILES.get(which, "-"))
+    if not os.path.exists(path):
         return None, None
-    for name in PMC_TRAFFIC_FILES:
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            with open(path) as fh:
-                return json.load(fh)["hbm_bytes_per_launch"], "profiles/" + name
+    with open(path) as fh:
+        doc = json.load(fh)
+    for name, e in doc["kernels"].items():
+        if name.startswith(kernel) and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"], "profiles/" + PMC_FILES[which]
     return None, None
 
 
@@ -258,7 +285,11 @@ def tower_search(G, S, dev, steps, with_roofline):
         flop = 2.0 * G * nets.merge_t_perm.Kp * D + 2.0 * G * A * hw * shape[0] * 32
         from tools.bench_towers import merge_conv_roofline
         out["roofline_tower"] = merge_conv_roofline(nets, G, A, D, hw, shape[0], s, flop)
-        out["roofline_tower"]["traffic"] = None
+        # the expansion call's launches (A actions per tree) dominate that kernel's record
+        out["roofline_tower"]["traffic"], out["roofline_tower"]["traffic_source"] = pmc_traffic(f"towers_{G}", "k_merge_conv_bf")
+        if out["roofline_tower"]["traffic_source"]:
+            out["roofline_tower"]["traffic_source"] += (" (mean over the kernel's launches in a search: expansion calls, "
+                                                        "as timed here, alternate with rollout-step calls of 1/A the rows)")
     del mcts, nets
     torch.cuda.empty_cache()
     return out
@@ -297,8 +328,11 @@ def main():
                          "expansion (self-play's form; bit-identical trees)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--selfplay-moves", type=int, default=8, help="timed self-play moves per game (0 = skip)")
-    ap.add_argument("--min-seconds", type=float, default=1.5,
-                    help="after the K timed steps, keep stepping for this long (a sustained-rate figure)")
+    ap.add_argument("--min-seconds", type=float, default=6.0,
+                    help="after the K timed steps, keep stepping for this long (a sustained-rate figure; longer than a "
+                         "5-second utilisation sampler's period)")
+    ap.add_argument("--more-games", type=int, nargs="*", default=[8192, 16384],
+                    help="also time the search at these game counts per GPU (secondary figures; empty = skip)")
     ap.add_argument("--tower-games", type=int, nargs="*", default=[256, 4096],
                     help="also time the residual-tower search at these tree counts (empty = skip)")
     ap.add_argument("--cpu-worker", nargs=2, metavar=("SEED", "SECONDS"), help="internal: one CPU-baseline process")
@@ -342,6 +376,13 @@ def main():
     def fence():
         sharding.fence(dist)
 
+    # set-up, not part of the measurement: the first call records the launch graph, and a few hundred
+    # milliseconds of the same step bring the chip from its idle clocks to the state a running job is in
+    step()
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.5:
+        step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     dt = sharding.timed_steps(step, args.steps, dist, device=dev)  # barrier + sync both sides, max over ranks
@@ -352,10 +393,14 @@ def main():
         "metric": "mcts_simulations_per_sec", "value": sharding.whole_job_rate(G * S, args.steps, world, dt),
         "unit": "sims/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (products as 3 fp16 matrix products on two-plane operands, f32 accumulate) + f64 tree", "data": "synthetic",
         "config": {"workload": f"c4_mlp: {G} Connect-Four games per GPU x {S} sims/move, A=7, D=168, "
                                "model_look_ahead=1, noise_frac=0.25 (fixed eta), MT19937 child-choice streams",
-                   "games_per_gpu": G, "sims_per_move": S, "parallelism": f"games sharded x{world}, no collective"},
+                   "games_per_gpu": G, "sims_per_move": S, "parallelism": f"games sharded x{world}, no collective",
+                   "latents": "every node's latent stored" if args.store_latents else
+                              "one merge row per expansion; a child's latent is relu(row + table[action]) when read (self-play's "
+                              "form; trees, policies and values bit-identical to the stored form)"},
         "searches_per_sec": world * G * args.steps / dt,
     }
     if dist is not None:
@@ -388,28 +433,51 @@ def main():
         line["selfplay_env_steps_per_sec"] = world * G * args.selfplay_moves / dts
         line["selfplay_ms_per_move"] = dts / args.selfplay_moves * 1e3
     if rank == 0 and not args.no_roofline:
-        ks = kernel_rooflines(mcts, nets.plan, step)
+        stored = mcts if args.store_latents else BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev,
+                                                             keep_latents=True)
+        ks = kernel_rooflines(mcts, nets.plan, step, stored, lambda: stored.run(latent, to_play, eta, rand))
+        del stored
         dom = "k_search[fused MCTS.run]"
-        # `achieved`: algorithmic flops of one launch (reference formulation x G*S simulations)
-        # over the kernel's measured duration.  The kernel EXECUTES fewer flops for the same
-        # results (heads whose output the search discards are skipped, the merge layer is split
-        # into W[:, :D] x + a per-action table): `executed_*` is what the MFMA pipe really does.
+        # `achieved`: ALGORITHMIC flops of one launch (the reference's formulation x G*S simulations) over the
+        # kernel's measured duration.  The kernel computes every float32 product as three fp16 matrix products
+        # (operands as two fp16 planes, float32 accumulation: float32-accurate results), so the rate such
+        # arithmetic can reach is a third of the fp16 pipe's peak: that is `peak`.  What the pipe really runs
+        # (fewer products than the reference formulation: discarded heads skipped, the merge layer split into
+        # W[:, :D] x + a per-action table; more flops per product: three, on padded tiles) is `executed_*`.
         alg = G * S * reference_flop_per_sim(nets.plan, mcts.depth)
+        exe = G * search_f16_flop_per_tree(nets.plan, S, mcts.depth)
         tf_alg = alg / ks[dom]["s"] / 1e12
-        tf_exe = ks[dom]["flop"] / ks[dom]["s"] / 1e12
-        traffic, traffic_file = pmc_traffic(G, S)
-        # `achieved` / `frac`: what the MFMA pipe EXECUTES (the utilisation figure); the reference
-        # formulation's flops over the same duration are kept beside it as `algorithmic_*`
-        line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tf_exe, "peak": FP32_MFMA_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": tf_exe / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+        tf_exe = exe / ks[dom]["s"] / 1e12
+        peak = F16_MFMA_PEAK_TFLOPS / F16_PRODUCTS_PER_FP32_PRODUCT
+        traffic, traffic_file = pmc_traffic("search_stored" if args.store_latents else "search", "k_search") \
+            if (G, S) == (4096, 50) else (None, None)
+        lat_bytes = LATENT_BYTES_PER_SIM if args.store_latents else IMPLICIT_LATENT_BYTES_PER_SIM
+        line["roofline"] = {"schema": ROOFLINE_SCHEMA, "bound": "mfma", "kernel": dom, "achieved": tf_alg, "peak": peak,
+                            "unit": "TFLOP/s", "frac": tf_alg / peak,
+                            "peak_note": "dense fp16 matrix peak 2500 TFLOP/s / 3 fp16 products per float32-accurate product",
+                            "traffic": traffic,
                             "traffic_source": f"committed profile ({traffic_file}), not measured in this run",
                             "avg_launch_us": ks[dom]["s"] * 1e6, "algorithmic_flop_per_launch": alg,
-                            "executed_flop_per_launch": ks[dom]["flop"], "executed_tflops": tf_exe,
-                            "executed_frac": tf_exe / FP32_MFMA_PEAK_TFLOPS,
-                            "algorithmic_tflops": tf_alg, "algorithmic_frac": tf_alg / FP32_MFMA_PEAK_TFLOPS,
-                            "algorithmic_hbm_GBps": G * S * (TREE_BYTES_PER_SIM + LATENT_BYTES_PER_SIM) / ks[dom]["s"] / 1e9,
+                            "algorithmic_tflops": tf_alg, "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                            "fp32_equivalent_frac": tf_alg / FP32_MFMA_PEAK_TFLOPS,
+                            "executed_f16_flop_per_launch": exe, "executed_f16_tflops": tf_exe,
+                            "f16_mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS, "executed_frac": tf_exe / F16_MFMA_PEAK_TFLOPS,
+                            "algorithmic_hbm_GBps": G * S * (TREE_BYTES_PER_SIM + lat_bytes) / ks[dom]["s"] / 1e9,
                             "hbm_peak_GBps": 8000.0}
         line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
+    if rank == 0 and args.more_games:
+        # secondary figures: more games per GPU (two or four 16-tree workgroups per compute unit)
+        line["more_games"] = {}
+        for mg in args.more_games:
+            m2 = BatchedMCTS(nets, mg, S, 1, discount=0.998, noise_frac=0.25, device=dev, keep_latents=args.store_latents)
+            reps = (mg + G - 1) // G
+            lat2, tp2 = latent.repeat(reps, 1)[:mg].contiguous(), to_play.repeat(reps)[:mg].contiguous()
+            eta2, rand2 = eta.repeat(reps, 1)[:mg].contiguous(), rand.repeat(reps, 1)[:mg].contiguous()
+            s2 = time_kernel(lambda: m2.run(lat2, tp2, eta2, rand2), iters=10)
+            assert int(m2.finish().visits.sum().item()) == mg * S
+            line["more_games"][str(mg)] = {"sims_per_sec": mg * S / s2, "ms_per_step": s2 * 1e3}
+            del m2, lat2, tp2, eta2, rand2
+            torch.cuda.empty_cache()
     if rank == 0 and args.tower_games:
         del mcts
         torch.cuda.empty_cache()

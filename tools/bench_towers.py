@@ -33,16 +33,6 @@ def pmc_traffic():
         return None
 
 
-def pmc_tower_traffic(G):
-    """HBM bytes per launch of the tower kernel's rollout-step call from the committed counter passes."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_i_tower_pmc_traffic.json")) as fh:
-            d = json.load(fh)
-        return d["hbm_bytes_per_launch"] if d.get("groups") == G else None
-    except (OSError, KeyError, ValueError):
-        return None
-
-
 def build_nets(shape, A):
     from muzero_amd.config import DenseLayerConfig, DynamicsNetworkConfig, PredictionNetworkConfig, ResBlockConfig
     from muzero_amd.neural_networks import DynamicsNetwork, PredictionNetwork
