@@ -50,10 +50,9 @@ class HostEnvPool:
         return (self._obs.to(self.device, non_blocking=True).clone(),
                 self._to_play.to(self.device, non_blocking=True).clone())
 
-    def step(self, action: torch.Tensor):
-        """action i32[G] (device or host).  Returns reward f32[G], done i8[G] on the device."""
-        acts = action.detach().to("cpu").tolist()
-
+    def step_host(self, acts):
+        """acts: G ints on the host.  Steps every simulator; returns reward f32[G], done i8[G] as host tensors
+        (copies).  Touches no device: a caller that overlaps this with GPU work never waits for the stream."""
         def one(i: int) -> None:
             state, reward, done = self.envs[i].step(int(acts[i]))
             self._reward[i] = float(reward)
@@ -61,17 +60,24 @@ class HostEnvPool:
             self._store(i, state)
 
         self._map(one, range(self.G))
+        return self._reward.clone(), self._done.clone()
+
+    def step(self, action: torch.Tensor):
+        """action i32[G] (device or host).  Returns reward f32[G], done i8[G] on the device."""
+        self.step_host(action.detach().to("cpu").tolist())
         return (self._reward.to(self.device, non_blocking=True).clone(),
                 self._done.to(self.device, non_blocking=True).clone())
 
-    def reset(self, mask: torch.Tensor | None = None) -> None:
-        """Restarts the games whose mask entry is non-zero (all games when mask is None)."""
-        which = range(self.G) if mask is None else torch.nonzero(mask.detach().to("cpu")).reshape(-1).tolist()
-
+    def reset_host(self, which) -> None:
+        """Restarts the games with the given indices (host ints)."""
         def one(i: int) -> None:
             self._store(i, self.envs[i].reset())
 
         self._map(one, which)
+
+    def reset(self, mask: torch.Tensor | None = None) -> None:
+        """Restarts the games whose mask entry is non-zero (all games when mask is None)."""
+        self.reset_host(range(self.G) if mask is None else torch.nonzero(mask.detach().to("cpu")).reshape(-1).tolist())
 
     def close(self) -> None:
         if self._pool is not None:

@@ -128,81 +128,27 @@ def pick_action(policy32: torch.Tensor, explore: torch.Tensor | None, random_act
     return out
 
 
-class SelfPlayEngine:
-    def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0,
-                 device_rng: bool = False, env=None, track_running_stats: bool = False):
-        """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps).
-        `env`: a batched environment (`observe`, `step`, `reset(mask)`, `num_actions`,
-        `observation_space`); default: G Connect-Four games on the GPU.  Host-side simulators go
-        through `muzero_amd.environments.host_pool.HostEnvPool`.
+class MoveStreams:
+    """The random inputs of one lock-step move of G games: child draws i32[G, S+1], Dirichlet noise f32[G, A],
+    exploration coin i8[G] and the uniform action i32[G] (src/training_data_generator.py:107-142 draws them
+    from three global generators, game after game).  One numpy Generator on the host (reproducible against
+    a CPU replay), or torch's generator on the device (`device_rng`: the whole move stays on the GPU)."""
 
-        The search consumes no random numbers itself: the Dirichlet noise, the child draws and the
-        exploration decisions of a move are inputs.  By default they come from a numpy generator on
-        the host (reproducible against a CPU replay); `device_rng=True` draws them on the GPU with
-        torch's generator instead, which keeps the whole move on the device.
-
-        `track_running_stats`: the BatchNorm running statistics of h, g and f advance with every network
-        call as the reference's train-mode calls make them (no output depends on them);
-        `sync_running_stats()` writes them back into the three modules."""
-        self.G, self.cfg = G, config
-        self.device = torch.device(device)
-        m = config.mcts
-        if m.max_iterations <= 0:
-            raise ValueError("batched self-play needs max_iterations > 0 (the time-bounded mode is single-game only)")
-        self.env = env if env is not None else BatchedConnectFour(G, device=device)
-        assert getattr(self.env, "G", G) == G, "the environment batch must hold G games"
-        self.A = self.env.num_actions
-        self.h = RepresentationRunner(repr_net, device=device, track_running_stats=track_running_stats)
-        # with a representation network that ends in a 1x1 convolution of a few channels, a residual-tower search starts
-        # from those channels' pooled values (the bottleneck form of its expansions) instead of the 256-channel latent
-        self._root_final = self.h.root_final()
-        self.nets = make_networks(dyn_net, pred_net, device=device, track_running_stats=track_running_stats,
-                                  root_final=self._root_final)
-        self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
-                                device=device, keep_latents=False)  # nothing here reads the children's latents
-        self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
+    def __init__(self, G: int, A: int, S: int, config, device, seed: int = 0, device_rng: bool = False):
+        self.G, self.A, self.S, self.cfg, self.device = G, A, S, config, torch.device(device)
+        self.alpha = config.mcts.dirichlet_alpha
         self.rng = np.random.default_rng(seed)
         self.device_rng = device_rng
         if device_rng:
             self.gen = torch.Generator(device=self.device)
             self.gen.manual_seed(seed)
-            self._alpha = torch.full((G, self.A), float(m.dirichlet_alpha), device=self.device)
+            self._alpha = torch.full((G, A), float(self.alpha), device=self.device)
             p = config.random_action_probability
-            p = np.full(self.A, 1.0 / self.A) if p is None else np.asarray(p)
+            p = np.full(A, 1.0 / A) if p is None else np.asarray(p)
             self._p_random = torch.as_tensor(p.astype(np.float32)).to(self.device)
-        self.alpha = m.dirichlet_alpha
-        dev = self.device
-        self.step_in_episode = torch.zeros(G, dtype=torch.int32, device=dev)
-        self.action = torch.zeros(G, dtype=torch.int32, device=dev)
-        self.env.reset()
 
-    def sync_running_stats(self) -> None:
-        """With track_running_stats: the advanced BatchNorm buffers of h, g and f go back into the modules."""
-        self.h.sync_running_stats()
-        if hasattr(self.nets, "sync_running_stats"):
-            self.nets.sync_running_stats()
-
-    def epsilon(self, training_steps: int) -> float:
-        c = self.cfg
-        return max(c.epsilon * (c.epsilon_decay ** training_steps), c.min_epsilon)
-
-    def move(self, training_steps: int = 0):
-        """One move of every game.  Returns device tensors (obs, policy32, value, action, reward,
-        done) for this move; games that ended (or hit max_steps_per_episode) restart."""
-        G, A, S, dev = self.G, self.A, self.mcts.S, self.device
-        obs, to_play = self.env.observe()
-        hist = self.history.push(obs, self.step_in_episode, None)  # self-play stores action id 0 with every frame
-        root_form = bool(getattr(self.nets, "has_root_form", False))
-        latent = self.h(hist, want_root_t=root_form).reshape(G, -1)
-        root_t = self.h.root_t.reshape(G, -1) if root_form and self.h.root_t is not None else None
-        if root_t is not None and not self.mcts.root_form_ok(root_t):
-            root_t = None
-        if root_t is not None:
-            seen = tuple((t._version, t.data_ptr()) for t in self._root_final.parameters())
-            if seen != getattr(self, "_root_seen", seen):
-                self.nets.refresh()  # the composed root weights hold a copy of the final convolution's
-            self._root_seen = seen
-        eps = self.epsilon(training_steps)
+    def draw(self, eps: float):
+        G, A, S, dev = self.G, self.A, self.S, self.device
         if self.device_rng:
             rand = torch.randint(0, A, (G, S + 1), device=dev, dtype=torch.int32, generator=self.gen)
             # Dirichlet(alpha) = normalised Gamma(alpha, 1) draws
@@ -216,8 +162,129 @@ class SelfPlayEngine:
             explore = torch.from_numpy((self.rng.random(G) < eps).astype(np.int8)).to(dev)
             p = self.cfg.random_action_probability
             rnd = torch.from_numpy(self.rng.choice(A, size=G, p=p).astype(np.int32)).to(dev)
+        return rand, eta, explore, rnd
+
+
+def episodes_from_records(rec, G: int):
+    """Finished episodes of `rec`, a list of per-move tuples (obs, policy32, value, action, reward, ended) over
+    G games, as lists of Chunk (states on the CPU) in the reference's Episode/Chunk format
+    (src/training_data_generator.py:20-40), game by game."""
+    from muzero_amd.training_data_generator import Chunk, Episode
+    obs, pol, val, act, rew, end = (torch.stack([r[i] for r in rec]).cpu() for i in range(6))
+    episodes = []
+    for g in range(G):
+        cur = []
+        for t in range(len(rec)):
+            cur.append(Chunk(state=obs[t, g].unsqueeze(0), policy=pol[t, g], reward=float(rew[t, g]),
+                             value=float(val[t, g]), best_action=int(act[t, g])))
+            if end[t, g]:
+                episodes.append(Episode(chunks=cur))
+                cur = []
+    return episodes
+
+
+class SelfPlayEngine:
+    def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0,
+                 device_rng: bool = False, env=None, track_running_stats: bool = False, root_form: bool = True,
+                 share: "SelfPlayEngine | None" = None):
+        """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps).
+        `env`: a batched environment (`observe`, `step`, `reset(mask)`, `num_actions`,
+        `observation_space`); default: G Connect-Four games on the GPU.  Host-side simulators go
+        through `muzero_amd.environments.host_pool.HostEnvPool`.
+
+        The search consumes no random numbers itself: the Dirichlet noise, the child draws and the
+        exploration decisions of a move are inputs.  By default they come from a numpy generator on
+        the host (reproducible against a CPU replay); `device_rng=True` draws them on the GPU with
+        torch's generator instead, which keeps the whole move on the device.
+
+        `track_running_stats`: the BatchNorm running statistics of h, g and f advance with every network
+        call as the reference's train-mode calls make them (no output depends on them);
+        `sync_running_stats()` writes them back into the three modules (`generate` does so at its end).
+
+        `root_form`: with a representation network that ends in a 1x1 convolution of a few channels, a
+        residual-tower search starts from those channels' pooled values: h's final convolution is composed
+        into the first layers of g and f, and the root expansion runs on the bf16-split merge kernel.  Its
+        network outputs agree with the reference-ordered float32 evaluation to 1e-5 of their scale, a bound
+        and not bit parity: a selection or a greedy action that two candidates tie for to that precision
+        may fall the other way.  False keeps the roots as full latents through the plain kernels.
+
+        `share`: another engine over the same three modules whose device copies of the weights (h runner,
+        packed g / f) this one uses instead of packing its own; the two must issue their device work on the
+        same stream."""
+        self.G, self.cfg = G, config
+        self.device = torch.device(device)
+        m = config.mcts
+        if m.max_iterations <= 0:
+            raise ValueError("batched self-play needs max_iterations > 0 (the time-bounded mode is single-game only)")
+        self.env = env if env is not None else BatchedConnectFour(G, device=device)
+        assert getattr(self.env, "G", G) == G, "the environment batch must hold G games"
+        self.A = self.env.num_actions
+        if share is not None:
+            self.h, self._root_final, self.nets = share.h, share._root_final, share.nets
+        else:
+            self.h = RepresentationRunner(repr_net, device=device, track_running_stats=track_running_stats)
+            self._root_final = self.h.root_final() if root_form else None
+            self.nets = make_networks(dyn_net, pred_net, device=device, track_running_stats=track_running_stats,
+                                      root_final=self._root_final)
+        self.mcts = BatchedMCTS(self.nets, G, m.max_iterations, m.model_look_ahead, m.discount_factor, m.noise_frac,
+                                device=device, keep_latents=False)  # nothing here reads the children's latents
+        self.history = DeviceHistory(G, repr_net.history_length, self.env.observation_space, device=device)
+        self.streams = MoveStreams(G, self.A, m.max_iterations, config, device, seed, device_rng)
+        self.device_rng = device_rng
+        dev = self.device
+        self.step_in_episode = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.action = torch.zeros(G, dtype=torch.int32, device=dev)
+        self.env.reset()
+
+    @property
+    def rng(self):
+        return self.streams.rng
+
+    def sync_running_stats(self) -> None:
+        """With track_running_stats: the advanced BatchNorm buffers of h, g and f go back into the modules."""
+        self.h.sync_running_stats()
+        if hasattr(self.nets, "sync_running_stats"):
+            self.nets.sync_running_stats()
+
+    def refresh(self) -> None:
+        """Re-reads the three modules' weights (call once after a weight update; `move` also notices a changed
+        representation network or final convolution by itself)."""
+        self.h.refresh()
+        self.nets.refresh()
+
+    def _root_versions(self):
+        if self._root_final is None:
+            return None
+        return tuple((t._version, t.data_ptr()) for t in self._root_final.parameters())
+
+    def epsilon(self, training_steps: int) -> float:
+        c = self.cfg
+        return max(c.epsilon * (c.epsilon_decay ** training_steps), c.min_epsilon)
+
+    def launch(self, draws):
+        """The device side of one move, up to the action pick (left in `self.action`): nothing here waits for
+        the GPU.  `draws`: this engine's games' (rand, eta, explore, rnd) of MoveStreams.draw.  Returns
+        (obs, SearchResult)."""
+        G = self.G
+        rand, eta, explore, rnd = draws
+        obs, to_play = self.env.observe()
+        hist = self.history.push(obs, self.step_in_episode, None)  # self-play stores action id 0 with every frame
+        root_form = self._root_final is not None and bool(getattr(self.nets, "has_root_form", False))
+        latent = self.h(hist, want_root_t=root_form).reshape(G, -1)
+        root_t = self.h.root_t.reshape(G, -1) if root_form and self.h.root_t is not None else None
+        if root_t is not None and not self.mcts.root_form_ok(root_t):
+            root_t = None
+        if root_t is not None:
+            if self._root_versions() != getattr(self.nets, "root_seen", None):
+                self.nets.refresh()  # the composed root weights hold a copy of the final convolution's (it records what it read)
         res = self.mcts.run(latent if root_t is None else None, to_play, eta, rand, root_t=root_t)
         pick_action(res.policy32, explore, rnd, self.action)
+        return obs, res
+
+    def move(self, training_steps: int = 0):
+        """One move of every game.  Returns device tensors (obs, policy32, value, action, reward,
+        done) for this move; games that ended (or hit max_steps_per_episode) restart."""
+        obs, res = self.launch(self.streams.draw(self.epsilon(training_steps)))
         reward, done = self.env.step(self.action)
         self.step_in_episode += 1
         ended = (done.bool() | (self.step_in_episode >= self.cfg.max_steps_per_episode)).to(torch.int8)
@@ -229,21 +296,115 @@ class SelfPlayEngine:
     def generate(self, num_moves: int, training_steps: int = 0):
         """Plays `num_moves` lock-step moves and returns the finished episodes as lists of Chunk
         (states on the CPU), in the reference's Episode/Chunk format."""
-        from muzero_amd.training_data_generator import Chunk, Episode
         rec = [self.move(training_steps) for _ in range(num_moves)]
-        obs = torch.stack([r[0] for r in rec]).cpu()
-        pol = torch.stack([r[1] for r in rec]).cpu()
-        val = torch.stack([r[2] for r in rec]).cpu()
-        act = torch.stack([r[3] for r in rec]).cpu()
-        rew = torch.stack([r[4] for r in rec]).cpu()
-        end = torch.stack([r[5] for r in rec]).cpu()
-        episodes = []
-        for g in range(self.G):
-            cur = []
-            for t in range(num_moves):
-                cur.append(Chunk(state=obs[t, g].unsqueeze(0), policy=pol[t, g], reward=float(rew[t, g]),
-                                 value=float(val[t, g]), best_action=int(act[t, g])))
-                if end[t, g]:
-                    episodes.append(Episode(chunks=cur))
-                    cur = []
-        return episodes
+        if getattr(self.h, "track_running_stats", False):
+            self.sync_running_stats()  # training advances the same buffers next (src/training.py runs the modules in train mode)
+        return episodes_from_records(rec, self.G)
+
+
+class PipelinedSelfPlay:
+    """Self-play with host-side simulators in two half-batches that alternate between the host and the
+    device: while the thread pool steps the simulators of one half (src/training_data_generator.py:131-137
+    for each of its games), the GPU runs observation upload, history, h, the search and the action pick of
+    the other half, launched beforehand on the one stream both halves use.  The host never waits for device
+    work other than the half it is about to step (one event per half), so a move costs about
+    max(host time, device time) instead of their sum.
+
+    The two halves share one device copy of the networks; each has its own tree pool, launch graph, history
+    ring and environment pool.  The random inputs of a move are drawn for all G games at once, exactly as
+    SelfPlayEngine draws them, so that with the same seed both engines play the same games wherever the
+    search's results do not depend on the batch size (they do not for the kernels used here: every tree
+    and every game's h call is computed independently of its neighbours).
+
+    `envs`: G single-game simulators with the reference's Environment methods (src/environment.py:6-94).
+    After every `move` the device is already working on the next one: one look-ahead search per half is
+    discarded when playing stops, and the exploration rate passed to `move` applies to the move launched
+    inside that call."""
+
+    def __init__(self, repr_net, dyn_net, pred_net, envs, config, device="cuda", seed: int = 0,
+                 device_rng: bool = False, workers: int = 0, track_running_stats: bool = False, root_form: bool = True):
+        from muzero_amd.environments.host_pool import HostEnvPool
+        envs = list(envs)
+        self.G, self.cfg, self.device = len(envs), config, torch.device(device)
+        assert self.G >= 2, "two half-batches need at least two games"
+        half = (self.G + 1) // 2
+        self.bounds = [(0, half), (half, self.G)]
+        lead = SelfPlayEngine(repr_net, dyn_net, pred_net, half, config, device=device, seed=seed, device_rng=device_rng,
+                              env=HostEnvPool(envs[:half], device=device, workers=workers),
+                              track_running_stats=track_running_stats, root_form=root_form)
+        rest = SelfPlayEngine(repr_net, dyn_net, pred_net, self.G - half, config, device=device, seed=seed,
+                              device_rng=device_rng, env=HostEnvPool(envs[half:], device=device, workers=workers),
+                              share=lead)
+        self.halves = [lead, rest]
+        self.A = lead.A
+        self.streams = MoveStreams(self.G, self.A, config.mcts.max_iterations, config, device, seed, device_rng)
+        pin = self.device.type == "cuda"
+        self._action_host = [torch.zeros(e.G, dtype=torch.int32, pin_memory=pin) for e in self.halves]
+        self._steps_host = [torch.zeros(e.G, dtype=torch.int32, pin_memory=pin) for e in self.halves]
+        self._event = [torch.cuda.Event() if pin else None for _ in self.halves]
+        self._pending = [None, None]
+        self._draws = None
+
+    @property
+    def nets(self):
+        return self.halves[0].nets
+
+    def epsilon(self, training_steps: int) -> float:
+        return self.halves[0].epsilon(training_steps)
+
+    def refresh(self) -> None:
+        self.halves[0].refresh()
+
+    def sync_running_stats(self) -> None:
+        self.halves[0].sync_running_stats()
+
+    def _launch(self, i: int) -> None:
+        e = self.halves[i]
+        lo, hi = self.bounds[i]
+        obs, res = e.launch(tuple(t[lo:hi] for t in self._draws))
+        self._action_host[i].copy_(e.action, non_blocking=True)
+        if self._event[i] is not None:
+            self._event[i].record()
+        self._pending[i] = (obs, res.policy32, res.value, e.action.clone())
+
+    def _complete(self, i: int):
+        """Waits for half i's device work, steps its simulators on the host, restarts finished games."""
+        e = self.halves[i]
+        if self._event[i] is not None:
+            self._event[i].synchronize()
+        obs, policy32, value, action = self._pending[i]
+        reward, done = e.env.step_host(self._action_host[i].tolist())
+        steps = self._steps_host[i]
+        steps += 1
+        ended = (done.bool() | (steps >= self.cfg.max_steps_per_episode)).to(torch.int8)
+        e.env.reset_host(torch.nonzero(ended).reshape(-1).tolist())
+        steps.masked_fill_(ended.bool(), 0)
+        e.step_in_episode.copy_(steps, non_blocking=True)  # queued behind the other half's search; read by this half's next push
+        return obs, policy32, value, action, reward, ended
+
+    def move(self, training_steps: int = 0):
+        """One move of every game: (obs, policy32, value, action) on the device, (reward, ended) on the host."""
+        eps = self.epsilon(training_steps)
+        if self._draws is None:
+            self._draws = self.streams.draw(eps)
+            for i in range(2):
+                self._launch(i)
+        outs = []
+        for i in range(2):
+            outs.append(self._complete(i))   # the other half's launched work keeps the GPU busy meanwhile
+            if i == 0:
+                self._draws = self.streams.draw(eps)
+            self._launch(i)
+        return tuple(torch.cat([o[k] for o in outs]) for k in range(6))
+
+    def generate(self, num_moves: int, training_steps: int = 0):
+        rec = [self.move(training_steps) for _ in range(num_moves)]
+        if getattr(self.halves[0].h, "track_running_stats", False):
+            self.sync_running_stats()
+        return episodes_from_records(rec, self.G)
+
+    def close(self) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        for e in self.halves:
+            e.env.close()

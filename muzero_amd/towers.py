@@ -161,6 +161,9 @@ class TowerNetworks:
             self._running, self._calls, self._mean_shift = {}, {}, {}
         self._keep = []
         self.version = getattr(self, "version", 0) + 1  # captured launch graphs hold the old buffers' addresses
+        # what this read of the final convolution saw: a caller checks it to learn whether the composed root weights are stale
+        self.root_seen = None if self.root_final is None else \
+            tuple((t._version, t.data_ptr()) for t in self.root_final.parameters())
         lib = _hip.lib()
         g, f = self.dynamics_net, self.prediction_net
         D, A = self.D, self.A

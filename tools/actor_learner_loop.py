@@ -88,7 +88,7 @@ def main():
 
     for _ in range(3):  # and of the sampler / autograd / the optimizer
         one_step()
-    eng.nets.refresh()
+    eng.refresh()
 
     t_play = t_learn = 0.0
     moves = steps = 0
@@ -106,7 +106,7 @@ def main():
         for _ in range(args.steps_per_iter):
             last = one_step()
             steps += 1
-        eng.nets.refresh()  # the actors search with the new weights from the next move on
+        eng.refresh()  # the actors search with the new weights from the next move on
         sharding.fence(dist)
         t_learn += sharding.max_over_ranks(time.perf_counter() - t0, dist, dev)
         losses.append(float(last))
