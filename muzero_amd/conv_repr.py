@@ -97,6 +97,7 @@ class _Bn:
             raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not supported")
         self.weight = self.bias = None
         self.running_mean = self.running_var = None
+        self.seen = None  # the module's running buffers as last read or written by the evaluator (the native BatchNorm call does not bump their version counters)
         self.calls = 0   # batch-size-1 calls since the running statistics were last written back
 
 
@@ -203,6 +204,7 @@ class ConvRepresentation:
             b.weight, b.bias = self._dev(ones), self._dev(zeros)
             if m.track_running_stats and m.running_mean is not None:
                 b.running_mean, b.running_var = self._dev(m.running_mean), self._dev(m.running_var)
+                b.seen = (m.running_mean.detach().clone(), m.running_var.detach().clone())  # a later change is someone else's update
             b.calls = 0
 
     def sync_running_stats(self) -> None:
@@ -213,8 +215,19 @@ class ConvRepresentation:
                 m = b.module
                 if b.calls == 0 or b.running_mean is None:
                     continue
-                m.running_mean.copy_(b.running_mean.to(m.running_mean.device))
-                m.running_var.copy_(b.running_var.to(m.running_var.device))
+                if not (torch.equal(m.running_mean, b.seen[0]) and torch.equal(m.running_var, b.seen[1])):
+                    # a training step advanced the module's buffers before these updates were handed over: writing
+                    # them back would undo that step; keep the module's values and go on from them
+                    import warnings
+                    warnings.warn("BatchNorm running statistics changed in the module since self-play read them: "
+                                  "self-play's updates are dropped (call sync_running_stats() before training)",
+                                  RuntimeWarning, stacklevel=2)
+                    b.running_mean.copy_(m.running_mean.detach().to(self.device, torch.float32))
+                    b.running_var.copy_(m.running_var.detach().to(self.device, torch.float32))
+                else:
+                    m.running_mean.copy_(b.running_mean.to(m.running_mean.device))
+                    m.running_var.copy_(b.running_var.to(m.running_var.device))
+                b.seen = (m.running_mean.detach().clone(), m.running_var.detach().clone())
                 if m.num_batches_tracked is not None:
                     m.num_batches_tracked += b.calls
                 b.calls = 0

@@ -89,6 +89,7 @@ class TowerNetworks:
         # expansion's separate kernels take 57 us there, the fused pair 43 us)
         self.fuse_min_rows = int(os.environ.get("MZ_FUSE_MIN_ROWS", "1"))
         self.track_running_stats = track_running_stats
+        self._buffers_seen: dict = {}  # id(bn module) -> its running buffers as last read or written here
         self._running: dict = {}   # id(tower struct) -> [(bn module, running_mean, running_var)] per block x 3
         self._calls: dict = {}     # id(tower struct) -> device counter of reference calls since the last sync
         self._mean_shift: dict = {}  # id(tower struct) -> {layer: constant missing from the exported batch mean}
@@ -414,12 +415,18 @@ class TowerNetworks:
                     continue
                 layers.append((bn, bn.running_mean.detach().to(self.device, torch.float32).clone(),
                                bn.running_var.detach().to(self.device, torch.float32).clone()))
+        for e in layers:
+            if e is not None:  # the buffers' state as read here: a later change of theirs is someone else's update
+                self._buffers_seen[id(e[0])] = (e[0].running_mean.detach().clone(), e[0].running_var.detach().clone())
         self._running[id(tower)] = layers
         # counted on the device, so that launches replayed from a recorded graph count as well
         self._calls[id(tower)] = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     def sync_running_stats(self) -> None:
-        """Writes the advanced running statistics and call counts back into the torch modules."""
+        """Writes the advanced running statistics and call counts back into the torch modules.  A module whose
+        buffers changed since they were read here (a training step ran the module in train mode before this
+        evaluator's updates were handed over) keeps its own values: overwriting them would undo that step's
+        update; the updates held here are dropped with a warning (only the call count is added)."""
         seen, counters = set(), {}
         for key, layers in self._running.items():
             cnt = self._calls.get(key)
@@ -431,9 +438,20 @@ class TowerNetworks:
                     continue
                 seen.add(id(e[0]))
                 bn, rm, rv = e
-                with torch.no_grad():
-                    bn.running_mean.copy_(rm.to(bn.running_mean.device))
-                    bn.running_var.copy_(rv.to(bn.running_var.device))
+                was = self._buffers_seen.get(id(bn))
+                if was is None or not (torch.equal(bn.running_mean, was[0]) and torch.equal(bn.running_var, was[1])):
+                    import warnings
+                    warnings.warn("BatchNorm running statistics changed in the module since self-play read them: "
+                                  "self-play's updates are dropped (call sync_running_stats() before training)",
+                                  RuntimeWarning, stacklevel=2)
+                    with torch.no_grad():  # continue from the module's values
+                        rm.copy_(bn.running_mean.detach().to(rm.device, torch.float32))
+                        rv.copy_(bn.running_var.detach().to(rv.device, torch.float32))
+                else:
+                    with torch.no_grad():
+                        bn.running_mean.copy_(rm.to(bn.running_mean.device))
+                        bn.running_var.copy_(rv.to(bn.running_var.device))
+                self._buffers_seen[id(bn)] = (bn.running_mean.detach().clone(), bn.running_var.detach().clone())
         for key, layers in self._running.items():
             for e in layers or ():
                 if e is not None and id(e[0]) in counters:

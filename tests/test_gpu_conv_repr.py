@@ -131,6 +131,73 @@ def test_running_statistics_follow_the_reference_calls():
     assert all(torch.equal(p, q) for p, q in zip(h.parameters(), ref.parameters()))
 
 
+def test_running_statistics_across_selfplay_training_selfplay():
+    """Self-play, a training step, self-play again, through the runner self-play uses.  In the reference's order
+    (self-play's buffers handed over before training, as SelfPlayEngine.generate does at its end) the module's buffers
+    equal those of a torch twin given the same calls in the same order.  Without the hand-over, the buffers a training
+    step left are NOT overwritten by the stale self-play copy when the runner re-reads the changed weights: the
+    training step's values stay, a warning says that self-play's updates were dropped."""
+    import warnings
+    from muzero_amd.selfplay import RepresentationRunner
+    h = _net((3, 12, 12), (16, 3, 3), 2, [_cv(64, 2, 2, 0), _rb(64), _rb(3)], [_rb(3)])
+    G, K = 5, 2
+    torch.manual_seed(6)
+    x1, x2, xb = (torch.rand(n, 3 * K + K, 12, 12) for n in (G, G, 4))
+
+    def train_step(m):  # a train-mode batch call (advances the buffers) and an in-place parameter update
+        m.train()
+        with torch.no_grad():
+            m(xb)
+            for p in m.parameters():
+                p.mul_(0.999)
+
+    def buffers_equal(a, b):
+        for (name, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+            if name.endswith("num_batches_tracked"):
+                assert int(u) == int(v), name
+            else:
+                np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=name)
+
+    # the reference's order
+    ref = copy.deepcopy(h).train()
+    run = RepresentationRunner(h, track_running_stats=True)
+    with torch.no_grad():
+        for i in range(G):
+            ref(x1[i:i + 1])
+    run(x1.cuda())
+    run.sync_running_stats()
+    train_step(h), train_step(ref)
+    with torch.no_grad():
+        for i in range(G):
+            ref(x2[i:i + 1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        run(x2.cuda())          # notices the changed parameters, re-reads weights and buffers
+        run.sync_running_stats()
+    buffers_equal(h, ref)
+    # no hand-over before training
+    h2 = _net((3, 12, 12), (16, 3, 3), 2, [_cv(64, 2, 2, 0), _rb(64), _rb(3)], [_rb(3)])
+    run2 = RepresentationRunner(h2, track_running_stats=True)
+    run2(x1.cuda())
+    train_step(h2)
+    after_training = copy.deepcopy(h2)
+    with pytest.warns(RuntimeWarning, match="dropped"):
+        run2.refresh()
+    for (name, u), (_, v) in zip(h2.named_buffers(), after_training.named_buffers()):
+        if not name.endswith("num_batches_tracked"):
+            assert torch.equal(u, v), name
+    # and self-play goes on from the training step's values
+    ref2 = copy.deepcopy(after_training).train()
+    with torch.no_grad():
+        for i in range(G):
+            ref2(x2[i:i + 1])
+    run2(x2.cuda())
+    run2.sync_running_stats()
+    for (name, u), (_, v) in zip(h2.named_buffers(), ref2.named_buffers()):
+        if not name.endswith("num_batches_tracked"):
+            np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=name)
+
+
 def _shipped_h():
     """The representation network of src/config/config_car_racing.yaml:57-131."""
     return _net((3, 96, 96), (256, 6, 6), 32,
