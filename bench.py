@@ -486,6 +486,8 @@ def main():
             r = tower_search(tg, S, dev, steps=5 if tg <= 1024 else 3, with_roofline=not args.no_roofline)
             line["towers"][str(tg)] = r
         line["towers"]["representation"] = representation_time(256, dev)
+        from tools.bench_conv_repr import flappy_time
+        line["towers"]["representation_flappy"] = flappy_time(16)  # FlappyBird's h: 3x512x288 frames, 16 games per call
         # whole self-play moves with host-side simulators (stand-ins returning random frames) and the shipped network
         # shapes: the serial engine, and two halves alternating between the host thread pool and the GPU
         from tools.bench_selfplay_towers import run as selfplay_host_envs

@@ -389,7 +389,12 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  *       (k-1)/2 on G images of H x W pixels (ResBlock.conv1 / conv2, network_builder.py:84-120): the
  *       pixels a tile's taps read are one contiguous range of the flat pixel index, staged in LDS once
  *       per channel chunk instead of once per tap; needs no index table.  Bit-identical to
- *       mz_conv3_forward; W is limited to 63 for k = 3;
+ *       mz_conv3_forward; W is limited to 63 for k = 3 (wider images, up to 144 pixels, are staged from
+ *       the float32 form only: mz_conv3_same_bn_forward);
+ *   mz_conv3_same_fits        1 when mz_conv3_same_forward (raw = 0) or mz_conv3_same_bn_forward (raw = 1;
+ *       with_bn: in_scale / in_shift given) takes the shape -- image width and the LDS the staged range and
+ *       the scale / shift rows need -- else 0; sets no error.  Callers choose between the staged kernels,
+ *       mz_conv3_forward and a separate mz_bn_apply3 with it instead of repeating the kernel's limits;
  *   mz_conv3_same_bn_forward  mz_conv3_same_forward whose input is the raw float32 output x of the previous
  *       convolution with that layer's per-game BatchNorm scale / shift f32[G][C] and activation: the operand
  *       in_activation(x * in_scale + in_shift) is formed and split while it is staged (conv2(relu(bn1(.))) of
@@ -418,6 +423,7 @@ int mz_conv3_same_bn_forward(const float *x, const float *in_scale, const float 
                              int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, const uint16_t *w3,
                              int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
                              int64_t y_plane, int32_t N, double *block_sums, void *stream);
+int mz_conv3_same_fits(int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, int32_t N, int32_t raw, int32_t with_bn);
 int mz_bn_stats_from_sums(const double *block_sums, int32_t G, int32_t P, int32_t C, const float *weight,
                           const float *bias, float eps, float *scale, float *shift, float *mean, float *var,
                           void *stream);
@@ -576,8 +582,13 @@ int mz_wide_forward(const mz_packed_layer *h_plan, const float *blob, const floa
  * instead of a caller-provided workspace; the call allocates nothing.  A call whose
  * mz_wide_workspace() exceeds that size fails with MZ_ERR_ARG.  The device the stream belongs to
  * must be the current device.  All calls on one GPU share the array: calls that overlap in time on
- * the same GPU (different streams or threads) race; calls on one stream are ordered and safe. */
+ * the same GPU (different streams or threads) race; calls on one stream are ordered and safe.
+ * The array's device address is looked up once per device, on the first call that needs it or in
+ * mz_wide_static_init() (current device; no counterpart in the reference either): that look-up is a
+ * runtime query which must not fall inside a stream capture, so a caller that captures its first use
+ * of a device calls mz_wide_static_init() on that device beforehand. */
 int64_t mz_wide_static_workspace_floats(void);
+int mz_wide_static_init(void);
 int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
                            const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream);
 

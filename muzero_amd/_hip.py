@@ -139,6 +139,7 @@ _SIGS = {
     "mz_wide_forward": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P,
                                   C.c_int64, _P]),
     "mz_wide_static_workspace_floats": (C.c_int64, []),
+    "mz_wide_static_init": (C.c_int, []),
     "mz_wide_forward_static": (C.c_int, [C.POINTER(PackedLayer), _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P]),
     "mz_nchw_to_nhwc": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mz_nhwc_to_nchw": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
@@ -163,6 +164,7 @@ _SIGS = {
     "mz_unsplit3": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
                                    C.c_int32, C.c_int32, _P, _P]),
+    "mz_conv3_same_fits": (C.c_int, [C.c_int32] * 8),
     "mz_conv3_same_bn_forward": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                            C.c_int64, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     "mz_bn_stats_from_sums": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),

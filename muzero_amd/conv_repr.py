@@ -273,10 +273,13 @@ class ConvRepresentation:
             _hip.check(_hip.lib().mz_split3(ptr(a.f), a.n, ptr(a.s), a.n, _stream()), "mz_split3")
         return a.s
 
-    def _staged(self, cv: _Conv, W: int) -> bool:
-        """Whether `cv` runs on the kernel that stages a tile's contiguous pixel range (stride-1 "same")."""
-        return (cv.fast and self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2
-                and (cv.k == 1 or W <= 63))
+    def _staged(self, cv: _Conv, G: int, H: int, W: int, raw: bool = True, with_bn: bool = False) -> bool:
+        """Whether `cv` runs on the kernel that stages a tile's contiguous pixel range (stride-1 "same") for G images
+        of H x W pixels; `raw`: from a float32 input (split while staged), `with_bn`: with the previous layer's
+        BatchNorm applied while staging.  The kernel's own limits decide (mz_conv3_same_fits)."""
+        if not (cv.fast and self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2):
+            return False
+        return bool(_hip.lib().mz_conv3_same_fits(cv.cin, G, H, W, cv.k, cv.cout, 1 if raw else 0, 1 if with_bn else 0))
 
     def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False, pre=None):
         """a: input activation [G, H, W, cin] -> (output activation, Ho, Wo).  The output is float32
@@ -293,7 +296,8 @@ class ConvRepresentation:
         n_out = rows * cv.cout
         out = self._Act(n=n_out)
         if cv.fast:
-            if pre is None and a.s is None and self._staged(cv, W):
+            if pre is None and a.f is not None and self._staged(cv, G, H, W) and \
+                    (a.s is None or not self._staged(cv, G, H, W, raw=False)):
                 pre = (None, None, 0)   # a float32 activation is split while it is staged
             x3 = self._s3(a, name + "_in") if pre is None else None
             if split_out:
@@ -307,7 +311,7 @@ class ConvRepresentation:
                                                         cv.w3.shape[1], ptr(cv.bias), cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout,
                                                         ptr(out.sums), _stream()), "mz_conv3_same_bn_forward")
                 return out, Ho, Wo
-            if self._staged(cv, W):
+            if self._staged(cv, G, H, W, raw=False):
                 # the taps of a stride-1 "same" convolution read one contiguous pixel range per tile
                 _hip.check(lib.mz_conv3_same_forward(ptr(x3), a.n, cv.cin, G, H, W, cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
                                                      cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout, ptr(out.sums), _stream()),
@@ -438,7 +442,7 @@ class ConvRepresentation:
                     raise ValueError(f"block {si} expects {c1.cin} channels, got {Cc}")
                 raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1", sums=True)
                 sc1, sh1 = self._stats(raw1, G, H1 * W1, b1, tag + "_bn1")
-                if self.fused_input_bn and self._staged(c2, W1) and 2 * c1.cout * 4 * min(G, 382 // (H1 * W1) + 2) <= 20 * 1024:
+                if self.fused_input_bn and self._staged(c2, G, H1, W1, with_bn=True):
                     # bn1 and the activation are applied while conv2 stages its input
                     raw2, H2, W2 = self._conv(raw1, G, H1, W1, c2, tag + "_c2", sums=True, pre=(sc1, sh1, act))
                 else:

@@ -246,21 +246,30 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
 // rows from global memory again: the activation traffic into the compute unit drops by ~k*k / 1.4,
 // which is what bounds k_conv3 on these layers.  Same reduction order and instruction sequence as
 // k_conv3, so the two produce identical bits.
-constexpr int kHaloSlots = 384;                       // 256 rows + 2 * 64 pixels of reach
-constexpr int kHaloPlane = (kHaloSlots + 4) * kARow;  // + the slot of zeros (index kHaloSlots)
-constexpr int kHaloBytes = 3 * kHaloPlane;
-constexpr int kHaloLds = kHaloBytes + 2 * kBStage;    // then the slot table u16[9][256]
-constexpr int kSlotBytes = 9 * kTM * 2;
+//
+// The range is staged by groups of 128 slots (one per thread quartet): NJ = 3 groups hold images up to 63
+// pixels wide; wider images (up to 144 pixels: 256 + 2 * 145 slots) take 4 or 5 groups, whose slots live in
+// registers between their fetch and the end of the chunk -- affordable only in the RAW form (two 16-byte
+// pieces per slot instead of three), which is therefore the only form offered for them.
+constexpr int kHaloSlots = 384;                       // NJ = 3: 256 rows + 2 * 64 pixels of reach
+constexpr int kSlotBytes = 9 * kTM * 2;               // the slot table u16[9][256]
+constexpr int kMaxLds = 160 * 1024;
+__host__ __device__ constexpr int halo_plane(int cap) { return (cap + 4) * kARow; }  // + the slot of zeros (index cap)
+
+// LDS of one launch: three planes of `cap` slots, two weight stages, the slot table, the scale / shift rows
+__host__ __device__ constexpr size_t same_lds(int cap, int bn_games, int C) {
+    return (size_t)3 * halo_plane(cap) + 2 * kBStage + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float);
+}
 
 //
 // RAW: the input is the float32 output xf of the previous convolution, and the operand is
 // in_act(xf * in_scale[game][c] + in_shift[game][c]) -- that layer's BatchNorm and activation --
 // formed and split while the range is staged, so the normalised activation is never written to
 // memory.  The scale / shift rows of the few games a range can touch sit in LDS behind the slot table.
-template <bool RAW>
+template <bool RAW, int NJ>
 __global__ void __launch_bounds__(kT3)
 k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const float *__restrict__ xf,
-             const float *__restrict__ in_scale, const float *__restrict__ in_shift, int in_act, int bn_games, int C, int H,
+             const float *__restrict__ in_scale, const float *__restrict__ in_shift, int in_act, int bn_games, int cap, int C, int H,
              int W, int ksize, const unsigned short *__restrict__ w3, long long w_plane, int K,
              const float *__restrict__ bias, int act, float *__restrict__ y, unsigned short *__restrict__ y3,
              long long y_plane, int rows, int N, double *__restrict__ sums) {
@@ -272,8 +281,9 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     const int m0 = blockIdx.y * kTM, n0 = blockIdx.x * kTN;
     const int taps = ksize * ksize, pad = (ksize - 1) >> 1, reach = pad * (W + 1);
     const int chunks = C / kTK, steps = taps * chunks;
-    unsigned char *s_halo = lds, *s_b = lds + kHaloBytes;
-    unsigned short *s_slot = reinterpret_cast<unsigned short *>(lds + kHaloLds);  // [tap][wm][m][t]
+    const int kHaloPlane = halo_plane(cap);
+    unsigned char *s_halo = lds, *s_b = lds + 3 * kHaloPlane;
+    unsigned short *s_slot = reinterpret_cast<unsigned short *>(s_b + 2 * kBStage);  // [tap][wm][m][t]
     if (tid < kTM) {  // one row per thread: its image coordinates once, then the taps
         const int r = tid, row = m0 + r;
         const int w = row % W, h = (row / W) % H;
@@ -282,19 +292,19 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
         for (int dy = -pad; dy <= pad; ++dy)
             for (int dx = -pad; dx <= pad; ++dx, ++tap) {
                 const bool in = row < rows && h + dy >= 0 && h + dy < H && w + dx >= 0 && w + dx < W;
-                dst[tap * (4 * 16 * 4)] = (unsigned short)(in ? r + reach + dy * W + dx : kHaloSlots);
+                dst[tap * (4 * 16 * 4)] = (unsigned short)(in ? r + reach + dy * W + dx : cap);
             }
     }
-    if (tid < 12) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + kHaloSlots * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 12) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + cap * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
 
-    // staging roles: halo slots hs, hs + 128, hs + 256 (three planes each), B column rb, piece pc
+    // staging roles: halo slots hs + 128 j, j < NJ (three planes each), B column rb, piece pc
     const int hs = tid >> 2, pc = tid & 3, rb = tid >> 2;
     const int nslots = kTM + 2 * reach;
     const int P = H * W;
     // RAW: scale rows then shift rows [bn_games][C] of the games from the one holding the first staged pixel on
-    float *s_bn = reinterpret_cast<float *>(lds + kHaloLds + kSlotBytes);
+    float *s_bn = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_slot) + kSlotBytes);
     const int g_first = max(m0 - reach, 0) / P;
-    int gl[3] = {0, 0, 0};
+    int gl[NJ] = {};
     if constexpr (RAW) {
         const int G = rows / P;
         for (int i = tid; in_scale && i < bn_games * C; i += kT3) {
@@ -303,14 +313,14 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
             s_bn[bn_games * C + i] = in_shift[(long long)g * C + c];
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) gl[j] = min(max(m0 - reach + hs + 128 * j, 0) / P - g_first, bn_games - 1);
+        for (int j = 0; j < NJ; ++j) gl[j] = min(max(m0 - reach + hs + 128 * j, 0) / P - g_first, bn_games - 1);
     }
-    constexpr int kGH = RAW ? 6 : 9;
+    constexpr int kGH = RAW ? 2 * NJ : 3 * NJ;
     u32x4 gh[kGH], gb[3];
     auto fetch_halo = [&](int chunk) {
         const int c0 = chunk * kTK + pc * 8;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int slot = hs + 128 * j;
             const long long pix = (long long)m0 - reach + slot;
             const bool ok = slot < nslots && pix >= 0 && pix < rows;
@@ -329,8 +339,9 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
         if constexpr (RAW) {
             const int c0 = chunk * kTK + pc * 8;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int slot = hs + 128 * j;
+                if (NJ > 3 && slot >= cap) continue;  // the image ends at `cap` slots (+ the slot of zeros)
                 const long long pix = (long long)m0 - reach + slot;
                 const bool ok = slot < nslots && pix >= 0 && pix < rows;
                 const float *sc = s_bn + gl[j] * C + c0, *sh = sc + bn_games * C;
@@ -359,10 +370,11 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * 3 + p];
+                    if (NJ == 3 || hs + 128 * j < cap)
+                        *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * 3 + p];
         }
     };
     auto fetch_b = [&](int s) {
@@ -630,22 +642,39 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
     return mz::check_launch("k_conv3");
 }
 
+// Shape of a staged-range launch: groups of 128 slots, slots of the LDS image, games whose scale / shift rows a
+// range can touch, LDS bytes.  Returns NULL when the kernel takes the shape, else why not.
+struct SameShape { int nj, cap, bn_games; size_t lds; };
+static const char *same_shape(int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, int32_t N, bool raw, bool with_bn,
+                              SameShape &s) {
+    if (G <= 0 || H <= 0 || W <= 0) return "non-positive size";
+    if (ksize < 1 || (ksize & 1) == 0 || ksize > 3) return "kernel size must be 1 or 3 (others use mz_conv3_forward)";
+    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
+        return "input channels must be a multiple of 64 and output channels a multiple of 128";
+    const int reach = ((ksize - 1) / 2) * (W + 1), nslots = kTM + 2 * reach;
+    s.nj = std::max(3, (nslots + 127) / 128);
+    if (s.nj > 5) return "the image width exceeds the staged range (256 + 2 * (W + 1) slots, at most 640)";
+    if (s.nj > 3 && !raw) return "an image width above 63 is staged from the float32 form only (mz_conv3_same_bn_forward)";
+    s.cap = s.nj == 3 ? kHaloSlots : (nslots + 3) & ~3;
+    // games a staged range can touch: it holds 256 + 2 * reach consecutive pixels
+    s.bn_games = with_bn ? (int)std::min<long long>(G, (nslots - 2) / ((long long)H * W) + 2) : 0;
+    const size_t need = same_lds(s.cap, s.bn_games, C);
+    s.lds = std::max<size_t>(need, kOutLds);
+    if (need > (size_t)kMaxLds) return "the staged range and the scale / shift rows do not fit in LDS (apply the BatchNorm with mz_bn_apply3 first)";
+    return nullptr;
+}
+
 static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plane, const float *xf, const float *in_scale,
                              const float *in_shift, int32_t in_act, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,
                              const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
                              int64_t y_plane, int32_t N, double *block_sums, void *stream) {
     const bool raw = xf != nullptr;
-    if ((!x3 && !xf) || !w3 || (!y && !y3) || G <= 0 || H <= 0 || W <= 0)
-        return mz::fail(MZ_ERR_ARG, "%s: NULL argument or non-positive size", who);
-    if (ksize < 1 || (ksize & 1) == 0 || ksize > 3)
-        return mz::fail(MZ_ERR_ARG, "%s: kernel size %d (1 or 3; others use mz_conv3_forward)", who, ksize);
-    const int reach = ((ksize - 1) / 2) * (W + 1);
-    if (kTM + 2 * reach > kHaloSlots)
-        return mz::fail(MZ_ERR_ARG, "%s: image width %d reaches %d pixels, the staged range holds %d "
-                        "(wider images use mz_conv3_forward)", who, W, reach, (kHaloSlots - kTM) / 2);
-    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
-        return mz::fail(MZ_ERR_ARG, "%s: input channels (%d) must be a multiple of 64 and output channels (%d) "
-                        "a multiple of %d", who, C, N, kTN);
+    if ((!x3 && !xf) || !w3 || (!y && !y3))
+        return mz::fail(MZ_ERR_ARG, "%s: NULL argument", who);
+    if (raw && in_scale && !in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input shift is NULL", who);
+    SameShape shp{};
+    if (const char *why = same_shape(C, G, H, W, ksize, N, raw, raw && in_scale, shp))
+        return mz::fail(MZ_ERR_ARG, "%s: %s (C %d, N %d, G %d, H %d, W %d, kernel %d)", who, why, C, N, G, H, W, ksize);
     if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID || (raw && (in_act < MZ_ACT_NONE || in_act > MZ_ACT_SIGMOID)))
         return mz::fail(MZ_ERR_ARG, "%s: activation is not element-wise", who);
     const long long rows = (long long)G * H * W, K = (long long)ksize * ksize * C;
@@ -656,26 +685,26 @@ static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plan
     if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(w3) |
          reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y3)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
         return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
-    // games a staged range can touch: it holds 256 + 2 * reach consecutive pixels
-    int bn_games = 0;
-    if (raw && in_scale) {
-        if (!in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input shift is NULL", who);
-        bn_games = std::min<long long>(G, (kTM + 2 * reach - 2) / ((long long)H * W) + 2);
-    }
-    const size_t lds = std::max<size_t>((size_t)kHaloLds + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float), kOutLds);
-    if (lds > 160 * 1024)
-        return mz::fail(MZ_ERR_ARG, "%s: the scale / shift rows of %d games x %d channels do not fit beside the staged range "
-                        "(apply the BatchNorm with mz_bn_apply3 first)", who, bn_games, C);
     auto launch = [&](auto kernel) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "%s: cannot enable %zu bytes of LDS: %s", who, lds, hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "%s: cannot enable %zu bytes of LDS: %s", who, shp.lds, hipGetErrorString(e));
         const dim3 grid(N / kTN, (unsigned)((rows + kTM - 1) / kTM));
-        hipLaunchKernelGGL(kernel, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, xf, in_scale, in_shift, in_act,
-                           bn_games, C, H, W, ksize, w3, (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane,
-                           (int)rows, N, block_sums);
+        hipLaunchKernelGGL(kernel, grid, dim3(kT3), shp.lds, (hipStream_t)stream, x3, (long long)x_plane, xf, in_scale, in_shift, in_act,
+                           shp.bn_games, shp.cap, C, H, W, ksize, w3, (long long)w_plane, (int)K, bias, activation, y, y3,
+                           (long long)y_plane, (int)rows, N, block_sums);
         return mz::check_launch("k_conv3_same");
     };
-    return raw ? launch(k_conv3_same<true>) : launch(k_conv3_same<false>);
+    if (!raw) return launch(k_conv3_same<false, 3>);
+    switch (shp.nj) {
+        case 3: return launch(k_conv3_same<true, 3>);
+        case 4: return launch(k_conv3_same<true, 4>);
+        default: return launch(k_conv3_same<true, 5>);
+    }
+}
+
+int mz_conv3_same_fits(int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, int32_t N, int32_t raw, int32_t with_bn) {
+    SameShape shp{};
+    return same_shape(C, G, H, W, ksize, N, raw != 0, raw != 0 && with_bn != 0, shp) == nullptr ? 1 : 0;
 }
 
 int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,

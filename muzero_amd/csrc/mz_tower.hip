@@ -2047,6 +2047,32 @@ int mz_wide_forward_gather(const mz_packed_layer *h_plan, const float *blob, con
 
 int64_t mz_wide_static_workspace_floats(void) { return kWideScratchFloats; }
 
+// The built-in array's address on the current device, looked up once per device (each GPU holds its own copy).
+static int wide_static_scratch(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "mz_wide_static: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices)
+        return mz::fail(MZ_ERR_ARG, "mz_wide_static: device index %d is outside the %d devices the built-in scratch is tracked for",
+                        dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_wide_scratch));
+        if (e != hipSuccess || !ptr)
+            return mz::fail(MZ_ERR_HIP, "mz_wide_static: hipGetSymbolAddress: %s (the first call on a device must not be made "
+                            "while a stream of it is being captured: call mz_wide_static_init() beforehand)", hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<float *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return MZ_OK;
+}
+
+int mz_wide_static_init(void) {
+    float *p = nullptr;
+    return wide_static_scratch(&p);
+}
+
 int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, const float *x, int64_t ldx,
                            const int32_t *x_rows, float *y, int64_t ldy, int32_t B, void *stream) {
     if (!h_plan || B < 0 || h_plan->Kp <= 0 || h_plan->Np <= 0)
@@ -2062,20 +2088,8 @@ int mz_wide_forward_static(const mz_packed_layer *h_plan, const float *blob, con
                         (long long)kWideScratchFloats);
     float *scratch = nullptr;
     if (need > 0) {
-        // the array's device address, looked up once per device (each GPU holds its own copy)
-        int dev = -1;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
-            return mz::fail(MZ_ERR_HIP, "mz_wide_forward_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        if (!g_scratch_ptr[dev]) {
-            void *ptr = nullptr;
-            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_wide_scratch));
-            if (e != hipSuccess || !ptr)
-                return mz::fail(MZ_ERR_HIP, "mz_wide_forward_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
-            g_scratch_ptr[dev] = static_cast<float *>(ptr);
-        }
-        scratch = g_scratch_ptr[dev];
+        const int rc = wide_static_scratch(&scratch);
+        if (rc != MZ_OK) return rc;
     }
     return wide_forward_impl(h_plan, blob, x, ldx, x_rows, y, ldy, B, scratch, need, stream);
 }

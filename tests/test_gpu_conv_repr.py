@@ -278,6 +278,87 @@ def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
     assert b"width" in lib.mz_last_error()
 
 
+def test_staged_range_on_wide_images_equals_the_gathering_kernel_bit_for_bit():
+    """Images wider than 63 pixels (FlappyBird's layers are 144 and 72 wide, src/config/config_flappy_bird.yaml:60-99)
+    are staged from the float32 form in 4 or 5 groups of slots: plain (the operand split while staged) against
+    mz_split3 + mz_conv3_forward, and with the previous layer's per-game BatchNorm + activation applied while staging
+    against mz_bn_apply3 + mz_conv3_forward -- identical bits, across image edges, games and a ragged last tile."""
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    for (G, H, W, Cin, N) in [(2, 5, 144, 128, 128), (1, 9, 72, 256, 256), (3, 4, 100, 64, 128), (2, 3, 64, 64, 128), (5, 2, 130, 64, 128)]:
+        k, rows, taps, P = 3, G * H * W, 9, H * W
+        assert lib.mz_conv3_same_fits(Cin, G, H, W, k, N, 1, 1) == 1 and lib.mz_conv3_same_fits(Cin, G, H, W, k, N, 0, 0) == 0
+        x = torch.randn(rows * Cin, device="cuda", generator=gen)
+        w = torch.randn(N * taps * Cin, device="cuda", generator=gen) * 0.05
+        bias = torch.randn(N, device="cuda", generator=gen)
+        scale = torch.rand(G, Cin, device="cuda", generator=gen) + 0.5
+        shift = torch.randn(G, Cin, device="cuda", generator=gen)
+        w3 = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
+        idx = torch.empty((taps, rows), dtype=torch.int32, device="cuda")
+        _hip.check(lib.mz_conv_index(ptr(idx), G, H, W, k, 1, 1, H, W, None), "mz_conv_index")
+        for with_bn in (False, True):
+            a3 = torch.empty((3, x.numel()), dtype=torch.int16, device="cuda")
+            if with_bn:
+                _hip.check(lib.mz_bn_apply3(ptr(x), ptr(scale), ptr(shift), None, None, None, None, 0, 1, None, ptr(a3), a3.shape[1],
+                                            G, P, Cin, None), "mz_bn_apply3")
+            else:
+                _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(a3), a3.shape[1], None), "mz_split3")
+            want = torch.full((rows * N,), float("nan"), device="cuda")
+            want3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
+            _hip.check(lib.mz_conv3_forward(ptr(a3), a3.shape[1], Cin, ptr(idx), taps, ptr(w3), w3.shape[1], ptr(bias), 1,
+                                            ptr(want), ptr(want3), want3.shape[1], rows, N, None, None), "mz_conv3_forward")
+            got = torch.full((rows * N,), float("nan"), device="cuda")
+            got3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
+            _hip.check(lib.mz_conv3_same_bn_forward(ptr(x), ptr(scale) if with_bn else None, ptr(shift) if with_bn else None, 1,
+                                                    Cin, G, H, W, k, ptr(w3), w3.shape[1], ptr(bias), 1, ptr(got), ptr(got3),
+                                                    got3.shape[1], N, None, None), "mz_conv3_same_bn_forward")
+            torch.cuda.synchronize()
+            assert torch.equal(got, want) and torch.equal(got3, want3), (G, H, W, Cin, N, with_bn)
+    # beyond 144 pixels the range no longer fits: refused by the query and by the entry point
+    assert lib.mz_conv3_same_fits(64, 1, 4, 200, 3, 128, 1, 0) == 0
+    assert lib.mz_conv3_same_bn_forward(ptr(x), None, None, 0, 64, 1, 4, 200, 3, ptr(w3), w3.shape[1], None, 0, ptr(got), None, 0,
+                                        128, None, None) != 0
+    assert b"width" in lib.mz_last_error()
+
+
+def _flappy_h():
+    """The representation network of src/config/config_flappy_bird.yaml:58-165."""
+    return _net((3, 512, 288), (256, 6, 6), 32,
+                [_cv(128, 2, 2, 0), _rb(128), _rb(128), _cv(256, 2, 2, 0), _rb(256), _rb(256), _rb(256), _pool(2, 2, "avg"),
+                 _rb(256), _rb(256), _rb(256), _pool(2, 2, "avg")], [_rb(3)], seed=4)
+
+
+def test_shipped_flappy_representation_network():
+    """FlappyBird's shipped h (32-frame history of 3x512x288 -> latent [256, 6, 6]) for 4 games in one call against
+    the torch module called once per game on the GPU (float32, MIOpen); every ResBlock convolution of its 144-, 72-
+    and 36-pixel-wide layers runs on the staged-range kernel."""
+    from muzero_amd.conv_repr import ConvRepresentation
+    h = _flappy_h()
+    G = 4
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.rand(G, 128, 512, 288, device="cuda", generator=gen) * 255.0
+    x[:, 96:] = torch.randint(0, 2, (G, 32, 1, 1), device="cuda", generator=gen).float()  # action planes
+    run = ConvRepresentation(h)
+    for (Gq, Hq, Wq, Cq) in [(G, 256, 144, 128), (G, 128, 72, 256), (G, 64, 36, 256)]:
+        c = next(cv for cv in run.convs if cv.k == 3 and cv.cin == Cq)
+        assert run._staged(c, Gq, Hq, Wq) and run._staged(c, Gq, Hq, Wq, with_bn=True)
+    got = run(x)
+    torch.cuda.synchronize()
+    want, _ = _per_game(h, x, torch.float32, device="cuda")
+    assert got.shape == (G, 256, 6, 6)
+    scale = float(want.abs().max())
+    err = (got - want).abs().amax(dim=(1, 2, 3)) / scale
+    want64, _ = _per_game(h, x[:1].cpu(), torch.float64)
+    ours = float((got[:1].double().cpu() - want64).abs().max()) / scale
+    theirs = float((want[:1].double().cpu() - want64).abs().max()) / scale
+    print(f"flappy h, {G} games: max |HIP - torch| / scale = {float(err.max()):.2e}; against float64: ours {ours:.2e}, float32 torch {theirs:.2e}")
+    assert ours <= 1e-5 or ours <= 2 * theirs, (ours, theirs)
+    assert float(err.max()) <= 1e-5 + 2 * (ours + theirs)
+
+
 def test_block_sums_give_the_statistics_of_the_separate_pass():
     """The column sums a convolution's epilogue leaves per 64-row block, turned into per-game BatchNorm
     scale / shift / mean / variance by mz_bn_stats_from_sums, against mz_bn_stats on the same output

@@ -99,3 +99,33 @@ def test_static_scratch_entry_point_refuses_what_does_not_fit():
     assert rc < 0 and b"scratch holds" in lib.mz_last_error()
     torch.cuda.synchronize()
     assert (y == 0).all()
+
+
+def test_static_scratch_entry_point_under_graph_capture():
+    """The callers the entry point is for: after mz_wide_static_init() on the device, a call captured into a graph
+    (no allocation, no runtime query inside the capture) replays to the bits of the workspace entry point, also
+    after the input buffer's contents change."""
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    _hip.check(lib.mz_wide_static_init(), "mz_wide_static_init")
+    pl, blob, _ = _layer(2048, 256, seed=5)
+    B, N = 96, pl.N
+    x = torch.randn(B, 2048, device="cuda")
+    y = torch.zeros(B, N, device="cuda")
+    need = lib.mz_wide_workspace(C.byref(pl), B)
+    assert 0 < need <= lib.mz_wide_static_workspace_floats()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _hip.check(lib.mz_wide_forward_static(C.byref(pl), ptr(blob), ptr(x), x.shape[1], None, ptr(y), N, B,
+                                              torch.cuda.current_stream().cuda_stream), "mz_wide_forward_static (captured)")
+    ws = torch.empty(need, device="cuda")
+    for seed in (1, 2):
+        x.copy_(torch.randn(B, 2048, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed)))
+        graph.replay()
+        want = torch.empty(B, N, device="cuda")
+        _hip.check(lib.mz_wide_forward(C.byref(pl), ptr(blob), ptr(x), x.shape[1], None, ptr(want), N, B, ptr(ws), need,
+                                       torch.cuda.current_stream().cuda_stream), "mz_wide_forward")
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)

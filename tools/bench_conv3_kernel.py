@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=256)
     ap.add_argument("--hw", type=int, default=48)
+    ap.add_argument("--width", type=int, default=0, help="image width when it differs from the height (--hw)")
     ap.add_argument("--cin", type=int, default=128)
     ap.add_argument("--cout", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
@@ -32,7 +33,7 @@ def main():
     ap.add_argument("--raw", action="store_true", help="float32 input with BatchNorm scale / shift applied while staging")
     a = ap.parse_args()
     lib = _hip.lib()
-    G, H, W, C, N, k = a.games, a.hw, a.hw, a.cin, a.cout, 3
+    G, H, W, C, N, k = a.games, a.hw, a.width or a.hw, a.cin, a.cout, 3
     rows, taps = G * H * W, k * k
     gen = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(rows * C, device="cuda", generator=gen)
@@ -74,7 +75,7 @@ def main():
         st = y.view(rows, N)[::256, :32].reshape(-1, 8, 4)
         print("stamps (prologue, loop, epilogue cycles): ", st[..., :3].mean(dim=(0, 1)).tolist(), file=sys.stderr)
     flop = 2.0 * rows * N * taps * C
-    print(json.dumps({"kernel": "gather" if a.gather else ("same+bn" if a.raw else "same"), "games": G, "hw": H, "cin": C, "cout": N,
+    print(json.dumps({"kernel": "gather" if a.gather else ("same+bn" if a.raw else "same"), "games": G, "hw": H, "width": W, "cin": C, "cout": N,
                       "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6, "bf16_executed_tflops": 6 * flop / us / 1e6,
                       "bf16_frac_of_peak": 6 * flop / us / 1e6 / BF16_PEAK_TFLOPS, "lib": os.environ.get("MUZERO_HIP_LIB", "default")}))
 
