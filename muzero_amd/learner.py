@@ -67,15 +67,22 @@ def windows_to_batch(windows, z_targets: np.ndarray, rewards: np.ndarray, is_wei
                        torch.as_tensor(np.asarray(is_weights, dtype=np.float64), dtype=torch.float32))
 
 
-def batched_unroll_loss(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, coeff=(1.0, 1.0, 1.0)):
+def batched_unroll_loss(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, coeff=(1.0, 1.0, 1.0), latent=None):
     """Returns (weighted_sum, per_window_loss[B], (policy_sum, value_sum, reward_sum)).
 
     weighted_sum = sum_b is_weights[b] * loss_b, NOT yet divided by sum(is_weights): the caller
     normalises (a data-parallel caller after summing over ranks).  Networks with BatchNorm layers
-    are evaluated with per-window statistics: the reference unrolls one window per call."""
+    are evaluated with per-window statistics: the reference unrolls one window per call.
+    `latent`: the root latents when the caller has evaluated repr_net itself (it is not called then)."""
     cp, cv, cr = coeff
     with per_call_statistics(repr_net), per_call_statistics(dyn_net), per_call_statistics(pred_net):
-        return _unroll(repr_net, dyn_net, pred_net, batch, roll_ahead, cp, cv, cr)
+        return _unroll(repr_net, dyn_net, pred_net, batch, roll_ahead, cp, cv, cr, latent)
+
+
+def representation_latents(repr_net, batch: WindowBatch):
+    """h on the windows' first histories, one window per call's statistics (src/training.py:252-256)."""
+    with per_call_statistics(repr_net):
+        return repr_net(batch.history)
 
 
 class _FusedUnrollLoss(torch.autograd.Function):
@@ -110,8 +117,9 @@ class _FusedUnrollLoss(torch.autograd.Function):
         return g_p * g_weighted, g_v * g_weighted, g_r * g_weighted, None, None, None, None, None, None, None
 
 
-def _unroll(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, cp: float, cv: float, cr: float):
-    latent = repr_net(batch.history)
+def _unroll(repr_net, dyn_net, pred_net, batch: WindowBatch, roll_ahead: int, cp: float, cv: float, cr: float, latent=None):
+    if latent is None:
+        latent = repr_net(batch.history)
     B = len(batch)
     if latent.is_cuda:
         # the networks step by step (torch / rocBLAS, autograd), the losses of all steps in one kernel
@@ -270,18 +278,22 @@ class DataParallelLearner:
 
     # ------------------------------------------------------------------ recorded step
     def step_local_recorded(self, local: WindowBatch):
-        """step_local replayed from HIP graphs: the unroll, its backward pass and the flattening
-        of the gradient are one recorded graph, the division by the weight total and the
-        optimizer step a second one, the all-reduce (world > 1) runs between the two.  On the
-        small networks a step is a few hundred launches of microsecond kernels, so replaying it
-        costs a fraction of issuing it.
+        """step_local replayed from HIP graphs, in three segments: (1) h, the unroll and the backward pass
+        through the unroll -- the gradients of f and g are complete there; (2) the backward pass through h;
+        (3) the division by the weight total and the optimizer step.  With several ranks the all-reduce of
+        the f / g gradients (with the weight total and the loss sum) is issued between (1) and (2) without
+        waiting for it, so it runs beside h's backward pass -- the bulk of the step for a convolutional h --
+        as the bucket hooks of step_local arrange it in the eager path (src/training.py:174-191 does backward
+        and step on one device); the all-reduce of h's gradients follows (2), and (3) waits for both on the
+        stream only.  On the small networks a step is a few hundred launches of microsecond kernels, so
+        replaying it costs a fraction of issuing it.
 
         Needs a fixed batch shape (DeviceEpisodeStore's samplers give one) and an optimizer whose
         step can be recorded (torch.optim.Adam/AdamW(..., capturable=True), plain SGD; a learning
         rate that changes must be a tensor).  The first call records (after one trial step whose
         effect on the weights and the optimizer state is undone).  Returns DEVICE tensors
         (normalised loss over all ranks, per-window |loss| of the local windows): nothing here
-        waits for the GPU.
+        waits for the GPU (with the RCCL backend; gloo's collectives wait on the host).
 
         A batch whose weight total is zero on every rank (only zero-weight windows) cannot skip the
         recorded optimizer step; its gradient is forced to exactly zero instead of 0/0, and the
@@ -297,31 +309,79 @@ class DataParallelLearner:
         for f in fields:
             getattr(self._rec_batch, f).copy_(getattr(local, f), non_blocking=True)
         self._rec_backward.replay()
+        waits = []
+        if self.world > 1:  # f / g gradients + [weight total, loss sum]: on its way while h's backward pass runs
+            waits.append(self._all_reduce_async(0, self._rec_split))
+        self._rec_backward_h.replay()
         if self.world > 1:
-            self.dist.all_reduce(self._rec_flat, op=self.dist.ReduceOp.SUM)
+            if self._rec_split < self._rec_flat.numel():
+                waits.append(self._all_reduce_async(self._rec_split, self._rec_flat.numel()))
+            for wait in waits:
+                wait()
         self._rec_update.replay()
         return self._rec_loss, self._rec_per_window
 
-    def _backward_into_flat(self):
-        self.optimizer.zero_grad(set_to_none=False)
-        wsum, per_window, _ = batched_unroll_loss(*self.nets, self._rec_batch, self.roll_ahead, self.coeff)
+    def _all_reduce_async(self, lo: int, hi: int):
+        """Starts the sum over ranks of _rec_flat[lo:hi]; returns the call that makes the current stream wait for it.
+        RCCL reduces the device buffer in place on its own stream.  gloo (several ranks rehearsing on one card; its
+        device-tensor collectives do not complete on this platform) gets a pinned host copy: the host waits for the
+        segment that produced the slice, the reduction then runs on gloo's thread beside the next segment."""
+        part = self._rec_flat[lo:hi]
+        if self.dist.get_backend() != "gloo":
+            return self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM, async_op=True).wait
+        if getattr(self, "_rec_host", None) is None or self._rec_host.numel() != self._rec_flat.numel():
+            self._rec_host = torch.empty(self._rec_flat.numel(), dtype=self._rec_flat.dtype, pin_memory=True)
+        host = self._rec_host[lo:hi]
+        host.copy_(part, non_blocking=True)
+        torch.cuda.current_stream(part.device).synchronize()
+        work = self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, async_op=True)
+
+        def wait():
+            work.wait()
+            part.copy_(host, non_blocking=True)
+        return wait
+
+    def _point_grads_at_flat(self):
+        """Every parameter's .grad is a view into the flat buffer: [f, g parameters | weight total, loss sum | h
+        parameters] -- no copy into a flat buffer before a collective, none back after it."""
+        off = 0
+        for group in (self._rec_fg, None, self._rec_h):
+            if group is None:
+                off += 2
+                continue
+            for p in group:
+                n = p.numel()
+                if p.grad is None or p.grad.data_ptr() != self._rec_flat[off:off + 1].data_ptr():
+                    p.grad = self._rec_flat[off:off + n].view_as(p)
+                off += n
+
+    def _backward_unroll(self):
+        self._rec_flat.zero_()
+        lat0 = representation_latents(self.nets[0], self._rec_batch)
+        self._rec_lat0 = lat0
+        lat = lat0.detach().requires_grad_(lat0.requires_grad)
+        wsum, per_window, _ = batched_unroll_loss(*self.nets, self._rec_batch, self.roll_ahead, self.coeff, latent=lat)
         wsum.backward()
-        n = self._rec_flat.numel() - 2
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self._rec_flat[:n])
+        self._rec_lat_grad = lat.grad
+        n = self._rec_split - 2
         self._rec_flat[n] = self._rec_batch.is_weights.sum()
         self._rec_flat[n + 1] = wsum.detach()
         self._rec_per_window.copy_(per_window.detach().abs())
 
+    def _backward_h(self):
+        if self._rec_lat_grad is not None:
+            self._rec_lat0.backward(self._rec_lat_grad)
+        self._rec_lat0 = self._rec_lat_grad = None
+
     def _update_from_flat(self):
         flat = self._rec_flat
-        norm = flat[-2]
+        n = self._rec_split - 2
+        norm = flat[n]
         ok = norm > 0
         safe, live = torch.where(ok, norm, torch.ones_like(norm)), ok.to(flat.dtype)  # x / safe * live: exact when ok
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad.copy_((flat[off:off + n] / safe * live).view_as(p))
-            off += n
+        self._rec_loss.copy_(flat[n + 1] / safe * live)
+        flat[:n].copy_(flat[:n] / safe * live)
+        flat[n + 2:].copy_(flat[n + 2:] / safe * live)
         torch._foreach_copy_(self._rec_before, [p.data for p in self.params])
         self.optimizer.step()
         # weight total zero: the step above ran on a zero gradient; undo whatever it still moved
@@ -329,21 +389,24 @@ class DataParallelLearner:
         with torch.no_grad():
             for p, b in zip(self.params, self._rec_before):
                 p.copy_(torch.where(ok, p, b))
-        self._rec_loss.copy_(flat[-1] / safe * live)
 
     def _record(self, local: WindowBatch, shapes):
         import copy
         dev = self.params[0].device
         self._rec_batch = WindowBatch(*(t.clone() for t in (local.history, local.actions, local.policies, local.z,
                                                             local.rewards, local.is_weights)))
+        self._rec_fg = [p for net in (self.nets[2], self.nets[1]) for p in net.parameters()]
+        self._rec_h = list(self.nets[0].parameters())
         n = sum(p.numel() for p in self.params)
+        self._rec_split = sum(p.numel() for p in self._rec_fg) + 2
         self._rec_flat = torch.zeros(n + 2, dtype=torch.float32, device=dev)
         self._rec_per_window = torch.zeros(len(local), dtype=torch.float32, device=dev)
         self._rec_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._rec_before = [torch.empty_like(p.data) for p in self.params]
+        self._bucket_list = None  # the eager path's buckets no longer own the .grad views
         for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
+            p.grad = None
+        self._point_grads_at_flat()
         # one trial step on a side stream (creates the optimizer state and every workspace), then
         # the weights and the optimizer state go back to what they were
         weights = [p.detach().clone() for p in self.params]
@@ -352,7 +415,8 @@ class DataParallelLearner:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            self._backward_into_flat()
+            self._backward_unroll()
+            self._backward_h()
             self._update_from_flat()
         torch.cuda.current_stream(dev).wait_stream(side)
         with torch.no_grad():
@@ -369,10 +433,15 @@ class DataParallelLearner:
                     for v in st.values():
                         if torch.is_tensor(v):
                             v.zero_()
+        self._point_grads_at_flat()
         torch.cuda.synchronize(dev)
-        self._rec_backward, self._rec_update = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._rec_backward, self._rec_backward_h, self._rec_update = (torch.cuda.CUDAGraph() for _ in range(3))
         with torch.cuda.graph(self._rec_backward):
-            self._backward_into_flat()
+            self._backward_unroll()
+        # the second segment runs backward through what the first one's forward pass saved: same memory pool,
+        # replayed in the order recorded
+        with torch.cuda.graph(self._rec_backward_h, pool=self._rec_backward.pool()):
+            self._backward_h()
         with torch.cuda.graph(self._rec_update, pool=self._rec_backward.pool()):
             self._update_from_flat()
         self._rec_shapes = shapes

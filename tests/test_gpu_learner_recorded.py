@@ -160,3 +160,57 @@ def test_fused_loss_kernel_matches_torch_losses_and_gradients():
     torch.testing.assert_close(sums[1:].detach(), torch.stack([lp.sum(), lv.sum(), lr.sum()]).detach(), rtol=1e-5, atol=1e-4)
     for a, b in zip(got_grads, want_grads):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def _recorded_dp_worker(rank, world, port, tmp):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # two ranks on the one card: gloo moves device tensors
+    try:
+        from muzero_amd.learner import DataParallelLearner
+        from tests.test_gpu_nets import _c4_nets
+        torch.cuda.set_device(0)
+        nets = [n.cuda() for n in _c4_nets(0)]
+        params = [p for n in nets for p in n.parameters()]
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+        dp = DataParallelLearner(*nets, opt, 5, (1.0, 0.5, 2.0), dist=dist)
+        losses = []
+        for b in _batches(3, 24, seed=21):
+            mine = torch.arange(rank, len(b), world, device="cuda")
+            loss, per_window = dp.step_local_recorded(b.rows(mine))
+            torch.cuda.synchronize()
+            assert per_window.shape == (len(mine),)
+            losses.append(float(loss))
+        torch.save({"losses": losses, "params": [p.detach().cpu().clone() for p in params]}, os.path.join(tmp, f"rec{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_recorded_step_equals_single_rank_eager_step(tmp_path):
+    """Two ranks, each replaying its three graph segments on its share of the windows with the two gradient
+    all-reduces issued between them (the f / g bucket while h's backward pass runs), take the steps one rank takes
+    eagerly on all the windows: same losses, same weights on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    from muzero_amd.learner import DataParallelLearner
+    from tests.test_gpu_nets import _c4_nets
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_recorded_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    nets = [n.cuda() for n in _c4_nets(0)]
+    params = [p for n in nets for p in n.parameters()]
+    single = DataParallelLearner(*nets, torch.optim.Adam(params, lr=1e-3, capturable=True), 5, (1.0, 0.5, 2.0))
+    losses = [single.step_local(b)[0] for b in _batches(3, 24, seed=21)]
+    r0 = torch.load(tmp_path / "rec0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rec1.pt", weights_only=True)
+    np.testing.assert_allclose(r0["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(r1["losses"], losses, rtol=1e-5)
+    for a, b, c in zip(r0["params"], r1["params"], params):
+        assert torch.equal(a, b)
+        # Adam divides by sqrt(v): where a gradient element is small beside its summands, the summation order of the
+        # two half-batches shows at the scale of a step (lr = 1e-3); the bound is 1e-2 of one step
+        torch.testing.assert_close(a, c.detach().cpu(), rtol=1e-5, atol=1e-5)
