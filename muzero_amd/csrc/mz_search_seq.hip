@@ -14,9 +14,13 @@
 //   policy 2 for leaf AND child as one 32-row pass      (its weights are read once, not twice)
 //   policy 3 for the 32 rows (one column tile: one wave), softmax; priors of the leaf, greedy action of the child
 //   value 1 (rollout latent)
-//   value 2 | reward 1 over the A children AND the rollout latent, in passes of four row tiles with
-//   the wave's reward-1 weights held in registers across the passes           (read once per round)
+//   value 2 | reward 1 of the rollout latent
 //   child records, backup
+//
+// The rewards of the A children of every expansion (src/search/expansion.py:29-33) are outputs only --
+// no selection, rollout or backup reads a node's reward -- so they are not computed inside the rounds:
+// after the last round the expansions' merge rows are read back from z_pool and reward 1 runs over all
+// (S + 1) * A * 16 child rows in one dense, barrier-free phase (the rounds' serial chain is 20 % shorter for it).
 //
 // Weights flow through a ring of two register slots per wave, a whole column tile (all its
 // k-chunks, 12-16 KiB per wave) per slot: while one tile is multiplied the next is in flight, and
@@ -50,7 +54,6 @@ using namespace mzs;
 
 namespace {
 
-constexpr int kPassTiles = 4;  // row tiles per pass of reward 1 over {children, rollout latent}
 
 struct SeqLds {
     int ld_d, ld_p, ld_q, ld_v, ld_l, tab_rows;
@@ -59,7 +62,9 @@ struct SeqLds {
     // (tile 0) and child (tile 1), split image; h2: policy layer 2 of leaf and child, likewise; r: split images
     // of a pass's row tiles, over h1 | h2 (dead by then); hv: value layer 1 (split image); lg: logits / policies
     // of the 32 rows; dote / dotv: partial sums of the folded layers; bias*: padded biases; dw*: the folded
-    // one-output layers' weights by k
+    // one-output layers' weights by k.  After the last round everything from `xi` up to `b_p0` is one arena for the
+    // children's rewards: ew holds every column tile of reward 1 (as packed: two fp16 planes per k-chunk)
+    size_t ew;
     size_t xi, z, zs, tab, h1, h2, r, hv, lg, dote, dotv, b_p0, b_m, b_p1, b_v0, b_v1, b_r0, dw_v, dw_r, b_p2, prior, rew, roll, ints, path,
         tabs, total;
 };
@@ -76,18 +81,24 @@ __host__ __device__ inline SeqLds seq_layout(const mz_packed_nets &P, int tab_le
     size_t off = sizeof(float) * kLdsReserve;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
     const size_t tile_d = sizeof(float) * kTrees * L.ld_d;
+    L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
+    const size_t arena = off;
     L.xi = take(tile_d);
     L.z = take(tile_d);
     L.zs = take(tile_d);
-    L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
     L.h1 = take(sizeof(float) * 2 * kTrees * L.ld_p);
     L.h2 = take(sizeof(float) * 2 * kTrees * L.ld_q);
     L.r = L.h1;
-    if (off < L.r + tile_d * kPassTiles) off = align16(L.r + tile_d * kPassTiles);
     L.hv = take(sizeof(float) * kTrees * L.ld_v);
     L.lg = take(sizeof(float) * 2 * kTrees * L.ld_l);
-    L.dote = take(sizeof(float) * dot_floats(P.reward.layer[0].Np >> 4, kTrees * kPassTiles));
+    L.dote = take(sizeof(float) * dot_floats(P.reward.layer[0].Np >> 4, kTrees));
     L.dotv = take(sizeof(float) * dot_floats(P.value.layer[1].Np >> 4, kTrees));
+    {   // the arena of the phase after the rounds
+        size_t eo = arena;
+        auto etake = [&](size_t bytes) { size_t o = eo; eo = align16(eo + bytes); return o; };
+        L.ew = etake(sizeof(float) * (size_t)P.reward.layer[0].Np * P.reward.layer[0].Kp);
+        if (off < eo) off = eo;
+    }
     L.b_p0 = take(sizeof(float) * P.policy.layer[0].Np);
     L.b_m = take(sizeof(float) * P.merge.layer[0].Np);
     L.b_p1 = take(sizeof(float) * P.policy.layer[1].Np);
@@ -245,7 +256,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     lds_f *Tab = to_lds(smem_raw + L.tab);
     lds_f *H1 = to_lds(smem_raw + L.h1);
     lds_f *H2 = to_lds(smem_raw + L.h2);
-    lds_f *R = to_lds(smem_raw + L.r);
     lds_f *Hv = to_lds(smem_raw + L.hv);
     lds_f *Lg = to_lds(smem_raw + L.lg);
     lds_f *DotE = to_lds(smem_raw + L.dote);
@@ -255,7 +265,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     lds_f *DwV = to_lds(smem_raw + L.dw_v), *DwR = to_lds(smem_raw + L.dw_r);
     lds_f *Bp2 = to_lds(smem_raw + L.b_p2);
     lds_f *s_prior = to_lds(smem_raw + L.prior);
-    lds_f *s_rew = to_lds(smem_raw + L.rew);
     lds_f *s_roll = to_lds(smem_raw + L.roll);
     lds_i *s_leaf = to_lds_i(smem_raw + L.ints);
     lds_i *s_child = s_leaf + kTrees;
@@ -420,35 +429,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         *reinterpret_cast<lds_f4 *>(qd) = hi;
         *reinterpret_cast<lds_f4 *>(qd + KCD * kChunkFloats) = lo;
     };
-    // row tiles [p0, p0 + kPassTiles) of {children of action 0 .. A-1, rollout latent} -> R (skipping tiles past them)
-    auto form_pass = [&](int p0, bool sim) {
-        for (int i = tid; i < kPassTiles * KCD * 64; i += kThreads) {
-            const int tl = i / (KCD * 64), a = p0 + tl;
-            if (a < A) form_item(i - tl * (KCD * 64), Z, a, nullptr, R + tl * 16 * ld_d);
-            else if (a == A && sim) form_item(i - tl * (KCD * 64), Zs, -1, s_act2, R + tl * 16 * ld_d);
-        }
-    };
-    // reward 1 over the pass's row tiles with the weights held in `s` -> partial sums in DotE
-    auto reward_pass = [&](const Slot<KMAX> &s) {
-        if (wave < nr0) {
-            f32x4 hi[kPassTiles], lo[kPassTiles];
-            mma_tile<KCD, kPassTiles>(s, R + lane * 4, 16 * ld_d, hi, lo);
-            epi_dot<kPassTiles, true>(hi, lo, wave, lds4(Br0 + wave * 16 + 4 * (lane >> 4)), lds4(DwR + wave * 16 + 4 * (lane >> 4)), DotE, lane);
-        }
-    };
-    // rewards of a finished pass: children -> s_rew, rollout latent -> s_roll[t][0]
-    auto finish_pass = [&](int p0, bool sim) {
-        const float b2 = Br0[Lr0.Np];
-        for (int r = tid; r < kTrees * kPassTiles; r += kThreads) {
-            const int a = p0 + r / kTrees, t = r % kTrees;
-            if (a < A || (a == A && sim)) {
-                const float rv = activate(ordered_sum(DotE + r, kTrees * kPassTiles, 4 * nr0) + b2, Lr1.act);
-                if (a < A) s_rew[t * (A + 1) + a] = rv;
-                else s_roll[t * 2] = rv;
-            }
-        }
-    };
-
     // expansion e = 0 is the root expansion (no simulation / backup follows it);
     // expansion e >= 1 belongs to simulation s = e - 1
     for (int e = 0; e <= S; ++e) {
@@ -638,14 +618,14 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             __syncthreads();
         }
         MZ_STAMP(5)  // policy 3, softmax, priors, greedy action
-        if (sim) prefetch2(v0_tile0, v0_tile1, KCD);  // value 1's tiles, in flight while the latents below are formed
-        // ---- rollout latent; first pass of row tiles for reward 1 ---------------------------------------
-        if (sim)
-            for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
-        form_pass(0, sim);
-        __syncthreads();
-        MZ_STAMP(6)  // rollout latent, children of the first pass
         if (sim) {
+            prefetch2(v0_tile0, v0_tile1, KCD);  // value 1's tiles, in flight while the latent below is formed
+            MZ_STAMP(20)
+            // ---- rollout latent ---------------------------------------------------------------------------
+            for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
+            MZ_STAMP(21)
+            __syncthreads();
+            MZ_STAMP(6)  // rollout latent
             // ---- value 1 of the rollout latent -> Hv (split image) -------------------------------------------
             run_step(std::integral_constant<int, KCD>{}, OnePair{}, v0_n, [&](int j) { return tile_of(Lv0, KCD, min(v0_first + j, nv0 - 1)); },
                      [&](Slot<KMAX> &s, int j) {
@@ -659,33 +639,26 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             fetch_tile<KCD>(s1, r0_tile, lane);  // reward 1: in flight through the barrier
             __syncthreads();
             MZ_STAMP(7)  // value 1
-        }
-        // ---- value 2 (slot 0) | reward 1 over the first pass (slot 1, kept for the later passes) ------------------
-        if (!sim) fetch_tile<KCD>(s1, r0_tile, lane);
-        if (sim && wave < nv1) {
-            f32x4 hi[1], lo[1];
-            mma_tile<KCV, 1>(s0, Hv + lane * 4, 0, hi, lo);
-            epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
-        }
-        reward_pass(s1);
-        __syncthreads();
-        MZ_STAMP(8)  // value 2 | reward 1, first pass
-        for (int p0 = kPassTiles; p0 < A + 1; p0 += kPassTiles) {
-            finish_pass(p0 - kPassTiles, sim);
-            MZ_STAMP(12)  // rewards of the previous pass
-            form_pass(p0, sim);
+            // ---- value 2 (slot 0) | reward 1 of the rollout latent (slot 1) ----------------------------------
+            if (wave < nv1) {
+                f32x4 hi[1], lo[1];
+                mma_tile<KCV, 1>(s0, Hv + lane * 4, 0, hi, lo);
+                epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
+            }
+            if (wave < nr0) {
+                f32x4 hi[1], lo[1];
+                mma_tile<KCD, 1>(s1, XI + lane * 4, 0, hi, lo);
+                epi_dot<1, true>(hi, lo, wave, lds4(Br0 + wave * 16 + 4 * (lane >> 4)), lds4(DwR + wave * 16 + 4 * (lane >> 4)), DotE, lane);
+            }
             __syncthreads();
-            MZ_STAMP(13)  // row tiles of the pass
-            reward_pass(s1);
-            __syncthreads();
-            MZ_STAMP(14)  // reward 1 over the pass
+            MZ_STAMP(8)  // value 2 | reward 1
+            if (tid < kTrees) {  // value of the rollout latent (as finish_dot)
+                s_roll[tid * 2 + 1] = activate(ordered_sum(DotV + tid, kTrees, 4 * nv1) + Bv1[Lv1.Np], Lv2.act);
+            } else if (tid >= 64 && tid < 64 + kTrees) {
+                const int t = tid - 64;
+                s_roll[t * 2] = activate(ordered_sum(DotE + t, kTrees, 4 * nr0) + Br0[Lr0.Np], Lr1.act);
+            }
         }
-        finish_pass(((A + 1 - 1) / kPassTiles) * kPassTiles, sim);
-        if (sim && tid < kTrees) {  // value of the rollout latent (as finish_dot)
-            s_roll[tid * 2 + 1] = activate(ordered_sum(DotV + tid, kTrees, 4 * nv1) + Bv1[Lv1.Np], Lv2.act);
-        }
-        __syncthreads();
-        MZ_STAMP(9)  // remaining passes, rewards, value
 
         // ---- child records ---------------------------------------------------------------------------
         for (int i = tid; i < trees * A; i += kThreads) {
@@ -693,10 +666,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             const size_t o = (size_t)(g0 + t) * p.cap;
             float pr = s_prior[t * A + a];
             if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
-            mzt::write_child(p, o, base, a, s_leaf[t], pr, s_rew[t * (A + 1) + a], (int8_t)s_leaf_tp[t]);
+            mzt::write_child(p, o, base, a, s_leaf[t], pr, 0.0f, (int8_t)s_leaf_tp[t]);  // (the reward follows after the rounds)
             if (a == 0) p.node[o + s_leaf[t]].first_child = base;
         }
-        __syncthreads();  // the drawn child's record exists before the backup updates it
+        __syncthreads();  // the drawn child's record exists before the backup updates it (and s_roll is complete)
         if (!sim) continue;
         // ---- backup: the recorded path is updated by independent lanes (see k_search) --------------------------
         if (tid >= kThreads / 2 && tid < kThreads / 2 + kTrees * kPathCap) {
@@ -728,6 +701,110 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         }
         __syncthreads();
         MZ_STAMP(11)  // child records, backup
+    }
+
+    // ---- rewards of every expansion's children (src/search/expansion.py:29-33) --------------------------------
+    // Row-stationary and barrier-free: reward 1's weights (all column tiles) are copied into LDS once; a wave takes
+    // units of up to four children of one expansion, reads its lanes' share of the expansion's merge row from z_pool
+    // once, forms the operand of two children at a time IN REGISTERS (a lane's eight k of row lane & 15 are exactly its
+    // piece of the B operand: no LDS round trip for the activations), multiplies them with every column tile, and folds
+    // the one-output layer as it goes: the four quarter sums of a tile sit in the lanes 16 apart and are added in
+    // ascending order through lane exchanges -- finish_dot's order.  Same per-accumulator instruction sequence and
+    // epilogue arithmetic as the rounds.
+    {
+        tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        lds_f *EW = to_lds(smem_raw + L.ew);
+        const float b2 = Br0[Lr0.Np];
+        __syncthreads();  // the rounds' buffers are dead from here on
+        {
+            const glb_f4 *src = (const glb_f4 *)(blob + Lr0.w_off);
+            for (int i = tid; i < nr0 * KCD * 128; i += kThreads) *reinterpret_cast<lds_f4 *>(EW + i * 4) = src[i];
+        }
+        __syncthreads();
+        const int uph = (A + 3) >> 2, units = (S + 1) * uph;
+        const int j = lane & 15, rq = lane >> 4;
+        for (int u = wave; u < units; u += kWaves) {
+            const int ex = u / uph, a0 = (u - ex * uph) * 4;
+            // this lane's part of the expansion's merge row: k = 32 c + 8 rq .. + 7 of tree j
+            f32x4 z0[KCD], z1[KCD];
+#pragma unroll
+            for (int c = 0; c < KCD; ++c) {
+                const int k0 = 32 * c + 8 * rq;
+                z0[c] = z1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < trees) {
+                    const float *zr = q.z_pool + ((size_t)(g0 + j) * (S + 1) + ex) * D + k0;
+                    if ((D & 3) == 0) {
+                        if (k0 < D) z0[c] = *(const glb_f4 *)(zr);
+                        if (k0 + 4 < D) z1[c] = *(const glb_f4 *)(zr + 4);
+                    } else {
+                        float t8[8];
+                        for (int i = 0; i < 8; ++i) t8[i] = k0 + i < D ? zr[i] : 0.0f;
+                        z0[c] = f32x4{t8[0], t8[1], t8[2], t8[3]};
+                        z1[c] = f32x4{t8[4], t8[5], t8[6], t8[7]};
+                    }
+                }
+            }
+            for (int sp = 0; sp < 2; ++sp) {
+                const int a_first = a0 + 2 * sp;
+                if (a_first >= A) break;
+                h8 xh[2][KCD], xl[2][KCD];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int a = min(a_first + mt, A - 1);
+#pragma unroll
+                    for (int c = 0; c < KCD; ++c) {
+                        const int k0 = 32 * c + 8 * rq;
+                        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                        if (k0 < Dp16) {
+                            const lds_f *tr = Tab + a * ld_d + k0;
+                            const f32x4 b0 = lds4(tr), b1 = lds4(tr + 4);
+                            v0 = f32x4{fmaxf(z0[c].x + b0.x, 0.f), fmaxf(z0[c].y + b0.y, 0.f), fmaxf(z0[c].z + b0.z, 0.f), fmaxf(z0[c].w + b0.w, 0.f)};
+                            v1 = f32x4{fmaxf(z1[c].x + b1.x, 0.f), fmaxf(z1[c].y + b1.y, 0.f), fmaxf(z1[c].z + b1.z, 0.f), fmaxf(z1[c].w + b1.w, 0.f)};
+                        }
+                        f32x4 hi, lo;
+                        split8(v0, v1, hi, lo);
+                        xh[mt][c] = __builtin_bit_cast(h8, hi);
+                        xl[mt][c] = __builtin_bit_cast(h8, lo);
+                    }
+                }
+                float sum[2] = {0.0f, 0.0f};
+                for (int nt = 0; nt < nr0; ++nt) {
+                    f32x4 hi[2], lo[2];
+                    hi[0] = hi[1] = lo[0] = lo[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const lds_f *wt = EW + (size_t)nt * KCD * 512 + lane * 4;
+#pragma unroll
+                    for (int c = 0; c < KCD; ++c) {
+                        const h8 wh = __builtin_bit_cast(h8, lds4(wt + (2 * c) * 256)), wl = __builtin_bit_cast(h8, lds4(wt + (2 * c + 1) * 256));
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[mt][c], hi[mt], 0, 0, 0);
+                            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[mt][c], lo[mt], 0, 0, 0);
+                            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[mt][c], lo[mt], 0, 0, 0);
+                        }
+                    }
+                    const f32x4 bb = lds4(Br0 + nt * 16 + 4 * rq), w2 = lds4(DwR + nt * 16 + 4 * rq);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f32x4 v = epi_value<true>(hi[mt], lo[mt], bb);
+                        float part = __fmul_rn(v.x, w2.x);
+                        part += __fmul_rn(v.y, w2.y);
+                        part += __fmul_rn(v.z, w2.z);
+                        part += __fmul_rn(v.w, w2.w);
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) sum[mt] += __shfl(part, j + 16 * qq, 64);  // quarters in ascending order
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int a = a_first + mt;
+                    if (rq == 0 && a < A && j < trees)
+                        p.node[(size_t)(g0 + j) * p.cap + 1 + ex * A + a].reward = activate(sum[mt] + b2, Lr1.act);
+                }
+            }
+        }
+        MZ_STAMP(9)  // the children's rewards
     }
 
     // ---- result -------------------------------------------------------------------------------
