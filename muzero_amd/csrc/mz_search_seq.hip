@@ -443,6 +443,20 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 
         if (sim) {
             // ---- select, draw, leaf latent -----------------------------------------------------
+            if (tid >= kThreads - kTrees) {  // the child each simulation starts from (src/search/mcts.py:64-66)
+                const int t = tid - (kThreads - kTrees);
+                int rc = 0;
+                if (t < trees) rc = q.rand_child[(size_t)(g0 + t) * (S + 1) + e];
+                rc = min(max(rc, 0), A - 1);
+                s_act[t] = rc;
+                s_child[t] = base + rc;
+                if (q.child_trace && t < trees) q.child_trace[(size_t)(g0 + t) * S + (e - 1)] = base + rc;
+            }
+            // Issuing a tile's loads occupies a wave for as long as the compute unit's L2 port needs to take them, and a
+            // barrier makes everybody wait for the issuing waves: the six waves that do not select request the first
+            // tiles of {policy 1 | merge} HERE, beside the selection (a latency chain of dependent record reads); the
+            // two selecting waves follow in the leaf-latent phase
+            if (wave >= 2) prefetch2(fl_tile0, fl_tile1, KCD);
             if (tid < kTrees * lpt) {
                 const int t = tid / lpt, a = tid % lpt;
                 int leaf = 0, dep = 0;
@@ -463,15 +477,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                         if (q.leaf_trace) q.leaf_trace[(size_t)(g0 + t) * S + (e - 1)] = leaf;
                     }
                 }
-            }
-            if (tid >= kThreads - kTrees) {  // the child each simulation starts from (src/search/mcts.py:64-66)
-                const int t = tid - (kThreads - kTrees);
-                int rc = 0;
-                if (t < trees) rc = q.rand_child[(size_t)(g0 + t) * (S + 1) + e];
-                rc = min(max(rc, 0), A - 1);
-                s_act[t] = rc;
-                s_child[t] = base + rc;
-                if (q.child_trace && t < trees) q.child_trace[(size_t)(g0 + t) * S + (e - 1)] = base + rc;
             }
             __syncthreads();
             MZ_STAMP(1)  // select
@@ -496,9 +501,11 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                         for (int j = 0; j < 8; ++j) z[j] = k0 + j < D ? zr[j] : 0.0f;
                     }
                 }
-                // the first tiles of {policy 1 | merge} are requested behind the rows (loads return in order: in front of
-                // them they would hold the rows back) and are in flight while the image is formed
-                prefetch2(fl_tile0, fl_tile1, KCD);
+                // The first tiles of {policy 1 | merge}.  Issuing a tile's loads occupies the wave for as long as the compute
+                // unit's L2 port needs to take them, so the waves that were idle during records, backup and selection
+                // requested theirs there; the two selecting waves do it here, behind the rows (loads return in order:
+                // in front of the rows they would hold them back)
+                if (wave < 2) prefetch2(fl_tile0, fl_tile1, KCD);
                 if (live) {
                     const lds_f *tr = Tab + a * ld_d + k0;
                     v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
@@ -554,6 +561,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             run_step(std::integral_constant<int, KCP>{}, OnePair{}, p1_n, ptr, work, [&] {
                 if (wave == 0) fetch_tile<KCP>(s0, tile_of(Lp2, KCP, 0), lane);
             });
+            // value 1's first tiles: in flight through policy 3, the softmax phase and the forming of the rollout latent
         }
         __syncthreads();
         MZ_STAMP(4)  // policy 2 (leaf + child)
@@ -567,6 +575,8 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             }
             __syncthreads();
             MZ_STAMP(19)  // policy 3
+            // value 1's first tiles: waves 4-7 request them beside the softmax phase (waves 0-3), which follow afterwards
+            if (sim && wave >= 4) prefetch2(v0_tile0, v0_tile1, KCD);
             // softmax_rows' arithmetic for A <= 8 (row maximum and sum over the columns in ascending order) with the
             // row's values exchanged through LDS instead of lane by lane: eight lanes per row, all 32 rows at once --
             // the network's own softmax; then the first maximum of the child's policy (src/search/simulation.py:36)
@@ -619,11 +629,9 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         }
         MZ_STAMP(5)  // policy 3, softmax, priors, greedy action
         if (sim) {
-            prefetch2(v0_tile0, v0_tile1, KCD);  // value 1's tiles, in flight while the latent below is formed
-            MZ_STAMP(20)
+            if (wave < 4) prefetch2(v0_tile0, v0_tile1, KCD);
             // ---- rollout latent ---------------------------------------------------------------------------
             for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
-            MZ_STAMP(21)
             __syncthreads();
             MZ_STAMP(6)  // rollout latent
             // ---- value 1 of the rollout latent -> Hv (split image) -------------------------------------------

@@ -11,8 +11,8 @@ NAMES = {0: "staging", 1: "select", 2: "leaf gather", 3: "policy1|merge (all wav
 
 # the sequential-program kernel (implicit child latents) stamps its own steps
 SEQ_NAMES = {0: "staging", 1: "select + draw", 2: "leaf latent", 3: "policy1|merge (leaf)", 16: "child latent",
-             18: "policy1|merge (child)", 4: "policy 2 (leaf + child)", 5: "priors", 19: "policy 3 (narrow)", 20: "(diag) prefetch issue", 21: "(diag) form before barrier",
-             6: "rollout latent", 7: "value 1", 8: "value 2 | reward 1", 9: "after the rounds: last rewards", 10: "after the rounds: merge rows staged", 12: "after the rounds: rewards of the previous pass", 13: "after the rounds: row tiles of a pass", 14: "after the rounds: reward 1 over a pass",
+             18: "policy1|merge (child)", 4: "policy 2 (leaf + child)", 5: "priors", 19: "policy 3 (narrow)",
+             6: "rollout latent", 7: "value 1", 8: "value 2 | reward 1", 9: "after the rounds: rewards of all children",
              11: "child records, backup"}
 
 
