@@ -9,9 +9,9 @@
 // saturated when both stream.  Here all eight waves run ONE sequential program per round:
 //
 //   select, leaf latent          (implicit child latents: formed from the parent's merge row)
-//   {policy 1 | merge}(leaf)
-//   {policy 1 | merge}(drawn child)
-//   policy 2 for leaf AND child as one 32-row pass      (its weights are read once, not twice)
+//   merge(leaf)                                         (the drawn child's latent needs only this)
+//   policy 1 for leaf AND child as one 32-row pass | merge(drawn child)
+//   policy 2 for leaf AND child as one 32-row pass      (their weights are read once, not twice)
 //   policy 3 for the 32 rows (one column tile: one wave), softmax; priors of the leaf, greedy action of the child
 //   value 1 (rollout latent)
 //   value 2 | reward 1 of the rollout latent
@@ -83,7 +83,7 @@ __host__ __device__ inline SeqLds seq_layout(const mz_packed_nets &P, int tab_le
     const size_t tile_d = sizeof(float) * kTrees * L.ld_d;
     L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
     const size_t arena = off;
-    L.xi = take(tile_d);
+    L.xi = take(2 * tile_d);  // row tile 0: leaf (later the rollout latent), row tile 1: drawn child
     L.z = take(tile_d);
     L.zs = take(tile_d);
     L.h1 = take(sizeof(float) * 2 * kTrees * L.ld_p);
@@ -343,19 +343,20 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     }
     __syncthreads();
     rows_to_split(Z, ld_d, XI, ld_d, 1, KCD, ld_d, whole_workgroup());
+    for (int i = tid; i < kTrees * ld_d; i += kThreads) XI[kTrees * ld_d + i] = 0.0f;  // (no drawn child in the root expansion)
     __syncthreads();
     MZ_STAMP(0)  // staging
 
     // ---- this wave's tiles in every step (static over the search) -----------------------------------
-    int fl_first, fl_n, p1_first, p1_n, v0_first, v0_n;
-    deal_pairs(np0 + nm0, wave, fl_first, fl_n);
+    int p0_first, p0_n, p1_first, p1_n, v0_first, v0_n;
+    deal_pairs(np0, wave, p0_first, p0_n);
     deal_pairs(np1, wave, p1_first, p1_n);
     deal_pairs(nv0, wave, v0_first, v0_n);
-    auto fl_tile = [&](int t) {  // tile t of {policy 1 | merge}
-        t = min(t, np0 + nm0 - 1);
-        return t < np0 ? tile_of(Lp0, KCD, t) : tile_of(Lm0, KCD, t - np0);
-    };
-    const float *fl_tile0 = fl_tile(fl_first), *fl_tile1 = fl_tile(fl_first + min(1, max(fl_n - 1, 0)));
+    // merge: column tiles wave, wave + 8 (at most two: checked by the host)
+    const int m_n = (wave < nm0 ? 1 : 0) + (wave + kWaves < nm0 ? 1 : 0);
+    auto m_tile = [&](int j) { return tile_of(Lm0, KCD, min(wave + kWaves * min(j, max(m_n - 1, 0)), nm0 - 1)); };
+    const float *m_tile0 = m_tile(0), *m_tile1 = m_tile(1);
+    const float *p0_tile0 = tile_of(Lp0, KCD, min(p0_first, np0 - 1)), *p0_tile1 = tile_of(Lp0, KCD, min(p0_first + 1, np0 - 1));
     const float *p1_tile0 = tile_of(Lp1, KCP, min(p1_first, np1 - 1)), *p1_tile1 = tile_of(Lp1, KCP, min(p1_first + 1, np1 - 1));
     const float *v0_tile0 = tile_of(Lv0, KCD, min(v0_first, nv0 - 1)), *v0_tile1 = tile_of(Lv0, KCD, min(v0_first + 1, nv0 - 1));
     const float *v1_tile = tile_of(Lv1, KCV, min(wave, nv1 - 1));   // value 2 and reward 1: tile `wave` each
@@ -395,17 +396,39 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     using MultiPair = std::true_type;
     using OnePair = std::false_type;
 
-    // {policy 1 | merge} of the rows whose image is in XI: policy 1 -> row tile `h_tile` of H1 (split image),
-    // merge pre-activation -> z_out (fp32 rows)
-    auto first_layers = [&](int h_tile, lds_f *z_out) {
-        lds_f *h_out = H1 + h_tile * 16 * ld_p;
-        run_step(std::integral_constant<int, KCD>{}, MultiPair{}, fl_n, [&](int j) { return fl_tile(fl_first + j); },
+    lds_f *XC = XI + kTrees * ld_d;  // the drawn child's image
+    // merge of the leaf (image in XI) -> Z (fp32 rows): at most two tiles per wave, both prefetched
+    auto merge_leaf = [&] {
+        run_step(std::integral_constant<int, KCD>{}, OnePair{}, m_n, m_tile,
                  [&](Slot<KMAX> &s, int j) {
-                     const int t = fl_first + j;
+                     const int t = wave + kWaves * j;
                      f32x4 hi[1], lo[1];
                      mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
-                     if (t < np0) epi_split<1, true>(hi, lo, t, lds4(Bp0 + t * 16 + 4 * (lane >> 4)), h_out, 16 * ld_p, KCP, np0, lane);
-                     else epi_rows<1, false>(hi, lo, t - np0, lds4(Bm + (t - np0) * 16 + 4 * (lane >> 4)), z_out, ld_d, lane);
+                     epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Z, ld_d, lane);
+                 },
+                 nothing);
+    };
+    // policy 1 of leaf AND drawn child as one pass over two row tiles (its weights are read once per round) -> H1
+    // (split image, two row tiles); with `child`, the merge of the drawn child (row tile 1) -> Zs behind it
+    auto policy1_and_child_merge = [&](bool child) {
+        const int n = p0_n + (child ? m_n : 0);
+        run_step(std::integral_constant<int, KCD>{}, MultiPair{}, n,
+                 [&](int j) {
+                     j = min(j, n - 1);
+                     return j < p0_n ? tile_of(Lp0, KCD, min(p0_first + j, np0 - 1)) : m_tile(j - p0_n);
+                 },
+                 [&](Slot<KMAX> &s, int j) {
+                     if (j < p0_n) {
+                         const int t = p0_first + j;
+                         f32x4 hi[2], lo[2];
+                         mma_tile<KCD, 2>(s, XI + lane * 4, 16 * ld_d, hi, lo);
+                         epi_split<2, true>(hi, lo, t, lds4(Bp0 + t * 16 + 4 * (lane >> 4)), H1, 16 * ld_p, KCP, np0, lane);
+                     } else {
+                         const int t = wave + kWaves * (j - p0_n);
+                         f32x4 hi[1], lo[1];
+                         mma_tile<KCD, 1>(s, XC + lane * 4, 0, hi, lo);
+                         epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Zs, ld_d, lane);
+                     }
                  },
                  nothing);
     };
@@ -454,9 +477,9 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             }
             // Issuing a tile's loads occupies a wave for as long as the compute unit's L2 port needs to take them, and a
             // barrier makes everybody wait for the issuing waves: the six waves that do not select request the first
-            // tiles of {policy 1 | merge} HERE, beside the selection (a latency chain of dependent record reads); the
+            // tiles of the leaf's merge HERE, beside the selection (a latency chain of dependent record reads); the
             // two selecting waves follow in the leaf-latent phase
-            if (wave >= 2) prefetch2(fl_tile0, fl_tile1, KCD);
+            if (wave >= 2) prefetch2(m_tile0, m_tile1, KCD);
             if (tid < kTrees * lpt) {
                 const int t = tid / lpt, a = tid % lpt;
                 int leaf = 0, dep = 0;
@@ -501,11 +524,11 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                         for (int j = 0; j < 8; ++j) z[j] = k0 + j < D ? zr[j] : 0.0f;
                     }
                 }
-                // The first tiles of {policy 1 | merge}.  Issuing a tile's loads occupies the wave for as long as the compute
+                // The tiles of the leaf's merge.  Issuing a tile's loads occupies the wave for as long as the compute
                 // unit's L2 port needs to take them, so the waves that were idle during records, backup and selection
                 // requested theirs there; the two selecting waves do it here, behind the rows (loads return in order:
                 // in front of the rows they would hold them back)
-                if (wave < 2) prefetch2(fl_tile0, fl_tile1, KCD);
+                if (wave < 2) prefetch2(m_tile0, m_tile1, KCD);
                 if (live) {
                     const lds_f *tr = Tab + a * ld_d + k0;
                     v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
@@ -523,30 +546,26 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             MZ_STAMP(2)  // leaf latent
         }
 
-        // ---- {policy 1 | merge} of the leaf, then of the drawn child ------------------------------------
-        for (int rep_i = 0; rep_i < (sim ? 2 : 1); ++rep_i) {
-            if (rep_i == 1) {  // the drawn child's latent
-                for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Z, -1, s_act, XI);
-                __syncthreads();
-                MZ_STAMP(16)  // child latent
-            }
-            if (!sim) prefetch2(fl_tile0, fl_tile1, KCD);  // (root expansion: nothing to hide it behind)
-            const bool again = sim && rep_i == 0;  // the same step follows once more
-            first_layers(rep_i, rep_i == 0 ? Z : Zs);
-            // in flight through the epilogue, the barrier and what lies between the steps
-            prefetch2(again ? fl_tile0 : p1_tile0, again ? fl_tile1 : p1_tile1, again ? KCD : KCP);
-            __syncthreads();
-            if (rep_i == 0) {
-                MZ_STAMP(3)  // policy 1 | merge (leaf)
-                // the leaf's merge row is all that is kept of its children's latents
-                for (int i = tid; i < trees * D; i += kThreads) {
-                    const int t = i / D, c = i - t * D;
-                    q.z_pool[((size_t)(g0 + t) * (S + 1) + e) * D + c] = Z[t * ld_d + c];
-                }
-            } else {
-                MZ_STAMP(18)  // policy 1 | merge (child)
-            }
+        // ---- merge of the leaf; the drawn child's latent; policy 1 of both | merge of the child -----------------
+        if (!sim) prefetch2(m_tile0, m_tile1, KCD);  // (root expansion: nothing to hide it behind)
+        merge_leaf();
+        prefetch2(p0_tile0, p0_tile1, KCD);  // in flight through the barrier, the row store and the forming of the child
+        __syncthreads();
+        MZ_STAMP(3)  // merge (leaf)
+        // the leaf's merge row is all that is kept of its children's latents
+        for (int i = tid; i < trees * D; i += kThreads) {
+            const int t = i / D, c = i - t * D;
+            q.z_pool[((size_t)(g0 + t) * (S + 1) + e) * D + c] = Z[t * ld_d + c];
         }
+        if (sim) {
+            for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Z, -1, s_act, XC);
+            __syncthreads();
+            MZ_STAMP(16)  // child latent
+        }
+        policy1_and_child_merge(sim);
+        prefetch2(p1_tile0, p1_tile1, KCP);
+        __syncthreads();
+        MZ_STAMP(18)  // policy 1 (leaf + child) | merge (child)
 
         // ---- policy 2 of leaf and child: one pass over two row tiles ---------------------------------
         {
@@ -861,6 +880,7 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
         return 0;
     if ((P.value.layer[1].Np >> 4) > kWaves || (P.reward.layer[0].Np >> 4) > kWaves) return 0;
     if ((P.policy.layer[1].Np >> 4) > 2 * kWaves || (P.value.layer[0].Np >> 4) > 2 * kWaves) return 0;
+    if ((P.policy.layer[0].Np >> 4) > 2 * kWaves || (P.merge.layer[0].Np >> 4) > 2 * kWaves) return 0;
     const int kcd = P.merge.layer[0].Kp >> 5, kcp = P.policy.layer[1].Kp >> 5, kcv = P.value.layer[1].Kp >> 5;
     if (P.policy.layer[0].Kp != P.merge.layer[0].Kp || P.value.layer[0].Kp != P.merge.layer[0].Kp ||
         P.reward.layer[0].Kp != P.merge.layer[0].Kp)

@@ -10,8 +10,8 @@ NAMES = {0: "staging", 1: "select", 2: "leaf gather", 3: "policy1|merge (all wav
          21: "S value head", 22: "S wait for E"}
 
 # the sequential-program kernel (implicit child latents) stamps its own steps
-SEQ_NAMES = {0: "staging", 1: "select + draw", 2: "leaf latent", 3: "policy1|merge (leaf)", 16: "child latent",
-             18: "policy1|merge (child)", 4: "policy 2 (leaf + child)", 5: "priors", 19: "policy 3 (narrow)",
+SEQ_NAMES = {0: "staging", 1: "select + draw", 2: "leaf latent", 3: "merge (leaf)", 16: "child latent",
+             18: "policy 1 (leaf + child) | merge (child)", 4: "policy 2 (leaf + child)", 5: "priors", 19: "policy 3 (narrow)",
              6: "rollout latent", 7: "value 1", 8: "value 2 | reward 1", 9: "after the rounds: rewards of all children",
              11: "child records, backup"}
 
