@@ -138,21 +138,43 @@ __device__ __forceinline__ void fetch_tile(Slot<KMAX> &s, const float *tile, int
 // x_tile floats apart.  Same instruction sequence per accumulator as stream_tiles.
 template <int KC, int MT, int KMAX>
 __device__ __forceinline__ void mma_tile(const Slot<KMAX> &s, const lds_f *img, int x_tile, f32x4 (&hi)[MT], f32x4 (&lo)[MT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) hi[mt] = lo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const h8 wh = __builtin_bit_cast(h8, s.w[c][0]), wl = __builtin_bit_cast(h8, s.w[c][1]);
+    // The rows' operands are read from LDS kAhead chunks ahead of the matrix instructions that use them, with
+    // scheduling fences between the groups: left to itself the compiler issues each chunk's reads right in front of
+    // its products and every chunk pays an LDS round trip.
+    constexpr int kAhead = MT == 1 ? 2 : 1, kBuf = kAhead + 1;
+    h8 ah[kBuf][MT], al[kBuf][MT];
+    auto read = [&](int c) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const lds_f *p = img + mt * x_tile + c * kChunkFloats;
-            const h8 ah = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p));
-            const h8 al = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p + KC * kChunkFloats));
-            hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, hi[mt], 0, 0, 0);
-            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al, lo[mt], 0, 0, 0);
-            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah, lo[mt], 0, 0, 0);
+            ah[c % kBuf][mt] = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p));
+            al[c % kBuf][mt] = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p + KC * kChunkFloats));
         }
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) hi[mt] = lo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < kAhead && c < KC; ++c) read(c);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        if (c + kAhead < KC) read(c + kAhead);
+        __builtin_amdgcn_sched_barrier(0);
+        const h8 wh = __builtin_bit_cast(h8, s.w[c][0]), wl = __builtin_bit_cast(h8, s.w[c][1]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[c % kBuf][mt], hi[mt], 0, 0, 0);
+            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[c % kBuf][mt], lo[mt], 0, 0, 0);
+            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[c % kBuf][mt], lo[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// v of the lane a DPP control selects (all rows and banks enabled; a lane without a source keeps its own value).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false));
 }
 
 // A float4 of an LDS array as a register value.
@@ -553,9 +575,18 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         __syncthreads();
         MZ_STAMP(3)  // merge (leaf)
         // the leaf's merge row is all that is kept of its children's latents
-        for (int i = tid; i < trees * D; i += kThreads) {
-            const int t = i / D, c = i - t * D;
-            q.z_pool[((size_t)(g0 + t) * (S + 1) + e) * D + c] = Z[t * ld_d + c];
+        if ((D & 3) == 0) {
+            const int d4 = D >> 2;
+            for (int i = tid; i < trees * d4; i += kThreads) {
+                const int t = i / d4, c = (i - t * d4) * 4;
+                *reinterpret_cast<float4 *>(q.z_pool + ((size_t)(g0 + t) * (S + 1) + e) * D + c) =
+                    __builtin_bit_cast(float4, lds4(Z + t * ld_d + c));
+            }
+        } else {
+            for (int i = tid; i < trees * D; i += kThreads) {
+                const int t = i / D, c = i - t * D;
+                q.z_pool[((size_t)(g0 + t) * (S + 1) + e) * D + c] = Z[t * ld_d + c];
+            }
         }
         if (sim) {
             for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Z, -1, s_act, XC);
@@ -596,45 +627,39 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             MZ_STAMP(19)  // policy 3
             // value 1's first tiles: waves 4-7 request them beside the softmax phase (waves 0-3), which follow afterwards
             if (sim && wave >= 4) prefetch2(v0_tile0, v0_tile1, KCD);
-            // softmax_rows' arithmetic for A <= 8 (row maximum and sum over the columns in ascending order) with the
-            // row's values exchanged through LDS instead of lane by lane: eight lanes per row, all 32 rows at once --
-            // the network's own softmax; then the first maximum of the child's policy (src/search/simulation.py:36)
-            // and expand_node's extra softmax for the leaf (src/search/expansion.py:27), without a barrier in between
-            // (a row's eight lanes sit in one wave)
+            // softmax_rows' arithmetic for A <= 8 (row maximum; sum over the columns in ascending order) with eight lanes
+            // per row, all 32 rows at once, the lanes of a row exchanging values through DPP moves instead of LDS round
+            // trips: the network's own softmax; then the first maximum of the child's policy
+            // (src/search/simulation.py:36) and expand_node's extra softmax for the leaf (src/search/expansion.py:27)
             if (tid < 2 * kTrees * 8) {
                 const int row = tid >> 3, jx = tid & 7;
-                lds_f *lr = Lg + row * ld_l;
-                auto softmax8 = [&](float v) {
-                    const f32x4 a0 = lds4(lr), a1 = lds4(lr + 4);
-                    const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    float mx = x[0];
-                    for (int i = 1; i < A; ++i) mx = fmaxf(mx, x[i]);
-                    const float ev = expf(v - mx);
-                    lr[8 + jx] = ev;  // columns 8 .. 15 of the row are free
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const f32x4 e0 = lds4(lr + 8), e1 = lds4(lr + 12);
-                    const float ex[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-                    float sum = 0.0f;
-                    for (int i = 0; i < A; ++i) sum += ex[i];
-                    return ev / sum;
-                };
                 const bool live = jx < A;
-                float v = live ? lr[jx] : 0.0f;
-                v = softmax8(v);
-                __builtin_amdgcn_wave_barrier();
-                if (live) lr[jx] = v;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (row >= kTrees) {
-                    if (jx == 0) {
-                        int best = 0;
-                        for (int a = 1; a < A; ++a)
-                            if (lr[a] > lr[best]) best = a;
-                        s_act2[row - kTrees] = best;
+                auto softmax8 = [&](float v) {  // v: this lane's column (dead lanes: any value)
+                    float mx = live ? v : -INFINITY;
+                    mx = fmaxf(mx, dpp_f32<0xB1>(mx));    // quad_perm [1,0,3,2]
+                    mx = fmaxf(mx, dpp_f32<0x4E>(mx));    // quad_perm [2,3,0,1]
+                    mx = fmaxf(mx, dpp_f32<0x141>(mx));   // row_half_mirror: all eight lanes hold the row maximum
+                    const float ev = live ? expf(v - mx) : 0.0f;
+                    float sum = ev;                       // lane k ends with e0 + e1 + ... + ek, added in that order
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) {
+                        const float below = dpp_f32<0x111>(sum);  // row_shr:1
+                        if (jx == k) sum = below + ev;
                     }
+                    const float top = dpp_f32<0xFF>(sum);         // quad_perm [3,3,3,3]: lanes 4-7 hold lane 7's total
+                    const float mir = dpp_f32<0x141>(top);        // lanes 0-3 take it from lanes 7-4
+                    return ev / (jx < 4 ? mir : top);
+                };
+                float v = live ? Lg[row * ld_l + jx] : 0.0f;
+                v = softmax8(v);
+                if (row >= kTrees) {
+                    float mx = live ? v : -INFINITY;
+                    mx = fmaxf(mx, dpp_f32<0xB1>(mx));
+                    mx = fmaxf(mx, dpp_f32<0x4E>(mx));
+                    mx = fmaxf(mx, dpp_f32<0x141>(mx));
+                    const unsigned long long hit = __ballot(live && v == mx);
+                    const unsigned bits = (unsigned)(hit >> (lane & ~7)) & 0xffu;
+                    if (jx == 0) s_act2[row - kTrees] = bits ? __ffs(bits) - 1 : 0;  // the first maximum
                 } else {
                     v = softmax8(v);
                     if (live) {
