@@ -391,8 +391,14 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
  *       per channel chunk instead of once per tap; needs no index table.  Bit-identical to
  *       mz_conv3_forward; W is limited to 63 for k = 3 (wider images, up to 144 pixels, are staged from
  *       the float32 form only: mz_conv3_same_bn_forward);
+ *   mz_conv3_same_block_forward  mz_conv3_same_bn_forward whose operand is the output of a whole ResBlock
+ *       (network_builder.py:138-145): in_activation(x * in_scale + in_shift + r), r = residual (identity skip: the
+ *       block's float32 input) or residual * res_scale + res_shift (the raw 1x1 skip convolution and its BatchNorm),
+ *       with mz_bn_apply3's roundings; block_out (optional, f32[G*H*W][C]) receives that output once -- the next
+ *       block's skip path needs it -- so the block's bn2 / skip sum / activation costs no pass of its own.  W <= 63;
  *   mz_conv3_same_fits        1 when mz_conv3_same_forward (raw = 0) or mz_conv3_same_bn_forward (raw = 1;
- *       with_bn: in_scale / in_shift given) takes the shape -- image width and the LDS the staged range and
+ *       with_bn = 1: in_scale / in_shift given; 2: mz_conv3_same_block_forward with an identity skip; 3: with the
+ *       skip path's scale / shift) takes the shape -- image width and the LDS the staged range and
  *       the scale / shift rows need -- else 0; sets no error.  Callers choose between the staged kernels,
  *       mz_conv3_forward and a separate mz_bn_apply3 with it instead of repeating the kernel's limits;
  *   mz_conv3_same_bn_forward  mz_conv3_same_forward whose input is the raw float32 output x of the previous
@@ -424,6 +430,11 @@ int mz_conv3_same_bn_forward(const float *x, const float *in_scale, const float 
                              int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
                              int64_t y_plane, int32_t N, double *block_sums, void *stream);
 int mz_conv3_same_fits(int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, int32_t N, int32_t raw, int32_t with_bn);
+int mz_conv3_same_block_forward(const float *x, const float *in_scale, const float *in_shift, const float *residual,
+                                const float *res_scale, const float *res_shift, int32_t in_activation, float *block_out,
+                                int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, const uint16_t *w3,
+                                int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
+                                int64_t y_plane, int32_t N, double *block_sums, void *stream);
 int mz_bn_stats_from_sums(const double *block_sums, int32_t G, int32_t P, int32_t C, const float *weight,
                           const float *bias, float eps, float *scale, float *shift, float *mean, float *var,
                           void *stream);

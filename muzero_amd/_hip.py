@@ -165,6 +165,8 @@ _SIGS = {
     "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
                                    C.c_int32, C.c_int32, _P, _P]),
     "mz_conv3_same_fits": (C.c_int, [C.c_int32] * 8),
+    "mz_conv3_same_block_forward": (C.c_int, [_P] * 6 + [C.c_int32, _P] + [C.c_int32] * 5 + [_P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
+                                               C.c_int32, _P, _P]),
     "mz_conv3_same_bn_forward": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                            C.c_int64, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     "mz_bn_stats_from_sums": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),

@@ -104,9 +104,12 @@ class _Bn:
 class ConvRepresentation:
     def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False,
                  fast_convolutions: bool = True, staged_range: bool = True, fused_statistics: bool = True,
-                 fused_input_bn: bool = True):
+                 fused_input_bn: bool = True, fused_block_output: bool = True):
         self.src = repr_net
         self.fused_input_bn = fused_input_bn
+        # a ResBlock's bn2 + skip sum + activation applied while the NEXT block's conv1 stages its input (which also
+        # writes the block output once, for that block's own skip path) instead of a pass of its own
+        self.fused_block_output = fused_block_output
         self.staged_range = staged_range
         self.fused_statistics = fused_statistics
         self.device = torch.device(device)
@@ -273,21 +276,24 @@ class ConvRepresentation:
             _hip.check(_hip.lib().mz_split3(ptr(a.f), a.n, ptr(a.s), a.n, _stream()), "mz_split3")
         return a.s
 
-    def _staged(self, cv: _Conv, G: int, H: int, W: int, raw: bool = True, with_bn: bool = False) -> bool:
+    def _staged(self, cv: _Conv, G: int, H: int, W: int, raw: bool = True, with_bn=False) -> bool:
         """Whether `cv` runs on the kernel that stages a tile's contiguous pixel range (stride-1 "same") for G images
         of H x W pixels; `raw`: from a float32 input (split while staged), `with_bn`: with the previous layer's
         BatchNorm applied while staging.  The kernel's own limits decide (mz_conv3_same_fits)."""
         if not (cv.fast and self.staged_range and cv.stride == 1 and cv.k in (1, 3) and cv.pad == (cv.k - 1) // 2):
             return False
-        return bool(_hip.lib().mz_conv3_same_fits(cv.cin, G, H, W, cv.k, cv.cout, 1 if raw else 0, 1 if with_bn else 0))
+        return bool(_hip.lib().mz_conv3_same_fits(cv.cin, G, H, W, cv.k, cv.cout, 1 if raw else 0, int(with_bn)))
 
-    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False, pre=None):
+    def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False, pre=None, block=None):
         """a: input activation [G, H, W, cin] -> (output activation, Ho, Wo).  The output is float32
         unless `split_out` and the layer runs on the split-bf16 product (then split only).
         `sums`: where the kernel can, also leave the column sums of every 64-row block in `out.sums`
         (the BatchNorm statistics that follow then need no pass over the output).
         `pre` = (scale, shift, activation): `a` is the raw float32 output of the previous convolution and
-        the layer reads activation(a * scale + shift) (only for layers `_staged` accepts)."""
+        the layer reads activation(a * scale + shift) (only for layers `_staged` accepts).
+        `block` = (scale, shift, activation, residual, res_scale, res_shift, block_out): `a` is the raw output of the
+        previous ResBlock's conv2 and the layer reads that block's output activation(a * scale + shift + skip), which it
+        also writes to `block_out` (mz_conv3_same_block_forward)."""
         lib = _hip.lib()
         Ho, Wo = cv.out_hw(H, W)
         if Ho <= 0 or Wo <= 0:
@@ -296,16 +302,23 @@ class ConvRepresentation:
         n_out = rows * cv.cout
         out = self._Act(n=n_out)
         if cv.fast:
-            if pre is None and a.f is not None and self._staged(cv, G, H, W) and \
+            if block is None and pre is None and a.f is not None and self._staged(cv, G, H, W) and \
                     (a.s is None or not self._staged(cv, G, H, W, raw=False)):
                 pre = (None, None, 0)   # a float32 activation is split while it is staged
-            x3 = self._s3(a, name + "_in") if pre is None else None
+            x3 = self._s3(a, name + "_in") if pre is None and block is None else None
             if split_out:
                 out.s = self._buf(name + "_s", (3, n_out), torch.int16)
             else:
                 out.f = self._buf(name, (n_out,))
             if sums and self.fused_statistics and (Ho * Wo) % 64 == 0:
                 out.sums = self._buf(name + "_sums", (rows // 64, cv.cout, 2), torch.float64)
+            if block is not None:
+                sc, sh, act_in, res, rsc, rsh, block_out = block
+                _hip.check(lib.mz_conv3_same_block_forward(ptr(a.f), ptr(sc), ptr(sh), ptr(res), ptr(rsc), ptr(rsh), act_in, ptr(block_out),
+                                                           cv.cin, G, H, W, cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias), cv.act,
+                                                           ptr(out.f), ptr(out.s), n_out, cv.cout, ptr(out.sums), _stream()),
+                           "mz_conv3_same_block_forward")
+                return out, Ho, Wo
             if pre is not None:
                 _hip.check(lib.mz_conv3_same_bn_forward(ptr(a.f), ptr(pre[0]), ptr(pre[1]), pre[2], cv.cin, G, H, W, cv.k, ptr(cv.w3),
                                                         cv.w3.shape[1], ptr(cv.bias), cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout,
@@ -415,6 +428,7 @@ class ConvRepresentation:
             x = self._Act(f=self._buf("in_nhwc", (n_in,)), n=n_in)
             _hip.check(lib.mz_nchw_to_nhwc(ptr(x_in), G, Cc, H * W, ptr(x.f), _stream()), "mz_nchw_to_nhwc")
         # activations ping-pong between named buffers; a block's input must survive until its skip sum
+        pending = None  # a block output not formed yet: the next block's conv1 forms it (fused_block_output)
         for si, step in enumerate(self.steps):
             tag = f"s{si % 2}"
             split_next = self._wants_split(si)
@@ -440,7 +454,16 @@ class ConvRepresentation:
                 _, c1, b1, c2, b2, down, dbn, act, pool = step
                 if c1.cin != Cc:
                     raise ValueError(f"block {si} expects {c1.cin} channels, got {Cc}")
-                raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1", sums=True)
+                if pending is not None:
+                    # the previous block's bn2 + skip sum + activation, applied while conv1 stages its input; `x` becomes
+                    # that block's output, written by the same launch
+                    raw_p, sc_p, sh_p, act_p, res_p, rsc_p, rsh_p, n_p, name_p = pending
+                    y_prev = self._Act(f=self._buf(name_p, (n_p,)), n=n_p)
+                    raw1, H1, W1 = self._conv(raw_p, G, H, W, c1, tag + "_c1", sums=True,
+                                              block=(sc_p, sh_p, act_p, res_p, rsc_p, rsh_p, y_prev.f))
+                    x, pending = y_prev, None
+                else:
+                    raw1, H1, W1 = self._conv(x, G, H, W, c1, tag + "_c1", sums=True)
                 sc1, sh1 = self._stats(raw1, G, H1 * W1, b1, tag + "_bn1")
                 if self.fused_input_bn and self._staged(c2, G, H1, W1, with_bn=True):
                     # bn1 and the activation are applied while conv2 stages its input
@@ -450,17 +473,30 @@ class ConvRepresentation:
                     raw2, H2, W2 = self._conv(a1, G, H1, W1, c2, tag + "_c2", sums=True)
                 sc2, sh2 = self._stats(raw2, G, H2 * W2, b2, tag + "_bn2")
                 out_split = split_next and pool is None
+                nxt = self.steps[si + 1] if si + 1 < len(self.steps) else None
+                defer = (self.fused_block_output and pool is None and nxt is not None and nxt[0] == "block" and raw2.f is not None
+                         and not (pre_final and si + 1 == len(self.steps) - 1)
+                         and nxt[1].cin == c2.cout and (down is not None or x.f is not None)
+                         and self._staged(nxt[1], G, H2, W2, with_bn=3 if down is not None else 2))
                 if down is not None:
                     d, Hd, Wd = self._conv(x, G, H, W, down, tag + "_d", sums=True)
                     if (Hd, Wd) != (H2, W2):
                         raise ValueError("the skip path and the main path of a residual block disagree in size")
                     scd, shd = self._stats(d, G, Hd * Wd, dbn, tag + "_bnd")
-                    y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=d.f, res_scale=scd,
-                                    res_shift=shd)
+                    if defer:
+                        pending = (raw2, sc2, sh2, act, d.f, scd, shd, G * H2 * W2 * c2.cout, tag + "_y")
+                        y = None
+                    else:
+                        y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=d.f, res_scale=scd,
+                                        res_shift=shd)
                 else:
                     if (H, W, Cc) != (H2, W2, c2.cout):
                         raise ValueError("an identity skip needs equal input and output shapes")
-                    y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=x)
+                    if defer:
+                        pending = (raw2, sc2, sh2, act, x.f, None, None, G * H2 * W2 * c2.cout, tag + "_y")
+                        y = None
+                    else:
+                        y = self._apply(raw2.f, sc2, sh2, act, G, H2 * W2, c2.cout, tag + "_y", out_split, res=x)
                 x, H, W, Cc = y, H2, W2, c2.cout
                 if pool is not None:
                     k, s_ = pool

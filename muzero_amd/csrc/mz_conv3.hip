@@ -266,10 +266,17 @@ __host__ __device__ constexpr size_t same_lds(int cap, int bn_games, int C) {
 // in_act(xf * in_scale[game][c] + in_shift[game][c]) -- that layer's BatchNorm and activation --
 // formed and split while the range is staged, so the normalised activation is never written to
 // memory.  The scale / shift rows of the few games a range can touch sit in LDS behind the slot table.
-template <bool RAW, int NJ>
+// RES (with RAW): the operand is the OUTPUT OF A WHOLE ResBlock, in_act(xf * in_scale + in_shift + r) with r the block's
+// skip path -- its input activation `res` (identity skip) or res * res_scale + res_shift (the raw 1x1 skip
+// convolution with its BatchNorm), network_builder.py:138-145 -- formed with the roundings of k_bn_apply3; the
+// workgroups of the first column tile also write it to act_out (float32) for their own 256 pixels: the next block's
+// skip path and nothing else reads it, so the block output costs one write and no pass of its own.
+template <bool RAW, int NJ, bool RES = false>
 __global__ void __launch_bounds__(kT3)
 k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const float *__restrict__ xf,
-             const float *__restrict__ in_scale, const float *__restrict__ in_shift, int in_act, int bn_games, int cap, int C, int H,
+             const float *__restrict__ in_scale, const float *__restrict__ in_shift, const float *__restrict__ res,
+             const float *__restrict__ res_scale, const float *__restrict__ res_shift, float *__restrict__ act_out, int in_act,
+             int bn_games, int cap, int C, int H,
              int W, int ksize, const unsigned short *__restrict__ w3, long long w_plane, int K,
              const float *__restrict__ bias, int act, float *__restrict__ y, unsigned short *__restrict__ y3,
              long long y_plane, int rows, int N, double *__restrict__ sums) {
@@ -311,12 +318,17 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
             const int g = min(g_first + i / C, G - 1), c = i % C;
             s_bn[i] = in_scale[(long long)g * C + c];
             s_bn[bn_games * C + i] = in_shift[(long long)g * C + c];
+            if (RES && res_scale) {
+                s_bn[2 * bn_games * C + i] = res_scale[(long long)g * C + c];
+                s_bn[3 * bn_games * C + i] = res_shift[(long long)g * C + c];
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) gl[j] = min(max(m0 - reach + hs + 128 * j, 0) / P - g_first, bn_games - 1);
     }
     constexpr int kGH = RAW ? 2 * NJ : 3 * NJ;
     u32x4 gh[kGH], gb[3];
+    u32x4 gr[RES ? 2 * NJ : 1];
     auto fetch_halo = [&](int chunk) {
         const int c0 = chunk * kTK + pc * 8;
 #pragma unroll
@@ -326,8 +338,10 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
             const bool ok = slot < nslots && pix >= 0 && pix < rows;
             if constexpr (RAW) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2; ++q) {
                     gh[j * 2 + q] = ok ? *reinterpret_cast<const u32x4 *>(xf + pix * C + c0 + 4 * q) : u32x4{0u, 0u, 0u, 0u};
+                    if constexpr (RES) gr[j * 2 + q] = ok ? *reinterpret_cast<const u32x4 *>(res + pix * C + c0 + 4 * q) : u32x4{0u, 0u, 0u, 0u};
+                }
             } else {
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
@@ -350,7 +364,25 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 x4 = __builtin_bit_cast(f32x4, gh[j * 2 + q]);
                     f32x4 v4 = x4;
-                    if (in_scale) {  // uniform
+                    if constexpr (RES) {
+                        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
+                        const f32x4 r4 = __builtin_bit_cast(f32x4, gr[j * 2 + q]);
+                        f32x4 add = r4;
+                        if (res_scale) {  // uniform
+                            const float *rs = sc + 2 * bn_games * C, *rh = sc + 3 * bn_games * C;
+                            const f32x4 rs4 = *reinterpret_cast<const f32x4 *>(rs + 4 * q), rh4 = *reinterpret_cast<const f32x4 *>(rh + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) add[e] = fmaf(r4[e], rs4[e], rh4[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = fmaf(x4[e], sc4[e], sh4[e]);  // the roundings of k_bn_apply3
+                            v += add[e];
+                            v4[e] = act3(v, in_act);
+                        }
+                        if (act_out && blockIdx.x == 0 && ok && slot >= reach && slot < reach + kTM)
+                            *reinterpret_cast<f32x4 *>(act_out + pix * C + c0 + 4 * q) = v4;
+                    } else if (in_scale) {  // uniform
                         const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v4[e] = act3(fmaf(x4[e], sc4[e], sh4[e]), in_act);
@@ -646,7 +678,7 @@ int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32
 // range can touch, LDS bytes.  Returns NULL when the kernel takes the shape, else why not.
 struct SameShape { int nj, cap, bn_games; size_t lds; };
 static const char *same_shape(int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, int32_t N, bool raw, bool with_bn,
-                              SameShape &s) {
+                              SameShape &s, bool with_res = false, bool with_res_bn = false) {
     if (G <= 0 || H <= 0 || W <= 0) return "non-positive size";
     if (ksize < 1 || (ksize & 1) == 0 || ksize > 3) return "kernel size must be 1 or 3 (others use mz_conv3_forward)";
     if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
@@ -658,7 +690,8 @@ static const char *same_shape(int32_t C, int32_t G, int32_t H, int32_t W, int32_
     s.cap = s.nj == 3 ? kHaloSlots : (nslots + 3) & ~3;
     // games a staged range can touch: it holds 256 + 2 * reach consecutive pixels
     s.bn_games = with_bn ? (int)std::min<long long>(G, (nslots - 2) / ((long long)H * W) + 2) : 0;
-    const size_t need = same_lds(s.cap, s.bn_games, C);
+    if (with_res && (!with_bn || s.nj != 3)) return "the residual form needs the BatchNorm rows and an image width of at most 63";
+    const size_t need = same_lds(s.cap, s.bn_games * (with_res_bn ? 2 : 1), C);
     s.lds = std::max<size_t>(need, kOutLds);
     if (need > (size_t)kMaxLds) return "the staged range and the scale / shift rows do not fit in LDS (apply the BatchNorm with mz_bn_apply3 first)";
     return nullptr;
@@ -667,13 +700,15 @@ static const char *same_shape(int32_t C, int32_t G, int32_t H, int32_t W, int32_
 static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plane, const float *xf, const float *in_scale,
                              const float *in_shift, int32_t in_act, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,
                              const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
-                             int64_t y_plane, int32_t N, double *block_sums, void *stream) {
+                             int64_t y_plane, int32_t N, double *block_sums, void *stream, const float *res = nullptr,
+                             const float *res_scale = nullptr, const float *res_shift = nullptr, float *act_out = nullptr) {
     const bool raw = xf != nullptr;
     if ((!x3 && !xf) || !w3 || (!y && !y3))
         return mz::fail(MZ_ERR_ARG, "%s: NULL argument", who);
     if (raw && in_scale && !in_shift) return mz::fail(MZ_ERR_ARG, "%s: the input shift is NULL", who);
     SameShape shp{};
-    if (const char *why = same_shape(C, G, H, W, ksize, N, raw, raw && in_scale, shp))
+    if (res_scale && !res_shift) return mz::fail(MZ_ERR_ARG, "%s: the residual's shift is NULL", who);
+    if (const char *why = same_shape(C, G, H, W, ksize, N, raw, raw && in_scale, shp, res != nullptr, res_scale != nullptr))
         return mz::fail(MZ_ERR_ARG, "%s: %s (C %d, N %d, G %d, H %d, W %d, kernel %d)", who, why, C, N, G, H, W, ksize);
     if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID || (raw && (in_act < MZ_ACT_NONE || in_act > MZ_ACT_SIGMOID)))
         return mz::fail(MZ_ERR_ARG, "%s: activation is not element-wise", who);
@@ -683,18 +718,20 @@ static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plan
     if (w_plane < K * N || (!raw && x_plane < rows * C) || (y3 && y_plane < rows * N))
         return mz::fail(MZ_ERR_ARG, "%s: plane strides too small", who);
     if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(w3) |
-         reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y3)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
+         reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y3) | reinterpret_cast<uintptr_t>(res) |
+         reinterpret_cast<uintptr_t>(act_out)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
         return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
     auto launch = [&](auto kernel) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "%s: cannot enable %zu bytes of LDS: %s", who, shp.lds, hipGetErrorString(e));
         const dim3 grid(N / kTN, (unsigned)((rows + kTM - 1) / kTM));
-        hipLaunchKernelGGL(kernel, grid, dim3(kT3), shp.lds, (hipStream_t)stream, x3, (long long)x_plane, xf, in_scale, in_shift, in_act,
-                           shp.bn_games, shp.cap, C, H, W, ksize, w3, (long long)w_plane, (int)K, bias, activation, y, y3,
+        hipLaunchKernelGGL(kernel, grid, dim3(kT3), shp.lds, (hipStream_t)stream, x3, (long long)x_plane, xf, in_scale, in_shift, res,
+                           res_scale, res_shift, act_out, in_act, shp.bn_games, shp.cap, C, H, W, ksize, w3, (long long)w_plane, (int)K, bias, activation, y, y3,
                            (long long)y_plane, (int)rows, N, block_sums);
         return mz::check_launch("k_conv3_same");
     };
     if (!raw) return launch(k_conv3_same<false, 3>);
+    if (res) return launch(k_conv3_same<true, 3, true>);
     switch (shp.nj) {
         case 3: return launch(k_conv3_same<true, 3>);
         case 4: return launch(k_conv3_same<true, 4>);
@@ -704,7 +741,18 @@ static int conv3_same_launch(const char *who, const uint16_t *x3, int64_t x_plan
 
 int mz_conv3_same_fits(int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, int32_t N, int32_t raw, int32_t with_bn) {
     SameShape shp{};
-    return same_shape(C, G, H, W, ksize, N, raw != 0, raw != 0 && with_bn != 0, shp) == nullptr ? 1 : 0;
+    return same_shape(C, G, H, W, ksize, N, raw != 0, raw != 0 && with_bn != 0, shp, with_bn >= 2, with_bn >= 3) == nullptr ? 1 : 0;
+}
+
+int mz_conv3_same_block_forward(const float *x, const float *in_scale, const float *in_shift, const float *residual,
+                                const float *res_scale, const float *res_shift, int32_t in_activation, float *block_out,
+                                int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize, const uint16_t *w3, int64_t w_plane,
+                                const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N,
+                                double *block_sums, void *stream) {
+    if (!x || !in_scale || !in_shift || !residual)
+        return mz::fail(MZ_ERR_ARG, "mz_conv3_same_block_forward: x, its scale / shift and the residual are required");
+    return conv3_same_launch("mz_conv3_same_block_forward", nullptr, 0, x, in_scale, in_shift, in_activation, C, G, H, W, ksize, w3,
+                             w_plane, bias, activation, y, y3, y_plane, N, block_sums, stream, residual, res_scale, res_shift, block_out);
 }
 
 int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W, int32_t ksize,

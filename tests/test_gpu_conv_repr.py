@@ -419,10 +419,25 @@ def test_fused_forms_reproduce_the_separate_kernels_bit_for_bit():
     no_bn = ConvRepresentation(h, fused_input_bn=False)(x).clone()
     no_range = ConvRepresentation(h, fused_input_bn=False, staged_range=False)(x).clone()
     no_sums = ConvRepresentation(h, fused_statistics=False)(x).clone()
+    no_block = ConvRepresentation(h, fused_block_output=False)(x).clone()
     torch.cuda.synchronize()
     assert torch.equal(full, no_bn)
     assert torch.equal(no_bn, no_range)
+    assert torch.equal(full, no_block)
     np.testing.assert_allclose(full.cpu().numpy(), no_sums.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(full.abs().max()))
+    # a block's bn2 + skip sum + activation formed while the next block's conv1 stages its input: identity skips and
+    # skips through a 1x1 convolution with its own BatchNorm, three blocks in a row, relu and tanh
+    for acts in (("relu", "relu", "relu"), ("tanh", "relu", "sigmoid")):
+        h2 = _net((3, 12, 12), (128, 3, 3), 5, [_cv(64, 2, 2, 0), _rb(128, act=acts[0]), _rb(128, act=acts[1]), _rb(256, act=acts[2]),
+                                                _rb(256, act=acts[0])], [])
+        x2 = torch.rand(7, 3 * 5 + 5, 12, 12).cuda()
+        run = ConvRepresentation(h2)
+        fused = run(x2).clone()
+        plain = ConvRepresentation(h2, fused_block_output=False)(x2).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(fused, plain), acts
+        want64, _ = _per_game(h2, x2.cpu(), torch.float64)
+        _close(fused, want64)
 
 
 def test_staged_convolution_applies_the_previous_batchnorm_bit_for_bit():
