@@ -327,7 +327,7 @@ def main():
                     help="keep every node's latent in the pool (the drop-in MCTS.run's form) instead of one merge row per "
                          "expansion (self-play's form; bit-identical trees)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--selfplay-moves", type=int, default=8, help="timed self-play moves per game (0 = skip)")
+    ap.add_argument("--selfplay-moves", type=int, default=16, help="timed self-play moves per game (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="after the K timed steps, keep stepping for this long (a sustained-rate figure; longer than a "
                          "5-second utilisation sampler's period)")
@@ -421,17 +421,21 @@ def main():
         # restart of finished games, for G games per GPU; the per-move Dirichlet, child-choice and
         # exploration streams are drawn on the device
         from muzero_amd.selfplay import SelfPlayEngine
-        sp = SelfPlayEngine(h, g, f, G, cfg.training_data_generator, device=dev, seed=rank, device_rng=True)
-        for _ in range(2):
-            sp.move()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.selfplay_moves):
-            sp.move()
-        fence()
-        dts = sharding.max_over_ranks(time.perf_counter() - t0, dist, dev)
-        line["selfplay_env_steps_per_sec"] = world * G * args.selfplay_moves / dts
-        line["selfplay_ms_per_move"] = dts / args.selfplay_moves * 1e3
+        for graphed in (False, True):
+            # launch by launch (some twenty-five launches per move), then the whole move replayed from one HIP graph
+            sp = SelfPlayEngine(h, g, f, G, cfg.training_data_generator, device=dev, seed=rank, device_rng=True, graph_moves=graphed)
+            for _ in range(4):
+                sp.move()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.selfplay_moves):
+                sp.move()
+            fence()
+            dts = sharding.max_over_ranks(time.perf_counter() - t0, dist, dev)
+            key = "" if graphed else "_launch_by_launch"
+            line["selfplay_env_steps_per_sec" + key] = world * G * args.selfplay_moves / dts
+            line["selfplay_ms_per_move" + key] = dts / args.selfplay_moves * 1e3
+            del sp
     if rank == 0 and not args.no_roofline:
         stored = mcts if args.store_latents else BatchedMCTS(nets, G, S, 1, discount=0.998, noise_frac=0.25, device=dev,
                                                              keep_latents=True)

@@ -186,7 +186,7 @@ def episodes_from_records(rec, G: int):
 class SelfPlayEngine:
     def __init__(self, repr_net, dyn_net, pred_net, G: int, config, device="cuda", seed: int = 0,
                  device_rng: bool = False, env=None, track_running_stats: bool = False, root_form: bool = True,
-                 share: "SelfPlayEngine | None" = None):
+                 share: "SelfPlayEngine | None" = None, graph_moves: bool = False):
         """`config`: TrainingDataGeneratorConfig (mcts settings, epsilon schedule, max steps).
         `env`: a batched environment (`observe`, `step`, `reset(mask)`, `num_actions`,
         `observation_space`); default: G Connect-Four games on the GPU.  Host-side simulators go
@@ -207,6 +207,11 @@ class SelfPlayEngine:
         network outputs agree with the reference-ordered float32 evaluation to 1e-5 of their scale, a bound
         and not bit parity: a selection or a greedy action that two candidates tie for to that precision
         may fall the other way.  False keeps the roots as full latents through the plain kernels.
+
+        `graph_moves` (device environment, device_rng, single-launch search only): after two ordinary moves the whole
+        move -- random draws, observation, history, h, search, action pick, environment step, restarts, some twenty-five
+        launches of which all but the search take a few microseconds -- is recorded as one HIP graph and replayed;
+        `move` then returns the graph's own output tensors, valid until the next move (`generate` copies them).
 
         `share`: another engine over the same three modules whose device copies of the weights (h runner,
         packed g / f) this one uses instead of packing its own; the two must issue their device work on the
@@ -235,6 +240,12 @@ class SelfPlayEngine:
         self.step_in_episode = torch.zeros(G, dtype=torch.int32, device=dev)
         self.action = torch.zeros(G, dtype=torch.int32, device=dev)
         self.env.reset()
+        self.graph_moves = bool(graph_moves)
+        if self.graph_moves and not (device_rng and env is None and getattr(self.nets, "fusable", True)):
+            raise ValueError("graph_moves needs the device environment, device_rng=True and networks the single-launch search covers")
+        self._move_graph = self._move_out = self._move_seen = None
+        self._moves_played = 0
+        self._eps = torch.zeros((), dtype=torch.float32, device=dev)
 
     @property
     def rng(self):
@@ -284,7 +295,32 @@ class SelfPlayEngine:
     def move(self, training_steps: int = 0):
         """One move of every game.  Returns device tensors (obs, policy32, value, action, reward,
         done) for this move; games that ended (or hit max_steps_per_episode) restart."""
-        obs, res = self.launch(self.streams.draw(self.epsilon(training_steps)))
+        if self.graph_moves:
+            return self._move_replayed(self.epsilon(training_steps))
+        return self._move(self.epsilon(training_steps))
+
+    def _move_replayed(self, eps: float):
+        self.h.refresh()
+        seen = (getattr(self.nets, "version", 0), self.h._seen)
+        if self._move_graph is not None and seen == self._move_seen:
+            self._eps.fill_(eps)
+            self._move_graph.replay()
+            return self._move_out
+        self._move_graph = None
+        self._eps.fill_(eps)
+        out = self._move(self._eps)  # an ordinary move (lazy set-up of every component happens in the first ones)
+        self._moves_played += 1
+        if self._moves_played >= 2:
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            graph.register_generator_state(self.streams.gen)
+            with torch.cuda.graph(graph):
+                self._move_out = self._move(self._eps)  # recorded, not executed: the games stay where they are
+            self._move_graph, self._move_seen = graph, seen
+        return out
+
+    def _move(self, eps):
+        obs, res = self.launch(self.streams.draw(eps))
         reward, done = self.env.step(self.action)
         self.step_in_episode += 1
         ended = (done.bool() | (self.step_in_episode >= self.cfg.max_steps_per_episode)).to(torch.int8)
@@ -296,7 +332,10 @@ class SelfPlayEngine:
     def generate(self, num_moves: int, training_steps: int = 0):
         """Plays `num_moves` lock-step moves and returns the finished episodes as lists of Chunk
         (states on the CPU), in the reference's Episode/Chunk format."""
-        rec = [self.move(training_steps) for _ in range(num_moves)]
+        rec = []
+        for _ in range(num_moves):
+            out = self.move(training_steps)
+            rec.append(tuple(t.clone() for t in out) if self.graph_moves else out)
         if getattr(self.h, "track_running_stats", False):
             self.sync_running_stats()  # training advances the same buffers next (src/training.py runs the modules in train mode)
         return episodes_from_records(rec, self.G)

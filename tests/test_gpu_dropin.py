@@ -210,6 +210,36 @@ def test_batched_selfplay_engine_produces_valid_episodes(device_rng):
             assert d == (i == len(ep.chunks) - 1)
 
 
+def test_selfplay_moves_replayed_from_one_graph_play_the_same_games():
+    """graph_moves: after two ordinary moves every move (random draws, observation, history, h, search, action pick,
+    environment step, restarts) is one graph replay.  With one seed the engine plays the games the ordinary engine
+    plays: the graph-safe generator hands the recorded draws the offsets the ordinary calls would have used."""
+    from muzero_amd.config import MCTSConfig, TrainingDataGeneratorConfig
+    from muzero_amd.selfplay import SelfPlayEngine
+    from tests.test_gpu_nets import _c4_nets
+    h, g, f = _c4_nets(0)
+    cfg = TrainingDataGeneratorConfig(
+        num_episodes=1, max_steps_per_episode=42, total_time=0, epsilon=0.5, epsilon_decay=0.9, min_epsilon=0.25,
+        mcts=MCTSConfig(selection_strategy="puct", max_iterations=8, max_time=0, model_look_ahead=1,
+                        discount_factor=0.998, dirichlet_alpha=0.3, noise_frac=0.25))
+    G = 64
+    plain = SelfPlayEngine(h, g, f, G, cfg, seed=11, device_rng=True)
+    replayed = SelfPlayEngine(h, g, f, G, cfg, seed=11, device_rng=True, graph_moves=True)
+    for t in range(12):
+        a = plain.move(training_steps=t)
+        b = replayed.move(training_steps=t)   # epsilon changes from move to move: it is an input of the graph
+        torch.cuda.synchronize()
+        for x, y, name in zip(a, b, ("obs", "policy32", "value", "action", "reward", "ended")):
+            assert torch.equal(x, y), (t, name)
+    assert replayed._move_graph is not None
+    want, got = plain.generate(num_moves=20), replayed.generate(num_moves=20)
+    assert len(want) == len(got) > 0
+    for ea, eb in zip(want, got):
+        assert len(ea.chunks) == len(eb.chunks)
+        assert all(torch.equal(ca.state, cb.state) and torch.equal(ca.policy, cb.policy) and ca.best_action == cb.best_action
+                   for ca, cb in zip(ea.chunks, eb.chunks))
+
+
 def test_actor_store_learner_loop_on_device():
     """Self-play -> device episode store -> batched learner step -> re-packed weights, all on
     the GPU: windows come out of the store in tensor form (z-targets by the HIP kernel), one

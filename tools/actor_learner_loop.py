@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--tune-gemms", action="store_true",
                     help="torch times the BLAS solutions for the learner's matrix products once (untimed warm-up) "
                          "and keeps the fastest (muzero_amd.learner.tune_small_gemms)")
+    ap.add_argument("--no-move-graph", action="store_true", help="issue every self-play move launch by launch")
     ap.add_argument("--prioritized", action="store_true",
                     help="episodes drawn by priority (alpha 0.6, beta 1.0, src/replay_buffer.py:11-39 defaults), "
                          "priorities updated from the per-window loss; default: uniform")
@@ -57,7 +58,7 @@ def main():
     cfg, h, g, f = bench.build_networks()  # identical seed-0 weights on every rank
     h, g, f = h.to(dev), g.to(dev), f.to(dev)
     tcfg, gcfg = cfg.training, cfg.training_data_generator
-    eng = SelfPlayEngine(h, g, f, args.games, gcfg, device=dev, seed=shard.rank, device_rng=True)
+    eng = SelfPlayEngine(h, g, f, args.games, gcfg, device=dev, seed=shard.rank, device_rng=True, graph_moves=not args.no_move_graph)
     store = DeviceEpisodeStore(args.games, gcfg.max_steps_per_episode, (2, 6, 7), 7, capacity=4 * args.games, device=dev)
     params = [p for n in (h, g, f) for p in n.parameters()]
     opt = torch.optim.Adam(params, lr=tcfg.learning_rate, betas=tuple(tcfg.betas), weight_decay=tcfg.weight_decay,
