@@ -315,7 +315,7 @@ def test_ragged_and_minimal_batches(G, S, depth):
 
 
 @pytest.mark.parametrize("which,G,S,depth", [("c4", 100, 50, 1), ("c4", 4100, 6, 2), ("tiny", 33, 25, 2), ("odd", 21, 12, 1),
-                                             ("wide", 19, 6, 0)])
+                                             ("wide", 19, 6, 0), ("mid", 40, 20, 1)])
 def test_implicit_child_latents_leave_identical_trees(which, G, S, depth):
     """keep_latents=False (one merge pre-activation row per expansion instead of A child latents; a leaf's
     latent is formed from its parent's row when it is expanded, src/search/expansion.py:25-33): every tree
@@ -331,6 +331,9 @@ def test_implicit_child_latents_leave_identical_trees(which, G, S, depth):
     elif which == "odd":
         g, f = _custom_nets((1, 1, 8), 3, [], [33], [17, 9, 40], ("tanh", "sigmoid", "relu"))
         latent_shape = (1, 1, 8)
+    elif which == "mid":   # the sequential-program kernel's second instantiation: 64-wide latents, 128-wide heads
+        g, f = _custom_nets((4, 4, 4), 5, [128], [128, 128], [128, 128], ("relu",))
+        latent_shape = (4, 4, 4)
     else:
         g, f = _custom_nets((2, 4, 4), 18, [24, 12], [8], [24], ("relu",))
         latent_shape = (2, 4, 4)
