@@ -421,6 +421,12 @@ int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *
 int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps,
                      const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y,
                      uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N, double *block_sums, void *stream);
+/* mz_conv3_forward on float32 input rows x[input pixels][C], split while they are staged: 4 bytes per value instead
+ * of the planes' 6 and whole 128-byte lines per gathered chunk (the strided ConvLayers, network_builder.py:33-60,
+ * whose input nothing else reads in split form).  Identical bits to mz_split3 + mz_conv3_forward. */
+int mz_conv3_forward_f32(const float *x, int32_t C, const int32_t *idx, int32_t taps, const uint16_t *w3, int64_t w_plane,
+                         const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t rows,
+                         int32_t N, double *block_sums, void *stream);
 int mz_conv3_same_forward(const uint16_t *x3, int64_t x_plane, int32_t C, int32_t G, int32_t H, int32_t W,
                           int32_t ksize, const uint16_t *w3, int64_t w_plane, const float *bias,
                           int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t N, double *block_sums,

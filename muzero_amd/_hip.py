@@ -164,6 +164,8 @@ _SIGS = {
     "mz_unsplit3": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "mz_conv3_forward": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
                                    C.c_int32, C.c_int32, _P, _P]),
+    "mz_conv3_forward_f32": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
+                                       C.c_int32, C.c_int32, _P, _P]),
     "mz_conv3_same_fits": (C.c_int, [C.c_int32] * 8),
     "mz_conv3_same_block_forward": (C.c_int, [_P] * 6 + [C.c_int32, _P] + [C.c_int32] * 5 + [_P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64,
                                                C.c_int32, _P, _P]),

@@ -104,8 +104,11 @@ class _Bn:
 class ConvRepresentation:
     def __init__(self, repr_net: torch.nn.Module, device="cuda", track_running_stats: bool = False,
                  fast_convolutions: bool = True, staged_range: bool = True, fused_statistics: bool = True,
-                 fused_input_bn: bool = True, fused_block_output: bool = True):
+                 fused_input_bn: bool = True, fused_block_output: bool = True, f32_gather: bool = True):
         self.src = repr_net
+        # the strided convolutions gather float32 rows and split them while staging (mz_conv3_forward_f32): their
+        # producers then write 4 bytes per value instead of three bf16 planes; identical bits either way
+        self.f32_gather = f32_gather
         self.fused_input_bn = fused_input_bn
         # a ResBlock's bn2 + skip sum + activation applied while the NEXT block's conv1 stages its input (which also
         # writes the block output once, for that block's own skip path) instead of a pass of its own
@@ -305,7 +308,7 @@ class ConvRepresentation:
             if block is None and pre is None and a.f is not None and self._staged(cv, G, H, W) and \
                     (a.s is None or not self._staged(cv, G, H, W, raw=False)):
                 pre = (None, None, 0)   # a float32 activation is split while it is staged
-            x3 = self._s3(a, name + "_in") if pre is None and block is None else None
+            x3 = None
             if split_out:
                 out.s = self._buf(name + "_s", (3, n_out), torch.int16)
             else:
@@ -324,13 +327,20 @@ class ConvRepresentation:
                                                         cv.w3.shape[1], ptr(cv.bias), cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout,
                                                         ptr(out.sums), _stream()), "mz_conv3_same_bn_forward")
                 return out, Ho, Wo
-            if self._staged(cv, G, H, W, raw=False):
+            if not (self.f32_gather and a.f is not None and a.s is None):
+                x3 = self._s3(a, name + "_in")
+            if x3 is not None and self._staged(cv, G, H, W, raw=False):
                 # the taps of a stride-1 "same" convolution read one contiguous pixel range per tile
                 _hip.check(lib.mz_conv3_same_forward(ptr(x3), a.n, cv.cin, G, H, W, cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
                                                      cv.act, ptr(out.f), ptr(out.s), n_out, cv.cout, ptr(out.sums), _stream()),
                            "mz_conv3_same_forward")
                 return out, Ho, Wo
             idx = self._index_table(G, H, W, cv, Ho, Wo)
+            if x3 is None:
+                _hip.check(lib.mz_conv3_forward_f32(ptr(a.f), cv.cin, ptr(idx), cv.k * cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
+                                                    cv.act, ptr(out.f), ptr(out.s), n_out, rows, cv.cout, ptr(out.sums), _stream()),
+                           "mz_conv3_forward_f32")
+                return out, Ho, Wo
             _hip.check(lib.mz_conv3_forward(ptr(x3), a.n, cv.cin, ptr(idx), cv.k * cv.k, ptr(cv.w3), cv.w3.shape[1], ptr(cv.bias),
                                             cv.act, ptr(out.f), ptr(out.s), n_out, rows, cv.cout, ptr(out.sums), _stream()),
                        "mz_conv3_forward")
@@ -398,6 +408,8 @@ class ConvRepresentation:
         if si + 1 >= len(self.steps):
             return False
         nxt = self.steps[si + 1]
+        if self.f32_gather:
+            return False   # every split-product kernel reads float32 rows and splits them while staging
         first = nxt[1] if nxt[0] in ("conv", "block") else None
         # the staged-range kernel splits a float32 activation on the fly; the gathering one reads planes
         return first is not None and first.fast and not (self.staged_range and first.stride == 1 and first.k in (1, 3)

@@ -143,8 +143,11 @@ __device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], unsigne
     }
 }
 
+// RAW: the input is float32 rows xf[pixel][C] (4 bytes per value instead of the planes' 6, and a row's 32-channel
+// chunk is one whole 128-byte line instead of three 64-byte pieces); it is split while it is staged.
+template <bool RAW>
 __global__ void __launch_bounds__(kT3)
-k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const int32_t *__restrict__ idx, int taps,
+k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *__restrict__ xf, int C, const int32_t *__restrict__ idx, int taps,
         const unsigned short *__restrict__ w3, long long w_plane, int K, const float *__restrict__ bias, int act,
         float *__restrict__ y, unsigned short *__restrict__ y3, long long y_plane, int rows, int N,
         double *__restrict__ sums) {
@@ -174,12 +177,19 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
         srow[0] = s_idx[tap * kTM + ra];
         srow[1] = s_idx[tap * kTM + ra + 128];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (RAW) {
+                const float *src = xf + (long long)max(srow[h], 0) * C + c0;
+                ga[h * 2] = *reinterpret_cast<const u32x4 *>(src);
+                ga[h * 2 + 1] = *reinterpret_cast<const u32x4 *>(src + 4);
+            } else {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const unsigned short *src = x3 + p * x_plane + (long long)max(srow[h], 0) * C + c0;
-                ga[h * 3 + p] = *reinterpret_cast<const u32x4 *>(src);
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned short *src = x3 + p * x_plane + (long long)max(srow[h], 0) * C + c0;
+                    ga[h * 3 + p] = *reinterpret_cast<const u32x4 *>(src);
+                }
             }
+        }
         const int kk = tap * C + c0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
@@ -187,13 +197,33 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, int C, const i
     auto stash = [&](int stage) {
         unsigned char *base = lds + stage * kStage;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (RAW) {
+                unsigned int pl[3][4];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                u32x4 v = ga[h * 3 + p];
-                if (srow[h] < 0) v = u32x4{0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4 *>(base + p * (kTM * kARow) + lds_off(ra + 128 * h, pc)) = v;
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 v4 = __builtin_bit_cast(f32x4, ga[h * 2 + q]);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        unsigned short lo[3], hi[3];
+                        split3(v4[e], lo[0], lo[1], lo[2]);
+                        split3(v4[e + 1], hi[0], hi[1], hi[2]);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) pl[p][q * 2 + (e >> 1)] = srow[h] < 0 ? 0u : ((unsigned int)lo[p] | ((unsigned int)hi[p] << 16));
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4 *>(base + p * (kTM * kARow) + lds_off(ra + 128 * h, pc)) = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    u32x4 v = ga[h * 3 + p];
+                    if (srow[h] < 0) v = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4 *>(base + p * (kTM * kARow) + lds_off(ra + 128 * h, pc)) = v;
+                }
             }
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(base + kAStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
     };
@@ -644,34 +674,51 @@ int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *
     return mz::check_launch("k_unsplit3");
 }
 
+static int conv3_launch(const char *who, const uint16_t *x3, int64_t x_plane, const float *xf, int32_t C, const int32_t *idx, int32_t taps,
+                        const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3,
+                        int64_t y_plane, int32_t rows, int32_t N, double *block_sums, void *stream) {
+    if ((!x3 && !xf) || !idx || !w3 || (!y && !y3) || rows <= 0 || taps <= 0)
+        return mz::fail(MZ_ERR_ARG, "%s: NULL argument or non-positive size", who);
+    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
+        return mz::fail(MZ_ERR_ARG, "%s: input channels (%d) must be a multiple of 64 and output channels (%d) "
+                        "a multiple of %d (other layers use mz_wide_forward_gather / mz_conv_direct_nhwc)", who, C, N, kTN);
+    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID)
+        return mz::fail(MZ_ERR_ARG, "%s: activation %d is not element-wise", who, activation);
+    const long long K = (long long)taps * C;
+    if (w_plane < K * N || (!xf && x_plane <= 0) || (y3 && y_plane < (long long)rows * N) || K > 0x7fffffffLL)
+        return mz::fail(MZ_ERR_ARG, "%s: plane strides too small", who);
+    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(xf) | reinterpret_cast<uintptr_t>(w3) |
+         reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y3)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
+        return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
+    if (taps > 16) return mz::fail(MZ_ERR_ARG, "%s: at most 16 taps (kernel size up to 4)", who);
+    if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "%s: block sums need a multiple of 64 rows", who);
+    const size_t lds = 2 * (size_t)kStage + (size_t)taps * kTM * sizeof(int);
+    auto launch = [&](auto kernel) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(2 * (size_t)kStage + 16 * kTM * sizeof(int)));
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_conv3: cannot enable %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        const dim3 grid(N / kTN, (rows + kTM - 1) / kTM);
+        hipLaunchKernelGGL(kernel, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, xf, C, idx, taps, w3,
+                           (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, rows, N, block_sums);
+        return mz::check_launch("k_conv3");
+    };
+    return xf ? launch(k_conv3<true>) : launch(k_conv3<false>);
+}
+
 int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps, const uint16_t *w3,
                      int64_t w_plane, const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane,
                      int32_t rows, int32_t N, double *block_sums, void *stream) {
-    if (!x3 || !idx || !w3 || (!y && !y3) || rows <= 0 || taps <= 0)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: NULL argument or non-positive size");
-    if (C <= 0 || C % 64 != 0 || N <= 0 || N % kTN != 0)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: input channels (%d) must be a multiple of 64 and output channels (%d) "
-                        "a multiple of %d (other layers use mz_wide_forward_gather / mz_conv_direct_nhwc)", C, N, kTN);
-    if (activation < MZ_ACT_NONE || activation > MZ_ACT_SIGMOID)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: activation %d is not element-wise", activation);
-    const long long K = (long long)taps * C;
-    if (w_plane < K * N || x_plane <= 0 || (y3 && y_plane < (long long)rows * N) || K > 0x7fffffffLL)
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: plane strides too small");
-    if ((reinterpret_cast<uintptr_t>(x3) | reinterpret_cast<uintptr_t>(w3) | reinterpret_cast<uintptr_t>(y) |
-         reinterpret_cast<uintptr_t>(y3)) & 15 || (x_plane & 7) || (w_plane & 7) || (y_plane & 7))
-        return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: operands must be 16-byte aligned");
-    if (taps > 16) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: at most 16 taps (kernel size up to 4)");
-    if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: block sums need a multiple of 64 rows");
-    const size_t lds = 2 * (size_t)kStage + (size_t)taps * kTM * sizeof(int);
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(2 * (size_t)kStage + 16 * kTM * sizeof(int)));
-        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_conv3: cannot enable %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    }
-    const dim3 grid(N / kTN, (rows + kTM - 1) / kTM);
-    hipLaunchKernelGGL(k_conv3, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, C, idx, taps, w3,
-                       (long long)w_plane, (int)K, bias, activation, y, y3, (long long)y_plane, rows, N, block_sums);
-    return mz::check_launch("k_conv3");
+    if (!x3) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward: x3 is NULL");
+    return conv3_launch("mz_conv3_forward", x3, x_plane, nullptr, C, idx, taps, w3, w_plane, bias, activation, y, y3, y_plane, rows, N,
+                        block_sums, stream);
+}
+
+int mz_conv3_forward_f32(const float *x, int32_t C, const int32_t *idx, int32_t taps, const uint16_t *w3, int64_t w_plane,
+                         const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N,
+                         double *block_sums, void *stream) {
+    if (!x) return mz::fail(MZ_ERR_ARG, "mz_conv3_forward_f32: x is NULL");
+    return conv3_launch("mz_conv3_forward_f32", nullptr, 0, x, C, idx, taps, w3, w_plane, bias, activation, y, y3, y_plane, rows, N,
+                        block_sums, stream);
 }
 
 // Shape of a staged-range launch: groups of 128 slots, slots of the LDS image, games whose scale / shift rows a

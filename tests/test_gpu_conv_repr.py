@@ -420,10 +420,13 @@ def test_fused_forms_reproduce_the_separate_kernels_bit_for_bit():
     no_range = ConvRepresentation(h, fused_input_bn=False, staged_range=False)(x).clone()
     no_sums = ConvRepresentation(h, fused_statistics=False)(x).clone()
     no_block = ConvRepresentation(h, fused_block_output=False)(x).clone()
+    planes = ConvRepresentation(h, f32_gather=False)(x).clone()      # strided layers gathering from split planes
+    planes_all = ConvRepresentation(h, f32_gather=False, staged_range=False, fused_input_bn=False)(x).clone()
     torch.cuda.synchronize()
     assert torch.equal(full, no_bn)
     assert torch.equal(no_bn, no_range)
     assert torch.equal(full, no_block)
+    assert torch.equal(full, planes) and torch.equal(full, planes_all)
     np.testing.assert_allclose(full.cpu().numpy(), no_sums.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(full.abs().max()))
     # a block's bn2 + skip sum + activation formed while the next block's conv1 stages its input: identity skips and
     # skips through a 1x1 convolution with its own BatchNorm, three blocks in a row, relu and tanh
