@@ -71,6 +71,27 @@ k_transpose(const float *__restrict__ in, float *__restrict__ out, int R, int Cc
     }
 }
 
+// The same through a 64 x 64 tile: 256-byte runs on both sides (the network input of h, [G][128][H*W]: 32-float
+// runs leave a third of the memory rate unused).
+__global__ void __launch_bounds__(kCT)
+k_transpose64(const float *__restrict__ in, float *__restrict__ out, int R, int Cc) {
+    __shared__ float tile[64][65];
+    const long long img = blockIdx.z;
+    const float *src = in + img * (long long)R * Cc;
+    float *dst = out + img * (long long)R * Cc;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    for (int j = ty; j < 64; j += 4) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < Cc) ? src[(long long)r * Cc + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < Cc && r < R) dst[(long long)c * R + r] = tile[tx][j];
+    }
+}
+
 // Per (game, channel): mean and biased variance over the P positions (float64 sums), folded with the
 // BatchNorm affine parameters: scale = w / sqrt(var + eps), shift = b - mean * scale.
 // x [G][P][C].  One workgroup per (game, 64 channels); 4 position groups x 64 channels.
@@ -249,6 +270,10 @@ int mz_conv_index(int32_t *idx, int32_t G, int32_t H, int32_t W, int32_t KS, int
 
 int mz_nchw_to_nhwc(const float *x, int32_t G, int32_t C, int32_t P, float *y, void *stream) {
     if (!x || !y || G <= 0 || C <= 0 || P <= 0) return mz::fail(MZ_ERR_ARG, "mz_nchw_to_nhwc: NULL or non-positive argument");
+    if (C >= 64 && P >= 64 && (C + 63) / 64 <= 65535 && G <= 65535) {
+        hipLaunchKernelGGL(k_transpose64, dim3((P + 63) / 64, (C + 63) / 64, G), dim3(kCT), 0, (hipStream_t)stream, x, y, C, P);
+        return mz::check_launch("k_transpose64");
+    }
     hipLaunchKernelGGL(k_transpose, dim3((P + 31) / 32, (C + 31) / 32, G), dim3(kCT), 0, (hipStream_t)stream, x, y, C, P);
     return mz::check_launch("k_transpose");
 }
