@@ -2,11 +2,12 @@
 // arithmetic as k_search (mz_search.hip) for the network shape the benchmark configuration and
 // the reference's config.yaml heads have, organised around the resource that bounds that kernel.
 //
-// A 16-tree workgroup reads ~1.7 MB of packed weights per simulation round for 16 rows of work.
+// A 16-tree workgroup reads ~1.3 MB of packed weights per simulation round for 16 rows of work.
 // They come from L2 (the whole model is 1 MB) into registers at no more than ~60 bytes per clock
-// and compute unit, every matrix step starts with a round trip to L2, and with two teams of waves
-// running different chains the port idles through their start-ups, epilogues and syncs and is
-// saturated when both stream.  Here all eight waves run ONE sequential program per round:
+// and compute unit; a wave that issues a tile's loads is held for as long as the port needs to
+// take them, every matrix step would start with a round trip to L2, and between the matrix steps
+// lie latency chains (selection, softmax, backup) during which the port would idle.  Here all eight
+// waves run ONE sequential program per round, separated by workgroup barriers:
 //
 //   select, leaf latent          (implicit child latents: formed from the parent's merge row)
 //   merge(leaf)                                         (the drawn child's latent needs only this)
@@ -26,7 +27,8 @@
 // k-chunks, 12-16 KiB per wave) per slot: while one tile is multiplied the next is in flight, and
 // the ring runs on ACROSS steps -- the first tile of the next step is requested before the current
 // step's epilogue, barrier and the vector work between the steps, so no step starts with an
-// exposed round trip.  Biases and the folded one-output layers' weights are staged in LDS once:
+// exposed round trip; where a latency chain follows that only some waves run, the OTHER waves issue
+// the requests right after the barrier, beside it.  Biases and the folded one-output layers' weights are staged in LDS once:
 // inside a round the only global loads are the ring's (a small load issued behind a tile fetch
 // would wait for the whole tile).  Steps are separated by workgroup barriers (no wave teams).
 //
@@ -36,8 +38,8 @@
 //
 // Covers: implicit child latents (pool->latent == NULL), model_look_ahead = 1, policy head
 // [matrix, matrix, softmax layer of at most 8 actions, its hidden widths in as many k-chunks], value head [matrix, matrix, 1] and reward head [matrix, 1]
-// with the last two layers folded, relu after every matrix layer, at most 8 column tiles in value 2 and reward 1, k-chunk counts
-// matching an instantiation below.  mz_search_run falls back to k_search for everything else.
+// with the last two layers folded, relu after every matrix layer, at most 8 column tiles in value 2 and reward 1 and 16 in
+// the other layers, k-chunk counts matching an instantiation below.  mz_search_run falls back to k_search for everything else.
 //
 // Compiled with -ffp-contract=off (every rounding is part of the contract).
 #include <algorithm>
