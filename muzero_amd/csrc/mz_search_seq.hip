@@ -243,18 +243,16 @@ __device__ __forceinline__ void epi_dot(const f32x4 (&hi)[MT], const f32x4 (&lo)
     }
 }
 
-// Sum of n (<= 32) partial sums p[0], p[stride], ... in ascending order (the order of finish_dot), with the
-// loads issued eight at a time instead of one per addition.
+// Sum of n (<= 32) partial sums p[0], p[stride], ... in ascending order (the order of finish_dot), with all the
+// loads issued before the first addition: one LDS round trip instead of one per few additions.
 __device__ __forceinline__ float ordered_sum(const lds_f *p, int stride, int n) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = p[min(i, n - 1) * stride];
     float s = 0.0f;
-    for (int k0 = 0; k0 < n; k0 += 8) {
-        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = p[min(k0 + i, n - 1) * stride];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (k0 + i < n) s += v[i];
-    }
+    for (int i = 0; i < 32; ++i)
+        if (i < n) s += v[i];
     return s;
 }
 
