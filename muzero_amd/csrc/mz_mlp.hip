@@ -6,6 +6,7 @@
 
 #include "mz_common.h"
 #include "mz_mlp_device.h"
+#include "mz_ring.h"
 
 using namespace mzd;
 
@@ -80,13 +81,17 @@ k_mlp_forward(mz_packed_mlp M, const float *__restrict__ blob, const float *__re
     lds_f *X = to_lds(smem) + kLdsReserve, *Xs = X + TM * ld_in, *bufA = Xs + TM * ld_in, *bufB = bufA + TM * ld_w;
     const int row0 = blockIdx.x * TM;
     const int rows = min(TM, B - row0);
+    const bool ring = uni((int)mlp_ring_ok(M));
+    MlpRing<MT> R;
+    if (ring) R.begin(M, blob);  // the first layer's weights travel while the rows are loaded
     load_rows_split(X, Xs, ld_in, MT, rows, M.in_features, [&](int r) -> const float * {
         long long src = x_rows ? (long long)x_rows[row0 + r] : (long long)(row0 + r);
         return src < 0 ? nullptr : x + src * ldx;
     });
     int ld_out;
     Team all = whole_workgroup();
-    lds_f *out = mlp_tile<MT>(all, M, 0, blob, Xs, X, ld_in, bufA, bufB, &ld_out);
+    lds_f *out = ring ? R.run(M, blob, Xs, ld_in, bufA, bufB, &ld_out)
+                      : mlp_tile<MT>(all, M, 0, blob, Xs, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
     // policy heads: the first maximum of each row, then `softmax_times` more softmax passes
     // (src/search/simulation.py:35, src/search/expansion.py:30) before the store
@@ -125,6 +130,9 @@ __device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const f
     const int ld_in = lds_stride(M.in_features), ld_w = lds_stride(M.max_width);
     lds_f *X = to_lds(smem) + kLdsReserve, *Xs = X + TM * ld_in, *bufA = Xs + TM * ld_in, *bufB = bufA + TM * ld_w;
     const int rows = min(TM, J.B - row0);
+    const bool ring = uni((int)mlp_ring_ok(M));
+    MlpRing<MT> R;
+    if (ring) R.begin(M, blob);
     const float *x = J.x;
     const int32_t *x_rows = J.x_rows;
     const long long ldx = J.ldx;
@@ -134,7 +142,8 @@ __device__ __forceinline__ void mlp_rows_forward(const mz_packed_mlp &M, const f
     });
     int ld_out;
     Team all = whole_workgroup();
-    lds_f *out = mlp_tile<MT>(all, M, 0, blob, Xs, X, ld_in, bufA, bufB, &ld_out);
+    lds_f *out = ring ? R.run(M, blob, Xs, ld_in, bufA, bufB, &ld_out)
+                      : mlp_tile<MT>(all, M, 0, blob, Xs, X, ld_in, bufA, bufB, &ld_out);
     const int N = M.out_features;
     float *y = J.y;
     const long long ldy = J.ldy;
