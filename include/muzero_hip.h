@@ -556,7 +556,11 @@ typedef struct mz_search_params {
                                    stage (diagnostics; leave NULL in production)               */
     float *z_pool;              /* f32[G][S+1][D], required when pool->latent is NULL: per tree
                                    and expansion the ONE row z = fc_merge.weight[:, :D] latent
-                                   from which the A children's latents are relu(z + table[a])  */
+                                   from which the A children's latents are relu(z + table[a]).
+                                   With pool->latent given it is an optional workspace: searches
+                                   of the shape the sequential-program kernel covers then run in
+                                   that form and write every node's latent as well (same bits);
+                                   NULL selects the general kernel                              */
 } mz_search_params;
 
 /* Requires pool->cap >= 1 + (S+1)*A, A <= 32, and either pool->latent (every node's latent is

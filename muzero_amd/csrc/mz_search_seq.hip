@@ -265,7 +265,8 @@ __device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int 
     count = max(0, min(groups * 2, total - first));
 }
 
-template <int KCD, int KCP, int KCV>
+// STORE: the pool keeps every node's latent (written from the root rows and in the phase after the rounds)
+template <int KCD, int KCP, int KCV, bool STORE>
 __global__ void __launch_bounds__(kThreads)
 k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q, SeqLds L,
              double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
@@ -347,7 +348,9 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     for (int k = tid; k < Lr0.Np; k += kThreads) DwR[k] = blob[Lr1.w_off + ((k >> 4) * 64 + 16 * ((k >> 2) & 3)) * 4 + (k & 3)];
     for (int i = tid; i < kTrees * ld_d; i += kThreads) {  // root latents as fp32 rows (Z is free until the first merge)
         const int t = i / ld_d, c = i - t * ld_d;
-        Z[i] = (t < trees && c < D) ? q.root_latent[(size_t)(g0 + t) * D + c] : 0.0f;
+        const float v = (t < trees && c < D) ? q.root_latent[(size_t)(g0 + t) * D + c] : 0.0f;
+        Z[i] = v;
+        if (STORE && t < trees && c < D) p.latent[(size_t)(g0 + t) * p.cap * D + c] = v;  // node 0
     }
     if (tid < kTrees) {
         int tp = 0;
@@ -815,6 +818,18 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                             v0 = f32x4{fmaxf(z0[c].x + b0.x, 0.f), fmaxf(z0[c].y + b0.y, 0.f), fmaxf(z0[c].z + b0.z, 0.f), fmaxf(z0[c].w + b0.w, 0.f)};
                             v1 = f32x4{fmaxf(z1[c].x + b1.x, 0.f), fmaxf(z1[c].y + b1.y, 0.f), fmaxf(z1[c].z + b1.z, 0.f), fmaxf(z1[c].w + b1.w, 0.f)};
                         }
+                        if (STORE && a_first + mt < A && j < trees && k0 < D) {
+                            // every node's latent stored (Node.latent_state, src/search/expansion.py:30-33): this lane's eight values
+                            float *dst = p.latent + ((size_t)(g0 + j) * p.cap + 1 + ex * A + a) * D + k0;
+                            if ((D & 3) == 0) {
+                                *(f32x4 *)dst = v0;
+                                if (k0 + 4 < D) *(f32x4 *)(dst + 4) = v1;
+                            } else {
+                                const float t8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                                for (int i = 0; i < 8; ++i)
+                                    if (k0 + i < D) dst[i] = t8[i];
+                            }
+                        }
                         f32x4 hi, lo;
                         split8(v0, v1, hi, lo);
                         xh[mt][c] = __builtin_bit_cast(h8, hi);
@@ -871,10 +886,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 #undef MZ_STAMP
 }
 
-template <int KCD, int KCP, int KCV>
+template <int KCD, int KCP, int KCV, bool STORE>
 int launch_seq(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params &q, const SeqLds &L,
                double *policy, float *policy32, double *value, int32_t *visits, hipStream_t st) {
-    auto kernel = k_search_seq<KCD, KCP, KCV>;
+    auto kernel = k_search_seq<KCD, KCP, KCV, STORE>;
     if (L.total > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_search_seq: cannot enable %zu bytes of LDS: %s", L.total, hipGetErrorString(e));
@@ -893,7 +908,7 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
     static const bool off = [] { const char *e = getenv("MZ_SEARCH_SEQ"); return e && atoi(e) == 0; }();
     if (off) return 0;
     const mz_packed_nets &P = *plan;
-    if (pool->latent != nullptr || prm->z_pool == nullptr || prm->depth != 1 || P.A > 32) return 0;
+    if (prm->z_pool == nullptr || prm->depth != 1 || P.A > 32) return 0;  // (z_pool: the expansions' merge rows, also when the latents are stored)
     if (P.policy.n_layers != 3 || P.value.n_layers != 3 || P.reward.n_layers != 2) return 0;
     if (!is_matrix_layer(P.policy.layer[0]) || !is_matrix_layer(P.policy.layer[1]) || !is_matrix_layer(P.policy.layer[2]) ||
         P.policy.layer[2].act != MZ_ACT_SOFTMAX || P.policy.layer[2].N != P.A || P.A > 8 || P.policy.layer[2].Kp != P.policy.layer[1].Kp)
@@ -914,8 +929,13 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
     if (L.total > 160 * 1024) return 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (kcd == 6 && kcp == 8 && kcv == 8) rc = launch_seq<6, 8, 8>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st);
-    else if (kcd == 2 && kcp == 4 && kcv == 4) rc = launch_seq<2, 4, 4>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st);
+    const bool store = pool->latent != nullptr;
+#define MZ_SEQ_LAUNCH(A_, B_, C_)                                                                                          \
+    rc = store ? launch_seq<A_, B_, C_, true>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st)             \
+               : launch_seq<A_, B_, C_, false>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st)
+    if (kcd == 6 && kcp == 8 && kcv == 8) MZ_SEQ_LAUNCH(6, 8, 8);
+    else if (kcd == 2 && kcp == 4 && kcv == 4) MZ_SEQ_LAUNCH(2, 4, 4);
     else return 0;
+#undef MZ_SEQ_LAUNCH
     return rc == MZ_OK ? 1 : rc;
 }

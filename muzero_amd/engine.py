@@ -257,21 +257,26 @@ class BatchedMCTS:
     """MCTS.run for G trees at once (PUCT selection, `max_iterations` mode)."""
 
     def __init__(self, nets: PackedNetworks, G: int, num_simulations: int, model_look_ahead: int,
-                 discount: float, noise_frac: float, device="cuda", keep_latents: bool = True):
+                 discount: float, noise_frac: float, device="cuda", keep_latents: bool = True,
+                 merge_row_workspace: bool = True):
         """keep_latents=False: with networks in bottleneck form (muzero_amd.towers) the non-root nodes'
         latents are kept only as their bottleneck values (`t_pool`); `pool.latent` then holds the
         roots alone.  With the MLP networks (`PackedNetworks`) the single-launch search keeps, per
         expansion, the one merge pre-activation row its A children's latents are formed from
         (`z_pool`) and the pool holds no latents at all (`implicit`); such an engine runs fused searches
-        only.  The search result does not depend on it: the trees are bit-identical."""
+        only.  The search result does not depend on it: the trees are bit-identical.
+        merge_row_workspace (MLP networks, keep_latents=True): also allocate the merge-row buffer
+        (G x (S+1) x D floats) so that the single-launch search can take its sequential-program form
+        and write the node latents from it; False keeps the general kernel (same bits, slower)."""
         self.nets = nets
         self.G, self.S, self.depth = G, num_simulations, model_look_ahead
         self.discount, self.noise_frac = discount, noise_frac
         self.A, self.D = nets.A, nets.D
         self.implicit = (not keep_latents) and isinstance(nets, PackedNetworks) and self.A <= 32
         self.pool = TreePool(G, self.A, num_simulations, self.D, device=device, with_latent=not self.implicit)
+        want_rows = self.implicit or (merge_row_workspace and isinstance(nets, PackedNetworks) and self.A <= 32)
         self.z_pool = (torch.empty((G, num_simulations + 1, self.D), dtype=torch.float32, device=self.pool.device)
-                       if self.implicit else None)
+                       if want_rows else None)
         dev = self.pool.device
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)

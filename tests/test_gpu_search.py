@@ -199,7 +199,7 @@ def test_search_replays_bit_exact_through_oracle(which, G, S, depth, noise, fuse
 
 
 @pytest.mark.parametrize("which,G,S,depth", [("c4", 100, 50, 1), ("c4", 16, 5, 0), ("tiny", 33, 25, 2), ("odd", 21, 12, 1),
-                                             ("wide", 19, 6, 2)])
+                                             ("wide", 19, 6, 2), ("mid", 40, 20, 1)])
 def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
     """One launch for the whole search vs the per-stage kernels: identical pools (every
     statistic and every latent), identical results."""
@@ -213,6 +213,9 @@ def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
     elif which == "odd":  # reward head without hidden layer, deep policy, mixed activations, A = 3
         g, f = _custom_nets((1, 1, 8), 3, [], [33], [17, 9, 40], ("tanh", "sigmoid", "relu"))
         latent_shape = (1, 1, 8)
+    elif which == "mid":  # the sequential-program kernel's second instantiation
+        g, f = _custom_nets((4, 4, 4), 5, [128], [128, 128], [128, 128], ("relu",))
+        latent_shape = (4, 4, 4)
     else:  # 18 actions (32 lanes per tree, three reward chunks), two hidden reward layers
         g, f = _custom_nets((2, 4, 4), 18, [24, 12], [8], [24], ("relu",))
         latent_shape = (2, 4, 4)
@@ -223,13 +226,19 @@ def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
             torch.from_numpy(rand).cuda())
     a = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25)
     b = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25)
+    # without the merge-row workspace the single launch is always the general kernel; with it, searches of the
+    # covered shape take the sequential-program kernel, which then writes the node latents too
+    c = BatchedMCTS(nets, G, S, depth, discount=0.997, noise_frac=0.25, merge_row_workspace=False)
+    assert a.z_pool is not None and c.z_pool is None
     ra = a.run(*args, fused=True)
     rb = b.run(*args, fused=False)
+    rc = c.run(*args, fused=True)
     torch.cuda.synchronize()
-    for name in ("visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes", "latent"):
-        assert torch.equal(getattr(a.pool, name), getattr(b.pool, name)), name
-    assert torch.equal(ra.policy, rb.policy) and torch.equal(ra.value, rb.value) and torch.equal(ra.visits, rb.visits)
-    assert torch.equal(ra.policy32, rb.policy32)
+    for m, r in ((a, ra), (c, rc)):
+        for name in ("visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes", "latent"):
+            assert torch.equal(getattr(m.pool, name), getattr(b.pool, name)), name
+        assert torch.equal(r.policy, rb.policy) and torch.equal(r.value, rb.value) and torch.equal(r.visits, rb.visits)
+        assert torch.equal(r.policy32, rb.policy32)
 
 
 def _replay_through_oracle(mcts, nets, res, trace, lat, eta, rand, to_play, depth, noise, discount):
