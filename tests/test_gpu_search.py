@@ -199,7 +199,7 @@ def test_search_replays_bit_exact_through_oracle(which, G, S, depth, noise, fuse
 
 
 @pytest.mark.parametrize("which,G,S,depth", [("c4", 100, 50, 1), ("c4", 16, 5, 0), ("tiny", 33, 25, 2), ("odd", 21, 12, 1),
-                                             ("wide", 19, 6, 2), ("mid", 40, 20, 1)])
+                                             ("wide", 19, 6, 2), ("mid", 40, 20, 1), ("ragged", 35, 12, 1)])
 def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
     """One launch for the whole search vs the per-stage kernels: identical pools (every
     statistic and every latent), identical results."""
@@ -216,6 +216,9 @@ def test_fused_kernel_equals_lockstep_kernels_bit_for_bit(which, G, S, depth):
     elif which == "mid":  # the sequential-program kernel's second instantiation
         g, f = _custom_nets((4, 4, 4), 5, [128], [128, 128], [128, 128], ("relu",))
         latent_shape = (4, 4, 4)
+    elif which == "ragged":  # sequential-program kernel, a latent width that is no multiple of 4 (element-wise row accesses)
+        g, f = _custom_nets((1, 10, 17), 6, [128], [256, 128], [256, 256], ("relu",))
+        latent_shape = (1, 10, 17)
     else:  # 18 actions (32 lanes per tree, three reward chunks), two hidden reward layers
         g, f = _custom_nets((2, 4, 4), 18, [24, 12], [8], [24], ("relu",))
         latent_shape = (2, 4, 4)
@@ -324,7 +327,7 @@ def test_ragged_and_minimal_batches(G, S, depth):
 
 
 @pytest.mark.parametrize("which,G,S,depth", [("c4", 100, 50, 1), ("c4", 4100, 6, 2), ("tiny", 33, 25, 2), ("odd", 21, 12, 1),
-                                             ("wide", 19, 6, 0), ("mid", 40, 20, 1)])
+                                             ("wide", 19, 6, 0), ("mid", 40, 20, 1), ("ragged", 35, 12, 1)])
 def test_implicit_child_latents_leave_identical_trees(which, G, S, depth):
     """keep_latents=False (one merge pre-activation row per expansion instead of A child latents; a leaf's
     latent is formed from its parent's row when it is expanded, src/search/expansion.py:25-33): every tree
@@ -343,6 +346,9 @@ def test_implicit_child_latents_leave_identical_trees(which, G, S, depth):
     elif which == "mid":   # the sequential-program kernel's second instantiation: 64-wide latents, 128-wide heads
         g, f = _custom_nets((4, 4, 4), 5, [128], [128, 128], [128, 128], ("relu",))
         latent_shape = (4, 4, 4)
+    elif which == "ragged":   # the first instantiation with a 170-wide latent
+        g, f = _custom_nets((1, 10, 17), 6, [128], [256, 128], [256, 256], ("relu",))
+        latent_shape = (1, 10, 17)
     else:
         g, f = _custom_nets((2, 4, 4), 18, [24, 12], [8], [24], ("relu",))
         latent_shape = (2, 4, 4)
