@@ -495,7 +495,7 @@ def main():
         # whole self-play moves with host-side simulators (stand-ins returning random frames) and the shipped network
         # shapes: the serial engine, and two halves alternating between the host thread pool and the GPU
         from tools.bench_selfplay_towers import run as selfplay_host_envs
-        line["towers"]["selfplay_host_envs"] = selfplay_host_envs(256, moves=4, parts=False)
+        line["towers"]["selfplay_host_envs"] = selfplay_host_envs(256, moves=8, parts=False)
         first = line["towers"][str(args.tower_games[0])]
         line["towers"].update(sims_per_sec=first["sims_per_sec"], ms_per_search=first["ms_per_search"],
                               roofline_tower=first.get("roofline_tower"))
