@@ -469,6 +469,9 @@ def main():
                             "algorithmic_hbm_GBps": G * S * (TREE_BYTES_PER_SIM + lat_bytes) / ks[dom]["s"] / 1e9,
                             "hbm_peak_GBps": 8000.0}
         line["kernels"] = {k: {"avg_us": v["s"] * 1e6, "tflops": v["flop"] / v["s"] / 1e12} for k, v in ks.items()}
+        if not args.store_latents:  # the same search with every node's latent written to the pool: the drop-in MCTS.run's form
+            other = ks["k_search[fused MCTS.run, stored latents]"]["s"]
+            line["stored_latent_form"] = {"sims_per_sec": G * S / other, "ms_per_step": other * 1e3}
     if rank == 0 and args.more_games:
         # secondary figures: more games per GPU (two or four 16-tree workgroups per compute unit)
         line["more_games"] = {}
