@@ -189,7 +189,7 @@ class ConvRepresentation:
             cv.fast = cv.fast and self.fast_convolutions
             if cv.fast:
                 n = cv.wk.numel()
-                cv.w3 = torch.empty((3, n), dtype=torch.int16, device=self.device)
+                cv.w3 = torch.empty((2, n), dtype=torch.int16, device=self.device)
                 _hip.check(lib.mz_split3(ptr(cv.wk), n, ptr(cv.w3), n, _stream()), "mz_split3")
             elif cv.matrix:
                 dense = _hip.Dense(ptr(cv.wk), ptr(cv.bias), cv.k * cv.k * cv.cin, cv.cout, cv.act, 0)
@@ -275,7 +275,7 @@ class ConvRepresentation:
 
     def _s3(self, a, name):
         if a.s is None:
-            a.s = self._buf(name + "_s", (3, a.n), torch.int16)
+            a.s = self._buf(name + "_s", (2, a.n), torch.int16)
             _hip.check(_hip.lib().mz_split3(ptr(a.f), a.n, ptr(a.s), a.n, _stream()), "mz_split3")
         return a.s
 
@@ -310,7 +310,7 @@ class ConvRepresentation:
                 pre = (None, None, 0)   # a float32 activation is split while it is staged
             x3 = None
             if split_out:
-                out.s = self._buf(name + "_s", (3, n_out), torch.int16)
+                out.s = self._buf(name + "_s", (2, n_out), torch.int16)
             else:
                 out.f = self._buf(name, (n_out,))
             if sums and self.fused_statistics and (Ho * Wo) % 64 == 0:
@@ -388,7 +388,7 @@ class ConvRepresentation:
         n = G * P * Cc
         out = self._Act(n=n)
         if split_out:
-            out.s = self._buf(name + "_s", (3, n), torch.int16)
+            out.s = self._buf(name + "_s", (2, n), torch.int16)
         else:
             out.f = self._buf(name, (n,))
         res_f = res3 = None
@@ -434,7 +434,7 @@ class ConvRepresentation:
         x_in = history.to(self.device, torch.float32).contiguous()
         n_in = G * H * W * Cc
         if self._wants_split(-1) and self.steps[0][0] == "conv":  # the first layer reads the split form only
-            x = self._Act(s=self._buf("in_nhwc_s", (3, n_in), torch.int16), n=n_in)
+            x = self._Act(s=self._buf("in_nhwc_s", (2, n_in), torch.int16), n=n_in)
             _hip.check(lib.mz_nchw_split3(ptr(x_in), G, Cc, H * W, ptr(x.s), n_in, _stream()), "mz_nchw_split3")
         else:
             x = self._Act(f=self._buf("in_nhwc", (n_in,)), n=n_in)

@@ -1,14 +1,18 @@
-// Convolutions of the representation network at the bf16 matrix rate with float32 accuracy (gfx950).
+// Convolutions of the representation network at the fp16 matrix rate with float32 accuracy (gfx950).
 //
-// The fp32 matrix instruction of gfx950 runs at 1/16 of the bf16 rate.  A float32 value splits
-// exactly into three bf16 terms, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 =
-// bf16(x - x1 - x2): 3 x 8 significant bits), and a product of two such values is, up to terms of
-// relative size 2^-24,
-//     x w = x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1),
-// six bf16 products accumulated in float32 by v_mfma_f32_16x16x32_bf16 -- the accuracy of an fp32
-// product at 16 / 6 = 2.7 times the fp32 matrix rate.  Activations between the layers are kept in
-// this split form (three bf16 planes [rows][C], channels-last), written by the producing kernel, so
-// the nine-fold re-reads of a 3 x 3 convolution's gather cost no conversion work.
+// The fp32 matrix instruction of gfx950 runs at 1/16 of the fp16 rate.  A float32 value is held as two fp16 terms,
+//     hi = fp16(v),   lo = fp16((v - hi) * 2^11)          (v = hi + lo * 2^-11 to 2^-22 |v|; the scale keeps lo out of
+//                                                          fp16's subnormal range),
+// and a product of two such values is, up to the lo * lo term of relative size 2^-22,
+//     x w = x_hi w_hi + 2^-11 (x_hi w_lo + x_lo w_hi).
+// So that ONE float32 accumulator takes all three terms, the main term uses w_hs = w_hi * 2^11 (an exact exponent
+// shift, formed from the w_hi operand in registers: four packed multiplications per operand):
+//     2^11 x w = x_hi w_hs + x_hi w_lo + x_lo w_hi,
+// three v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block into one accumulator, scaled back by 2^-11 (exact) in the
+// epilogue -- float32 accuracy at 16 / 3 = 5.3 times the fp32 matrix rate, with the register budget of a plain
+// product.  Operands must stay below 65504 in magnitude (weights below 32): beyond that the conversion gives
+// infinity and the results are NaN -- loud, not silently wrong.
+// Split operands in memory are two planes of 16-bit values [plane][rows][C] (channels last): plane 0 = hi, plane 1 = lo.
 //
 //   k_conv3        implicit-GEMM convolution: 256 output pixels x 128 output channels per workgroup
 //                  (8 waves, 64 x 64 per wave), reduction over (tap, input channel) in steps of 32,
@@ -16,10 +20,10 @@
 //                  staged through a double-buffered, XOR-swizzled LDS image (conflict-free b128
 //                  reads: see lds_off), one barrier per step; channel chunks outermost so that the taps of a
 //                  chunk find their pixels in cache
-//   k_split3       float32 rows -> the three planes (weights at pack time, network input)
+//   k_split3       float32 rows -> the planes (weights at pack time, network input)
 //   k_bn_apply3    BatchNorm scale/shift + residual + activation of a ResBlock, reading the raw
-//                  float32 convolution output, writing the split activation of the next layer
-//   k_unsplit3     planes -> float32 (for the few consumers outside this path)
+//                  float32 convolution output, writing the float32 and / or split activation of the next layer
+//   k_unsplit3     planes -> float32 (for the few consumers outside this path; 22 significant bits)
 #include <algorithm>
 
 #include "mz_common.h"
@@ -33,15 +37,17 @@
 
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 constexpr int kT3 = 512;          // threads: 8 waves
 constexpr int kTM = 256, kTN = 128, kTK = 32;
-constexpr int kARow = 64;         // bytes of one LDS row: 32 bf16
-constexpr int kAStage = 3 * kTM * kARow, kBStage = 3 * kTN * kARow;
-constexpr int kStage = kAStage + kBStage;   // 73,728 bytes; two stages
+constexpr int kARow = 64;         // bytes of one LDS row: 32 fp16
+constexpr int kPA = 2, kPW = 2;   // planes of an activation operand and of a weight operand (hi, lo)
+constexpr int kAStage = kPA * kTM * kARow, kBStage = kPW * kTN * kARow;
+constexpr int kStage = kAStage + kBStage;   // 57,344 bytes; two stages
+constexpr float kLoScale = 2048.0f, kLoUnscale = 1.0f / 2048.0f;   // 2^11: scale of the lo and hs planes
 
 __device__ __forceinline__ float act3(float v, int act) {
     switch (act) {
@@ -52,20 +58,19 @@ __device__ __forceinline__ float act3(float v, int act) {
     }
 }
 
-__device__ __forceinline__ unsigned short bf16_bits(float v) {
-    const __bf16 b = (__bf16)v;  // round to nearest even
-    return __builtin_bit_cast(unsigned short, b);
-}
-__device__ __forceinline__ float bf16_value(unsigned short b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
+__device__ __forceinline__ unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ float f16_value(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
 
-// x = p1 + p2 + p3 with every term a bf16 value
-__device__ __forceinline__ void split3(float x, unsigned short &p1, unsigned short &p2, unsigned short &p3) {
-    p1 = bf16_bits(x);
-    const float r1 = x - bf16_value(p1);
-    p2 = bf16_bits(r1);
-    const float r2 = r1 - bf16_value(p2);
-    p3 = bf16_bits(r2);
+// x -> (hi, lo): x = hi + lo * 2^-11 to 2^-22 |x|.  Conversions round to nearest even; the subtraction is exact.
+__device__ __forceinline__ void split2(float x, unsigned short &hi, unsigned short &lo) {
+    const _Float16 h = (_Float16)x;
+    hi = f16_bits(h);
+    lo = f16_bits((_Float16)((x - (float)h) * kLoScale));
 }
+// w_hi * 2^11 of a weight operand (exact unless it overflows: |w| >= 32)
+__device__ __forceinline__ h8 scaled_hi(const h8 &hi) { return hi * (_Float16)kLoScale; }
+// the value two planes hold
+__device__ __forceinline__ float unsplit2(unsigned short hi, unsigned short lo) { return f16_value(hi) + f16_value(lo) * kLoUnscale; }
 
 // byte offset of the 16-byte piece `pc` (8 reduction indices) of row `r` inside one plane image.
 // A ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
@@ -103,7 +108,7 @@ __device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], unsigne
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int lr = wm * 64 + mt * 16 + kg * 4 + j;
-                const float v = act3(acc[mt][nt][j] + bv, act);
+                const float v = act3(acc[mt][nt][j] * kLoUnscale + bv, act);
                 tile[lr * kOutLd + lc] = v;
                 if (m0 + lr < rows) {
                     cs += (double)v;
@@ -132,19 +137,19 @@ __device__ __forceinline__ void conv3_epilogue(const f32x4 (&acc)[4][4], unsigne
         const long long o = (long long)row * N + n0 + c4;
         if (y) *reinterpret_cast<f32x4 *>(y + o) = v;
         if (y3) {
-            unsigned short p[3][4];
+            unsigned short p[kPA][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split3(v[e], p[0][e], p[1][e], p[2][e]);
+            for (int e = 0; e < 4; ++e) split2(v[e], p[0][e], p[1][e]);
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < kPA; ++q)
                 *reinterpret_cast<uint2 *>(y3 + q * y_plane + o) =
                     uint2{(unsigned)p[q][0] | ((unsigned)p[q][1] << 16), (unsigned)p[q][2] | ((unsigned)p[q][3] << 16)};
         }
     }
 }
 
-// RAW: the input is float32 rows xf[pixel][C] (4 bytes per value instead of the planes' 6, and a row's 32-channel
-// chunk is one whole 128-byte line instead of three 64-byte pieces); it is split while it is staged.
+// RAW: the input is float32 rows xf[pixel][C] (a row's 32-channel chunk is one whole 128-byte line instead of two
+// 64-byte pieces); it is split while it is staged.
 template <bool RAW>
 __global__ void __launch_bounds__(kT3)
 k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *__restrict__ xf, int C, const int32_t *__restrict__ idx, int taps,
@@ -171,7 +176,7 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *_
     // staging roles: A rows ra and ra + 128 (three planes each), B column rb, piece pc
     const int ra = tid >> 2, pc = tid & 3, rb = tid >> 2;
     int srow[2];
-    u32x4 ga[6], gb[3];
+    u32x4 ga[4], gb[kPW];
     auto fetch = [&](int s) {
         const int chunk = s / taps, tap = s - chunk * taps, c0 = chunk * kTK + pc * 8;
         srow[0] = s_idx[tap * kTM + ra];
@@ -184,48 +189,48 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *_
                 ga[h * 2 + 1] = *reinterpret_cast<const u32x4 *>(src + 4);
             } else {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < kPA; ++p) {
                     const unsigned short *src = x3 + p * x_plane + (long long)max(srow[h], 0) * C + c0;
-                    ga[h * 3 + p] = *reinterpret_cast<const u32x4 *>(src);
+                    ga[h * kPA + p] = *reinterpret_cast<const u32x4 *>(src);
                 }
             }
         }
         const int kk = tap * C + c0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
+        for (int p = 0; p < kPW; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
     };
     auto stash = [&](int stage) {
         unsigned char *base = lds + stage * kStage;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if constexpr (RAW) {
-                unsigned int pl[3][4];
+                unsigned int pl[kPA][4];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 v4 = __builtin_bit_cast(f32x4, ga[h * 2 + q]);
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        unsigned short lo[3], hi[3];
-                        split3(v4[e], lo[0], lo[1], lo[2]);
-                        split3(v4[e + 1], hi[0], hi[1], hi[2]);
+                        unsigned short ev[kPA], od[kPA];   // the planes of an even / odd channel
+                        split2(v4[e], ev[0], ev[1]);
+                        split2(v4[e + 1], od[0], od[1]);
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) pl[p][q * 2 + (e >> 1)] = srow[h] < 0 ? 0u : ((unsigned int)lo[p] | ((unsigned int)hi[p] << 16));
+                        for (int p = 0; p < kPA; ++p) pl[p][q * 2 + (e >> 1)] = srow[h] < 0 ? 0u : ((unsigned int)ev[p] | ((unsigned int)od[p] << 16));
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < kPA; ++p)
                     *reinterpret_cast<u32x4 *>(base + p * (kTM * kARow) + lds_off(ra + 128 * h, pc)) = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
             } else {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    u32x4 v = ga[h * 3 + p];
+                for (int p = 0; p < kPA; ++p) {
+                    u32x4 v = ga[h * kPA + p];
                     if (srow[h] < 0) v = u32x4{0u, 0u, 0u, 0u};
                     *reinterpret_cast<u32x4 *>(base + p * (kTM * kARow) + lds_off(ra + 128 * h, pc)) = v;
                 }
             }
         }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(base + kAStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
+        for (int p = 0; p < kPW; ++p) *reinterpret_cast<u32x4 *>(base + kAStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
     };
 
     f32x4 acc[4][4];
@@ -242,23 +247,22 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *_
         const bool more = s + 1 < steps;
         if (more) fetch(s + 1);
         const unsigned char *sa = lds + stage * kStage, *sb = sa + kAStage;
-        bf16x8 a[3][4], b[3][4];
+        h8 a[kPA][4], b[kPW][4];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[p][t] = *reinterpret_cast<const bf16x8 *>(sa + p * (kTM * kARow) + lds_off(wm * 64 + t * 16 + m, kg));
-                b[p][t] = *reinterpret_cast<const bf16x8 *>(sb + p * (kTN * kARow) + lds_off(wn * 64 + t * 16 + m, kg));
-            }
-        // smallest terms first; consecutive instructions never share an accumulator
+            for (int p = 0; p < kPA; ++p) a[p][t] = *reinterpret_cast<const h8 *>(sa + p * (kTM * kARow) + lds_off(wm * 64 + t * 16 + m, kg));
+#pragma unroll
+            for (int p = 0; p < kPW; ++p) b[p][t] = *reinterpret_cast<const h8 *>(sb + p * (kTN * kARow) + lds_off(wn * 64 + t * 16 + m, kg));
+        }
+        // the cross terms first, then x_hi * w_hs; consecutive instructions never share an accumulator
 #define MZ_TERM(P, Q)                                                                                        \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0);
-        MZ_TERM(2, 0)
-        MZ_TERM(1, 1)
-        MZ_TERM(0, 2)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0);
         MZ_TERM(1, 0)
         MZ_TERM(0, 1)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[0][t] = scaled_hi(b[0][t]);
         MZ_TERM(0, 0)
 #undef MZ_TERM
         if (more) stash(stage ^ 1);
@@ -279,16 +283,16 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *_
 //
 // The range is staged by groups of 128 slots (one per thread quartet): NJ = 3 groups hold images up to 63
 // pixels wide; wider images (up to 144 pixels: 256 + 2 * 145 slots) take 4 or 5 groups, whose slots live in
-// registers between their fetch and the end of the chunk -- affordable only in the RAW form (two 16-byte
-// pieces per slot instead of three), which is therefore the only form offered for them.
+// registers between their fetch and the end of the chunk; they are offered in the RAW form only (the form the
+// representation network uses for every layer).
 constexpr int kHaloSlots = 384;                       // NJ = 3: 256 rows + 2 * 64 pixels of reach
 constexpr int kSlotBytes = 9 * kTM * 2;               // the slot table u16[9][256]
 constexpr int kMaxLds = 160 * 1024;
 __host__ __device__ constexpr int halo_plane(int cap) { return (cap + 4) * kARow; }  // + the slot of zeros (index cap)
 
-// LDS of one launch: three planes of `cap` slots, two weight stages, the slot table, the scale / shift rows
+// LDS of one launch: the planes of `cap` slots, two weight stages, the slot table, the scale / shift rows
 __host__ __device__ constexpr size_t same_lds(int cap, int bn_games, int C) {
-    return (size_t)3 * halo_plane(cap) + 2 * kBStage + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float);
+    return (size_t)kPA * halo_plane(cap) + 2 * kBStage + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float);
 }
 
 //
@@ -319,7 +323,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     const int taps = ksize * ksize, pad = (ksize - 1) >> 1, reach = pad * (W + 1);
     const int chunks = C / kTK, steps = taps * chunks;
     const int kHaloPlane = halo_plane(cap);
-    unsigned char *s_halo = lds, *s_b = lds + 3 * kHaloPlane;
+    unsigned char *s_halo = lds, *s_b = lds + kPA * kHaloPlane;
     unsigned short *s_slot = reinterpret_cast<unsigned short *>(s_b + 2 * kBStage);  // [tap][wm][m][t]
     if (tid < kTM) {  // one row per thread: its image coordinates once, then the taps
         const int r = tid, row = m0 + r;
@@ -332,9 +336,9 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                 dst[tap * (4 * 16 * 4)] = (unsigned short)(in ? r + reach + dy * W + dx : cap);
             }
     }
-    if (tid < 12) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + cap * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 4 * kPA) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + cap * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
 
-    // staging roles: halo slots hs + 128 j, j < NJ (three planes each), B column rb, piece pc
+    // staging roles: halo slots hs + 128 j, j < NJ (two planes each), B column rb, piece pc
     const int hs = tid >> 2, pc = tid & 3, rb = tid >> 2;
     const int nslots = kTM + 2 * reach;
     const int P = H * W;
@@ -356,8 +360,8 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
 #pragma unroll
         for (int j = 0; j < NJ; ++j) gl[j] = min(max(m0 - reach + hs + 128 * j, 0) / P - g_first, bn_games - 1);
     }
-    constexpr int kGH = RAW ? 2 * NJ : 3 * NJ;
-    u32x4 gh[kGH], gb[3];
+    constexpr int kGH = 2 * NJ;   // RAW: two float32 pieces per slot, else one piece of each plane
+    u32x4 gh[kGH], gb[kPW];
     u32x4 gr[RES ? 2 * NJ : 1];
     auto fetch_halo = [&](int chunk) {
         const int c0 = chunk * kTK + pc * 8;
@@ -374,8 +378,8 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    gh[j * 3 + p] = ok ? *reinterpret_cast<const u32x4 *>(x3 + p * x_plane + pix * C + c0) : u32x4{0u, 0u, 0u, 0u};
+                for (int p = 0; p < kPA; ++p)
+                    gh[j * kPA + p] = ok ? *reinterpret_cast<const u32x4 *>(x3 + p * x_plane + pix * C + c0) : u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
@@ -389,7 +393,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                 const long long pix = (long long)m0 - reach + slot;
                 const bool ok = slot < nslots && pix >= 0 && pix < rows;
                 const float *sc = s_bn + gl[j] * C + c0, *sh = sc + bn_games * C;
-                unsigned int pl[3][4];
+                unsigned int pl[kPA][4];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 x4 = __builtin_bit_cast(f32x4, gh[j * 2 + q]);
@@ -419,35 +423,35 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                     }
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        unsigned short lo[3], hi[3];
-                        split3(v4[e], lo[0], lo[1], lo[2]);
-                        split3(v4[e + 1], hi[0], hi[1], hi[2]);
+                        unsigned short ev[kPA], od[kPA];   // the planes of an even / odd channel
+                        split2(v4[e], ev[0], ev[1]);
+                        split2(v4[e + 1], od[0], od[1]);
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) pl[p][q * 2 + (e >> 1)] = ok ? ((unsigned int)lo[p] | ((unsigned int)hi[p] << 16)) : 0u;
+                        for (int p = 0; p < kPA; ++p) pl[p][q * 2 + (e >> 1)] = ok ? ((unsigned int)ev[p] | ((unsigned int)od[p] << 16)) : 0u;
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < kPA; ++p)
                     *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(slot, pc)) = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < kPA; ++p)
                     if (NJ == 3 || hs + 128 * j < cap)
-                        *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * 3 + p];
+                        *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * kPA + p];
         }
     };
     auto fetch_b = [&](int s) {
         const int chunk = s / taps, tap = s - chunk * taps;
         const int kk = tap * C + chunk * kTK + pc * 8;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
+        for (int p = 0; p < kPW; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
     };
     auto stash_b = [&](int stage) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(s_b + stage * kBStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
+        for (int p = 0; p < kPW; ++p) *reinterpret_cast<u32x4 *>(s_b + stage * kBStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
     };
 
     f32x4 acc[4][4];
@@ -462,9 +466,9 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     stash_halo(0);
     stash_b(0);
     __syncthreads();
-    // Operand reads and matrix instructions of a step are issued in three waves so that the products of
-    // one pair of planes run while the next pair is still on its way from LDS (the fences keep the
-    // compiler from gathering all 24 reads in front of the first product): smallest terms first.
+    // Operand reads and matrix instructions of a step are issued in groups so that the products of one pair of
+    // planes run while the next plane is still on its way from LDS (the fences keep the compiler from gathering
+    // all 16 reads in front of the first product): the cross terms first, then x_hi * w_hs.
     const long long t_loop = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     auto slots_of = [&](int tap) { return *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4); };
     uint2 sl = slots_of(0);
@@ -485,41 +489,35 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                 bo[t] = lds_off(wn * 64 + t * 16 + m, kg);
             }
             sl = slots_of(tap + 1 < taps ? tap + 1 : 0);  // the next step's slots, a step ahead of their use
-            bf16x8 a[3][4], b[3][4];
+            h8 a[kPA][4], b[kPW][4];
             auto read_a = [&](int p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (!(MZ_CONV3_SKIP & 2)) a[p][t] = *reinterpret_cast<const bf16x8 *>(s_halo + p * kHaloPlane + ao[t]);
-                    else a[p][t] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)ao[t], 1u, 2u, 3u});
+                    if (!(MZ_CONV3_SKIP & 2)) a[p][t] = *reinterpret_cast<const h8 *>(s_halo + p * kHaloPlane + ao[t]);
+                    else a[p][t] = __builtin_bit_cast(h8, u32x4{(unsigned)ao[t], 1u, 2u, 3u});
                 }
             };
             auto read_b = [&](int p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    if (!(MZ_CONV3_SKIP & 4)) b[p][t] = *reinterpret_cast<const bf16x8 *>(sb + p * (kTN * kARow) + bo[t]);
-                    else b[p][t] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)(s + t), 1u, 2u, 3u});
+                    if (!(MZ_CONV3_SKIP & 4)) b[p][t] = *reinterpret_cast<const h8 *>(sb + p * (kTN * kARow) + bo[t]);
+                    else b[p][t] = __builtin_bit_cast(h8, u32x4{(unsigned)(s + t), 1u, 2u, 3u});
                 }
             };
 #define MZ_TERM(P, Q)                                                                                        \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
-        if (!(MZ_CONV3_SKIP & 1)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0); \
+        if (!(MZ_CONV3_SKIP & 1)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0); \
         else asm volatile("" ::"v"(a[P][mt]), "v"(b[Q][nt]));
-            read_a(2);
+            read_a(1);
             read_b(0);
             __builtin_amdgcn_sched_barrier(0);
-            read_a(1);
+            read_a(0);
             read_b(1);
             __builtin_amdgcn_sched_barrier(0);
-            MZ_TERM(2, 0)
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(0);
-            read_b(2);
-            __builtin_amdgcn_sched_barrier(0);
-            MZ_TERM(1, 1)
-            __builtin_amdgcn_sched_barrier(0);
-            MZ_TERM(0, 2)
             MZ_TERM(1, 0)
             MZ_TERM(0, 1)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[0][t] = scaled_hi(b[0][t]);
             MZ_TERM(0, 0)
 #undef MZ_TERM
             if (more && !(MZ_CONV3_SKIP & 8)) stash_b(stage ^ 1);
@@ -549,15 +547,14 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
 __global__ void __launch_bounds__(256)
 k_split3(const float *__restrict__ x, long long total, unsigned short *__restrict__ out, long long plane) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        unsigned short p1, p2, p3;
-        split3(x[i], p1, p2, p3);
-        out[i] = p1;
-        out[plane + i] = p2;
-        out[2 * plane + i] = p3;
+        unsigned short hi, lo;
+        split2(x[i], hi, lo);
+        out[i] = hi;
+        out[plane + i] = lo;
     }
 }
 
-// The network input: [G][C][P] float32 (channels first) -> the three planes [G * P][C] (channels last),
+// The network input: [G][C][P] float32 (channels first) -> the two activation planes [G * P][C] (channels last),
 // transposed through a 64-channel x 32-pixel LDS tile so that reads run along the pixels and writes
 // along the channels.
 __global__ void __launch_bounds__(256)
@@ -578,19 +575,18 @@ k_nchw_split3(const float *__restrict__ x, int C, int P, unsigned short *__restr
     for (int j = tp; j < 32; j += 4) {
         const int c = c0 + tc, p = p0 + j;
         if (c >= C || p >= P) continue;
-        unsigned short p1, p2, p3;
-        split3(tile[tc][j], p1, p2, p3);
+        unsigned short hi, lo;
+        split2(tile[tc][j], hi, lo);
         const long long o = (img * P + p) * C + c;
-        out[o] = p1;
-        out[plane + o] = p2;
-        out[2 * plane + o] = p3;
+        out[o] = hi;
+        out[plane + o] = lo;
     }
 }
 
 __global__ void __launch_bounds__(256)
 k_unsplit3(const unsigned short *__restrict__ x3, long long plane, long long total, float *__restrict__ out) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
-        out[i] = (bf16_value(x3[i]) + bf16_value(x3[plane + i])) + bf16_value(x3[2 * plane + i]);
+        out[i] = unsplit2(x3[i], x3[plane + i]);
 }
 
 // y = act(x * scale[g][c] + shift[g][c] + r): r = 0, the split activation res3 (identity skip) or
@@ -605,15 +601,14 @@ k_bn_apply3(const float *__restrict__ x, const float *__restrict__ scale, const 
         const long long o = (long long)g * C + c;
         float v = fmaf(x[i], scale[o], shift[o]);  // the same single rounding as the staged form of k_conv3_same
         if (res) v += rscale ? fmaf(res[i], rscale[o], rshift[o]) : res[i];
-        if (res3) v += (bf16_value(res3[i]) + bf16_value(res3[res_plane + i])) + bf16_value(res3[2 * res_plane + i]);
+        if (res3) v += unsplit2(res3[i], res3[res_plane + i]);
         v = act3(v, act);
         if (y) y[i] = v;
         if (y3) {
-            unsigned short p1, p2, p3;
-            split3(v, p1, p2, p3);
-            y3[i] = p1;
-            y3[y_plane + i] = p2;
-            y3[2 * y_plane + i] = p3;
+            unsigned short hi, lo;
+            split2(v, hi, lo);
+            y3[i] = hi;
+            y3[y_plane + i] = lo;
         }
     }
 }
@@ -692,10 +687,11 @@ static int conv3_launch(const char *who, const uint16_t *x3, int64_t x_plane, co
         return mz::fail(MZ_ERR_ARG, "%s: operands must be 16-byte aligned", who);
     if (taps > 16) return mz::fail(MZ_ERR_ARG, "%s: at most 16 taps (kernel size up to 4)", who);
     if (block_sums && rows % 64 != 0) return mz::fail(MZ_ERR_ARG, "%s: block sums need a multiple of 64 rows", who);
-    const size_t lds = 2 * (size_t)kStage + (size_t)taps * kTM * sizeof(int);
+    // two operand stages + the index table; the epilogue reuses the space as its output tile
+    const size_t lds = std::max<size_t>(2 * (size_t)kStage + (size_t)taps * kTM * sizeof(int), kOutLds);
     auto launch = [&](auto kernel) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(2 * (size_t)kStage + 16 * kTM * sizeof(int)));
+                                           (int)std::max<size_t>(2 * (size_t)kStage + 16 * kTM * sizeof(int), kOutLds));
         if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_conv3: cannot enable %zu bytes of LDS: %s", lds, hipGetErrorString(e));
         const dim3 grid(N / kTN, (rows + kTM - 1) / kTM);
         hipLaunchKernelGGL(kernel, grid, dim3(kT3), lds, (hipStream_t)stream, x3, (long long)x_plane, xf, C, idx, taps, w3,

@@ -248,8 +248,8 @@ def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
         x = torch.randn(rows * Cin, device="cuda", generator=gen)
         w = torch.randn(N * taps * Cin, device="cuda", generator=gen) * 0.05
         bias = torch.randn(N, device="cuda", generator=gen)
-        x3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
-        w3 = torch.empty((3, N * taps * Cin), dtype=torch.int16, device="cuda")
+        x3 = torch.empty((2, rows * Cin), dtype=torch.int16, device="cuda")
+        w3 = torch.empty((2, N * taps * Cin), dtype=torch.int16, device="cuda")
         _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
         _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
         idx = torch.empty((taps, rows), dtype=torch.int32, device="cuda")
@@ -257,7 +257,7 @@ def test_staged_range_convolution_equals_the_gathering_kernel_bit_for_bit():
         outs = []
         for same in (False, True):
             y = torch.full((rows * N,), float("nan"), device="cuda")
-            y3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
+            y3 = torch.zeros((2, rows * N), dtype=torch.int16, device="cuda")
             if same:
                 _hip.check(lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], ptr(bias), 1,
                                                      ptr(y), ptr(y3), y3.shape[1], N, None, None), "mz_conv3_same_forward")
@@ -295,23 +295,23 @@ def test_staged_range_on_wide_images_equals_the_gathering_kernel_bit_for_bit():
         bias = torch.randn(N, device="cuda", generator=gen)
         scale = torch.rand(G, Cin, device="cuda", generator=gen) + 0.5
         shift = torch.randn(G, Cin, device="cuda", generator=gen)
-        w3 = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        w3 = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
         _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
         idx = torch.empty((taps, rows), dtype=torch.int32, device="cuda")
         _hip.check(lib.mz_conv_index(ptr(idx), G, H, W, k, 1, 1, H, W, None), "mz_conv_index")
         for with_bn in (False, True):
-            a3 = torch.empty((3, x.numel()), dtype=torch.int16, device="cuda")
+            a3 = torch.empty((2, x.numel()), dtype=torch.int16, device="cuda")
             if with_bn:
                 _hip.check(lib.mz_bn_apply3(ptr(x), ptr(scale), ptr(shift), None, None, None, None, 0, 1, None, ptr(a3), a3.shape[1],
                                             G, P, Cin, None), "mz_bn_apply3")
             else:
                 _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(a3), a3.shape[1], None), "mz_split3")
             want = torch.full((rows * N,), float("nan"), device="cuda")
-            want3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
+            want3 = torch.zeros((2, rows * N), dtype=torch.int16, device="cuda")
             _hip.check(lib.mz_conv3_forward(ptr(a3), a3.shape[1], Cin, ptr(idx), taps, ptr(w3), w3.shape[1], ptr(bias), 1,
                                             ptr(want), ptr(want3), want3.shape[1], rows, N, None, None), "mz_conv3_forward")
             got = torch.full((rows * N,), float("nan"), device="cuda")
-            got3 = torch.zeros((3, rows * N), dtype=torch.int16, device="cuda")
+            got3 = torch.zeros((2, rows * N), dtype=torch.int16, device="cuda")
             _hip.check(lib.mz_conv3_same_bn_forward(ptr(x), ptr(scale) if with_bn else None, ptr(shift) if with_bn else None, 1,
                                                     Cin, G, H, W, k, ptr(w3), w3.shape[1], ptr(bias), 1, ptr(got), ptr(got3),
                                                     got3.shape[1], N, None, None), "mz_conv3_same_bn_forward")
@@ -374,8 +374,8 @@ def test_block_sums_give_the_statistics_of_the_separate_pass():
     bias = torch.randn(N, device="cuda", generator=gen)
     gamma = torch.rand(N, device="cuda", generator=gen) + 0.5
     beta = torch.randn(N, device="cuda", generator=gen)
-    x3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
-    w3 = torch.empty((3, N * taps * Cin), dtype=torch.int16, device="cuda")
+    x3 = torch.empty((2, rows * Cin), dtype=torch.int16, device="cuda")
+    w3 = torch.empty((2, N * taps * Cin), dtype=torch.int16, device="cuda")
     _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
     _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
     idx = torch.empty((taps, rows), dtype=torch.int32, device="cuda")
@@ -457,9 +457,9 @@ def test_staged_convolution_applies_the_previous_batchnorm_bit_for_bit():
         scale = torch.rand((G, Cin), device="cuda", generator=gen) + 0.5
         shift = torch.randn((G, Cin), device="cuda", generator=gen)
         w = torch.randn(N * 9 * Cin, device="cuda", generator=gen) * 0.05
-        w3 = torch.empty((3, w.numel()), dtype=torch.int16, device="cuda")
+        w3 = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
         _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
-        a3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
+        a3 = torch.empty((2, rows * Cin), dtype=torch.int16, device="cuda")
         _hip.check(lib.mz_bn_apply3(ptr(x), ptr(scale), ptr(shift), None, None, None, None, 0, 1, None, ptr(a3), a3.shape[1], G, P, Cin,
                                     None), "mz_bn_apply3")
         want, got = torch.empty(rows * N, device="cuda"), torch.empty(rows * N, device="cuda")
@@ -469,7 +469,7 @@ def test_staged_convolution_applies_the_previous_batchnorm_bit_for_bit():
                                                 ptr(got), None, 0, N, None, None), "mz_conv3_same_bn_forward")
         torch.cuda.synchronize()
         assert torch.equal(got, want), (G, H, W, Cin, N)
-        x3 = torch.empty((3, rows * Cin), dtype=torch.int16, device="cuda")
+        x3 = torch.empty((2, rows * Cin), dtype=torch.int16, device="cuda")
         _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
         _hip.check(lib.mz_conv3_same_forward(ptr(x3), x3.shape[1], Cin, G, H, W, k, ptr(w3), w3.shape[1], None, 0, ptr(want), None, 0, N,
                                              None, None), "mz_conv3_same_forward")
