@@ -25,12 +25,14 @@
 //                  float32 convolution output, writing the float32 and / or split activation of the next layer
 //   k_unsplit3     planes -> float32 (for the few consumers outside this path; 22 significant bits)
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #include "mz_common.h"
 
 // Diagnostic builds (-DMZ_CONV3_SKIP=mask, tools/diag_conv3.sh) leave parts of k_conv3_same out to
-// see what bounds it: 1 matrix instructions, 2 A operand reads, 4 B operand reads, 8 weight staging,
-// 16 restaging of the pixel range after the first chunk.  Results are wrong in those builds.
+// see what bounds it: 1 matrix instructions, 8 weight staging, 16 restaging of the pixel range after the
+// first chunk, 32 clock stamps.  Results are wrong in those builds.
 #ifndef MZ_CONV3_SKIP
 #define MZ_CONV3_SKIP 0
 #endif
@@ -56,6 +58,12 @@ __device__ __forceinline__ float act3(float v, int act) {
         case MZ_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         default: return v;
     }
+}
+
+// f(integral_constant<int, K>) for every K of the sequence, in order
+template <int... K, class F>
+__device__ __forceinline__ void for_each_index(std::integer_sequence<int, K...>, F &&f) {
+    (f(std::integral_constant<int, K>{}), ...);
 }
 
 __device__ __forceinline__ unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
@@ -255,15 +263,15 @@ k_conv3(const unsigned short *__restrict__ x3, long long x_plane, const float *_
 #pragma unroll
             for (int p = 0; p < kPW; ++p) b[p][t] = *reinterpret_cast<const h8 *>(sb + p * (kTN * kARow) + lds_off(wn * 64 + t * 16 + m, kg));
         }
-        // the cross terms first, then x_hi * w_hs; consecutive instructions never share an accumulator
+        // x_lo * w_hi, x_hi * w_hs, x_hi * w_lo; consecutive instructions never share an accumulator
 #define MZ_TERM(P, Q)                                                                                        \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0);
         MZ_TERM(1, 0)
-        MZ_TERM(0, 1)
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[0][t] = scaled_hi(b[0][t]);
         MZ_TERM(0, 0)
+        MZ_TERM(0, 1)
 #undef MZ_TERM
         if (more) stash(stage ^ 1);
         __syncthreads();
@@ -290,9 +298,9 @@ constexpr int kSlotBytes = 9 * kTM * 2;               // the slot table u16[9][2
 constexpr int kMaxLds = 160 * 1024;
 __host__ __device__ constexpr int halo_plane(int cap) { return (cap + 4) * kARow; }  // + the slot of zeros (index cap)
 
-// LDS of one launch: the planes of `cap` slots, two weight stages, the slot table, the scale / shift rows
+// LDS of one launch: the planes of `cap` slots, three weight stages, the slot table, the scale / shift rows
 __host__ __device__ constexpr size_t same_lds(int cap, int bn_games, int C) {
-    return (size_t)kPA * halo_plane(cap) + 2 * kBStage + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float);
+    return (size_t)kPA * halo_plane(cap) + 3 * kBStage + kSlotBytes + (size_t)2 * bn_games * C * sizeof(float);
 }
 
 //
@@ -324,7 +332,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     const int chunks = C / kTK, steps = taps * chunks;
     const int kHaloPlane = halo_plane(cap);
     unsigned char *s_halo = lds, *s_b = lds + kPA * kHaloPlane;
-    unsigned short *s_slot = reinterpret_cast<unsigned short *>(s_b + 2 * kBStage);  // [tap][wm][m][t]
+    unsigned short *s_slot = reinterpret_cast<unsigned short *>(s_b + 3 * kBStage);  // [tap][wm][m][t]
     if (tid < kTM) {  // one row per thread: its image coordinates once, then the taps
         const int r = tid, row = m0 + r;
         const int w = row % W, h = (row / W) % H;
@@ -383,64 +391,72 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
             }
         }
     };
-    auto stash_halo = [&](int chunk) {
-        if constexpr (RAW) {
-            const int c0 = chunk * kTK + pc * 8;
+    // RAW: a staged slot goes from its fetched float32 form to the operand planes in place -- the piece (j, q), four
+    // channels of slot hs + 128 j, turns gh[2 j + q] into {two words of the hi plane, two words of the lo plane}.
+    // (The input activation is a run-time value: a piece is instantiated for relu, the usual case, and for the
+    // general switch, so that the common path is straight-line code.  Spreading the pieces between the matrix
+    // instructions of a chunk's last two steps was measured: slower, 589 -> 708 us per 48 x 48 x 128 layer.)
+    auto convert_piece_as = [&](int chunk, auto k_tag, auto relu_tag) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_tag)::value, j = k >> 1, q = k & 1;
+        constexpr bool kRelu = decltype(relu_tag)::value;
+        auto in_activation = [&](float v) { return kRelu ? (v > 0.0f ? v : 0.0f) : act3(v, in_act); };
+        const int c0 = chunk * kTK + pc * 8;
+        const int slot = hs + 128 * j;
+        const long long pix = (long long)m0 - reach + slot;
+        const bool ok = slot < nslots && pix >= 0 && pix < rows;
+        const float *sc = s_bn + gl[j] * C + c0, *sh = sc + bn_games * C;
+        const f32x4 x4 = __builtin_bit_cast(f32x4, gh[k]);
+        f32x4 v4 = x4;
+        if constexpr (RES) {
+            const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
+            const f32x4 r4 = __builtin_bit_cast(f32x4, gr[k]);
+            f32x4 add = r4;
+            if (res_scale) {  // uniform
+                const float *rs = sc + 2 * bn_games * C, *rh = sc + 3 * bn_games * C;
+                const f32x4 rs4 = *reinterpret_cast<const f32x4 *>(rs + 4 * q), rh4 = *reinterpret_cast<const f32x4 *>(rh + 4 * q);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int slot = hs + 128 * j;
-                if (NJ > 3 && slot >= cap) continue;  // the image ends at `cap` slots (+ the slot of zeros)
-                const long long pix = (long long)m0 - reach + slot;
-                const bool ok = slot < nslots && pix >= 0 && pix < rows;
-                const float *sc = s_bn + gl[j] * C + c0, *sh = sc + bn_games * C;
-                unsigned int pl[kPA][4];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const f32x4 x4 = __builtin_bit_cast(f32x4, gh[j * 2 + q]);
-                    f32x4 v4 = x4;
-                    if constexpr (RES) {
-                        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
-                        const f32x4 r4 = __builtin_bit_cast(f32x4, gr[j * 2 + q]);
-                        f32x4 add = r4;
-                        if (res_scale) {  // uniform
-                            const float *rs = sc + 2 * bn_games * C, *rh = sc + 3 * bn_games * C;
-                            const f32x4 rs4 = *reinterpret_cast<const f32x4 *>(rs + 4 * q), rh4 = *reinterpret_cast<const f32x4 *>(rh + 4 * q);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) add[e] = fmaf(r4[e], rs4[e], rh4[e]);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = fmaf(x4[e], sc4[e], sh4[e]);  // the roundings of k_bn_apply3
-                            v += add[e];
-                            v4[e] = act3(v, in_act);
-                        }
-                        if (act_out && blockIdx.x == 0 && ok && slot >= reach && slot < reach + kTM)
-                            *reinterpret_cast<f32x4 *>(act_out + pix * C + c0 + 4 * q) = v4;
-                    } else if (in_scale) {  // uniform
-                        const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v4[e] = act3(fmaf(x4[e], sc4[e], sh4[e]), in_act);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        unsigned short ev[kPA], od[kPA];   // the planes of an even / odd channel
-                        split2(v4[e], ev[0], ev[1]);
-                        split2(v4[e + 1], od[0], od[1]);
-#pragma unroll
-                        for (int p = 0; p < kPA; ++p) pl[p][q * 2 + (e >> 1)] = ok ? ((unsigned int)ev[p] | ((unsigned int)od[p] << 16)) : 0u;
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < kPA; ++p)
-                    *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(slot, pc)) = u32x4{pl[p][0], pl[p][1], pl[p][2], pl[p][3]};
+                for (int e = 0; e < 4; ++e) add[e] = fmaf(r4[e], rs4[e], rh4[e]);
             }
-        } else {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(x4[e], sc4[e], sh4[e]);  // the roundings of k_bn_apply3
+                v += add[e];
+                v4[e] = in_activation(v);
+            }
+            if (act_out && blockIdx.x == 0 && ok && slot >= reach && slot < reach + kTM)
+                *reinterpret_cast<f32x4 *>(act_out + pix * C + c0 + 4 * q) = v4;
+        } else if (in_scale) {  // uniform
+            const f32x4 sc4 = *reinterpret_cast<const f32x4 *>(sc + 4 * q), sh4 = *reinterpret_cast<const f32x4 *>(sh + 4 * q);
 #pragma unroll
-                for (int p = 0; p < kPA; ++p)
-                    if (NJ == 3 || hs + 128 * j < cap)
-                        *reinterpret_cast<u32x4 *>(s_halo + p * kHaloPlane + lds_off(hs + 128 * j, pc)) = gh[j * kPA + p];
+            for (int e = 0; e < 4; ++e) v4[e] = in_activation(fmaf(x4[e], sc4[e], sh4[e]));
+        }
+        unsigned int pl[kPA][2];
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            unsigned short ev[kPA], od[kPA];   // the planes of an even / odd channel
+            split2(v4[e], ev[0], ev[1]);
+            split2(v4[e + 1], od[0], od[1]);
+#pragma unroll
+            for (int p = 0; p < kPA; ++p) pl[p][e >> 1] = ok ? ((unsigned int)ev[p] | ((unsigned int)od[p] << 16)) : 0u;
+        }
+        gh[k] = u32x4{pl[0][0], pl[0][1], pl[1][0], pl[1][1]};
+    };
+    auto convert_piece = [&](int chunk, auto k_tag) __attribute__((always_inline)) {
+        if constexpr (RAW && decltype(k_tag)::value < 2 * NJ) {
+            if (in_act == MZ_ACT_RELU) convert_piece_as(chunk, k_tag, std::true_type{});
+            else convert_piece_as(chunk, k_tag, std::false_type{});
+        }
+    };
+    // the converted slots (RAW) or the fetched planes -> the LDS image
+    auto write_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int slot = hs + 128 * j;
+            if (NJ > 3 && slot >= cap) continue;  // the image ends at `cap` slots (+ the slot of zeros)
+            const u32x4 u = gh[j * 2], v = gh[j * 2 + 1];
+            const u32x4 hi = RAW ? u32x4{u.x, u.y, v.x, v.y} : u, lo = RAW ? u32x4{u.z, u.w, v.z, v.w} : v;
+            *reinterpret_cast<u32x4 *>(s_halo + lds_off(slot, pc)) = hi;
+            *reinterpret_cast<u32x4 *>(s_halo + kHaloPlane + lds_off(slot, pc)) = lo;
         }
     };
     auto fetch_b = [&](int s) {
@@ -463,71 +479,133 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     fetch_halo(0);
     fetch_b(0);
     if constexpr (RAW) __syncthreads();  // the scale / shift rows are in place
-    stash_halo(0);
+    for_each_index(std::make_integer_sequence<int, 2 * NJ>{}, [&](auto k_tag) __attribute__((always_inline)) { convert_piece(0, k_tag); });
+    write_halo();
     stash_b(0);
+    fetch_b(min(1, steps - 1));
+    stash_b(1);
+    fetch_b(min(2, steps - 1));  // stored by step 0
     __syncthreads();
-    // Operand reads and matrix instructions of a step are issued in groups so that the products of one pair of
-    // planes run while the next plane is still on its way from LDS (the fences keep the compiler from gathering
-    // all 16 reads in front of the first product): the cross terms first, then x_hi * w_hs.
+    // The step loop is software-pipelined through the operand registers: every LDS read of step s + 1 is issued
+    // during the matrix instructions of step s, into the register whose operand has just been multiplied for the
+    // last time (x_lo[mt] after its four products of the first term, w_hi[nt] after the second term's, w_lo[nt] and
+    // x_hi[mt] during the third), one read behind every four products: the reads, the few vector instructions and
+    // the matrix instructions of a wave interleave instead of alternating in phases (both waves of a SIMD leave the
+    // barrier in the same phase, so what one wave does not overlap itself is not overlapped at all), and a step's
+    // products start right behind the barrier.  The weights therefore rotate through THREE stages: step s
+    // multiplies stage s % 3 (read during step s - 1), reads stage (s + 1) % 3 ahead, and at its very start stores
+    // the weights of step s + 2 -- requested from memory at the start of step s - 1, a whole step earlier, so the
+    // store does not wait for them -- then requests those of step s + 3.  The step's barrier sits right behind that
+    // store, where the wave must wait for its prefetched operands anyway.  The pixel range is constant over the
+    // taps of a chunk, only a chunk's first step waits for its reads.  Reads and fetches past the last step / tap
+    // are made anyway, from clamped addresses (a step is one straight-line block).
+    // Terms: x_lo * w_hi, x_hi * w_hs, x_hi * w_lo (k_conv3 adds them in the same order).
     const long long t_loop = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    auto slots_of = [&](int tap) { return *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4); };
-    uint2 sl = slots_of(0);
-    int s = 0;
+    int bo[4], ao[4], an[4];  // LDS offsets of the weight operands, of the pixel operands read in this step, in the next
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bo[t] = lds_off(wn * 64 + t * 16 + m, kg);
+    auto a_offsets = [&](int tap, int (&dst)[4]) {
+        const uint2 sl = *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t] = lds_off((int)((t < 2 ? sl.x : sl.y) >> (16 * (t & 1))) & 0xffff, kg);
+    };
+    auto read_a = [&](int plane, int t) { return *reinterpret_cast<const h8 *>(s_halo + plane * kHaloPlane + ao[t]); };
+    auto read_b = [&](int plane, int stage, int t) {
+        return *reinterpret_cast<const h8 *>(s_b + stage * kBStage + plane * (kTN * kARow) + bo[t]);
+    };
+#define MZ_MMA(MT, NT, AA, BB)                                                                                         \
+    if (!(MZ_CONV3_SKIP & 1)) acc[MT][NT] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AA, BB, acc[MT][NT], 0, 0, 0);     \
+    else asm volatile("" ::"v"(AA), "v"(BB));
+    h8 xl[4], xh[4], wh[4], wl[4];
+    a_offsets(0, ao);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        xl[t] = read_a(1, t);
+        wh[t] = read_b(0, 0, t);
+        xh[t] = read_a(0, t);
+        wl[t] = read_b(1, 0, t);
+    }
+    a_offsets(min(1, taps - 1), an);
+    int s = 0, stage = 0;  // stage = s % 3
+    long long seg[5] = {0, 0, 0, 0, 0};  // (stamped diagnostic build) cycles of a step's parts, summed over the steps
+#define MZ_SEG(i)                                                          \
+    if (MZ_CONV3_SKIP & 32) {                                              \
+        const long long t_now = (long long)__builtin_amdgcn_s_memtime();   \
+        seg[i] += t_now - t_seg;                                           \
+        t_seg = t_now;                                                     \
+    }
     for (int chunk = 0; chunk < chunks; ++chunk) {
         const bool next_chunk = chunk + 1 < chunks;
-        if (next_chunk && !(MZ_CONV3_SKIP & 16)) fetch_halo(chunk + 1);  // in flight behind the taps of this chunk
         for (int tap = 0; tap < taps; ++tap, ++s) {
-            const int stage = s & 1;
-            const bool more = s + 1 < steps;
-            if (more && !(MZ_CONV3_SKIP & 8)) fetch_b(s + 1);
-            const unsigned char *sb = s_b + stage * kBStage;
-            int ao[4], bo[4];
+            const int st1 = stage == 2 ? 0 : stage + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+            long long t_seg = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ao[t] = an[t];
+            MZ_SEG(0)
+            __syncthreads();
+            MZ_SEG(1)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { MZ_MMA(mt, nt, xl[mt], wh[nt]) }
+                xl[mt] = read_a(1, mt);
+                if (mt == 0) {
+                    // behind the first products, not in front of the barrier: the store of the weights of step
+                    // s + 2, the request for those of step s + 3
+                    if (!(MZ_CONV3_SKIP & 8)) {
+                        stash_b(st2);
+                        fetch_b(min(s + 3, steps - 1));
+                    }
+                    // the next chunk's pixel range: in flight behind the taps of this chunk.  Requested BEHIND the
+                    // weights: loads return in order, and these come from memory -- in front they would hold the weights back
+                    if (tap == 0 && next_chunk && !(MZ_CONV3_SKIP & 16)) fetch_halo(chunk + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            MZ_SEG(2)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const h8 ws = scaled_hi(wh[nt]);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) { MZ_MMA(mt, nt, xh[mt], ws) }
+                wh[nt] = read_b(0, st1, nt);
+                if (nt == 0) a_offsets(min(tap + 2, taps - 1), an);  // (the pixel operands of the next step's reads)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            MZ_SEG(3)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) { MZ_MMA(mt, nt, xh[mt], wl[nt]) }
+                wl[nt] = read_b(1, st1, nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                MZ_MMA(mt, 3, xh[mt], wl[3])
+                xh[mt] = read_a(0, mt);
+            }
+            wl[3] = read_b(1, st1, 3);
+            MZ_SEG(4)
+            stage = st1;
+        }
+        if (next_chunk && !(MZ_CONV3_SKIP & 16)) {
+            __syncthreads();  // every wave has left the old range
+            for_each_index(std::make_integer_sequence<int, 2 * NJ>{}, [&](auto k_tag) __attribute__((always_inline)) { convert_piece(chunk + 1, k_tag); });
+            write_halo();
+            __syncthreads();
+            a_offsets(0, ao);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int slot = (int)((t < 2 ? sl.x : sl.y) >> (16 * (t & 1))) & 0xffff;
-                ao[t] = lds_off(slot, kg);
-                bo[t] = lds_off(wn * 64 + t * 16 + m, kg);
+                xl[t] = read_a(1, t);
+                xh[t] = read_a(0, t);
             }
-            sl = slots_of(tap + 1 < taps ? tap + 1 : 0);  // the next step's slots, a step ahead of their use
-            h8 a[kPA][4], b[kPW][4];
-            auto read_a = [&](int p) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (!(MZ_CONV3_SKIP & 2)) a[p][t] = *reinterpret_cast<const h8 *>(s_halo + p * kHaloPlane + ao[t]);
-                    else a[p][t] = __builtin_bit_cast(h8, u32x4{(unsigned)ao[t], 1u, 2u, 3u});
-                }
-            };
-            auto read_b = [&](int p) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (!(MZ_CONV3_SKIP & 4)) b[p][t] = *reinterpret_cast<const h8 *>(sb + p * (kTN * kARow) + bo[t]);
-                    else b[p][t] = __builtin_bit_cast(h8, u32x4{(unsigned)(s + t), 1u, 2u, 3u});
-                }
-            };
-#define MZ_TERM(P, Q)                                                                                        \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)       \
-        if (!(MZ_CONV3_SKIP & 1)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[P][mt], b[Q][nt], acc[mt][nt], 0, 0, 0); \
-        else asm volatile("" ::"v"(a[P][mt]), "v"(b[Q][nt]));
-            read_a(1);
-            read_b(0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_a(0);
-            read_b(1);
-            __builtin_amdgcn_sched_barrier(0);
-            MZ_TERM(1, 0)
-            MZ_TERM(0, 1)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[0][t] = scaled_hi(b[0][t]);
-            MZ_TERM(0, 0)
-#undef MZ_TERM
-            if (more && !(MZ_CONV3_SKIP & 8)) stash_b(stage ^ 1);
-            __syncthreads();
-        }
-        if (next_chunk && !(MZ_CONV3_SKIP & 16)) {  // every wave has left the old range behind the barrier above
-            stash_halo(chunk + 1);
-            __syncthreads();
+            a_offsets(min(1, taps - 1), an);
         }
     }
+#undef MZ_MMA
+#undef MZ_SEG
+    __syncthreads();  // (the epilogue's tile overlays the operand images)
 
     const long long t_epi = (MZ_CONV3_SKIP & 32) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     conv3_epilogue(acc, lds, m0, n0, wm, wn, m, kg, bias, act, y, y3, y_plane, rows, N, sums);
@@ -535,11 +613,11 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
         __builtin_amdgcn_s_waitcnt(0);
         const long long t_end = (long long)__builtin_amdgcn_s_memtime();
         if (lane == 0) {
-            float *dst = y + (long long)m0 * N + n0 + wave * 4;
+            float *dst = y + (long long)m0 * N + n0 + wave * 8;
             dst[0] = (float)(t_loop - t_start);
             dst[1] = (float)(t_epi - t_loop);
             dst[2] = (float)(t_end - t_epi);
-            dst[3] = (float)(t_start & 0xffffff);
+            for (int i = 0; i < 5; ++i) dst[3 + i] = (float)seg[i];
         }
     }
 }

@@ -38,8 +38,8 @@ def main():
     gen = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(rows * C, device="cuda", generator=gen)
     w = torch.randn(N * taps * C, device="cuda", generator=gen) * 0.05
-    x3 = torch.empty((3, rows * C), dtype=torch.int16, device="cuda")
-    w3 = torch.empty((3, N * taps * C), dtype=torch.int16, device="cuda")
+    x3 = torch.empty((2, rows * C), dtype=torch.int16, device="cuda")
+    w3 = torch.empty((2, N * taps * C), dtype=torch.int16, device="cuda")
     _hip.check(lib.mz_split3(ptr(x), x.numel(), ptr(x3), x3.shape[1], None), "mz_split3")
     _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
     y = torch.empty(rows * N, device="cuda")
@@ -72,8 +72,9 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     if os.environ.get("MZ_CONV3_STAMPS"):  # stamped diagnostic build: cycles per part, mean over waves
-        st = y.view(rows, N)[::256, :32].reshape(-1, 8, 4)
-        print("stamps (prologue, loop, epilogue cycles): ", st[..., :3].mean(dim=(0, 1)).tolist(), file=sys.stderr)
+        st = y.view(rows, N)[::256, :64].reshape(-1, 8, 8)
+        print("stamps (prologue, loop, epilogue cycles; in the loop: stores + requests, barrier, the three terms): ",
+              [round(v) for v in st.mean(dim=(0, 1)).tolist()], file=sys.stderr)
     flop = 2.0 * rows * N * taps * C
     print(json.dumps({"kernel": "gather" if a.gather else ("same+bn" if a.raw else "same"), "games": G, "hw": H, "width": W, "cin": C, "cout": N,
                       "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6, "bf16_executed_tflops": 6 * flop / us / 1e6,
