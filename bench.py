@@ -308,11 +308,11 @@ def representation_time(G, dev, iters=3):
     torch.cuda.empty_cache()
     tf = flops_per_game() * G / s / 1e12
     return {"games": G, "ms_per_move": s * 1e3, "tflops": tf, "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-            # every float32 product is six bf16 products on the matrix cores (whole network, small layers included)
-            "bf16_executed_tflops": 6 * tf, "bf16_mfma_peak_tflops": BF16_MFMA_PEAK_TFLOPS,
-            "bf16_executed_frac": 6 * tf / BF16_MFMA_PEAK_TFLOPS,
-            "kernel": "convolutions as split-bf16 matrix products with float32 accuracy (k_conv3_same / k_conv3), "
-                      "per-game BatchNorm statistics from the convolution epilogue"}
+            # every float32 product is three fp16 products on the matrix cores (whole network, small layers included)
+            "f16_executed_tflops": 3 * tf, "f16_mfma_peak_tflops": F16_MFMA_PEAK_TFLOPS,
+            "f16_executed_frac": 3 * tf / F16_MFMA_PEAK_TFLOPS,
+            "kernel": "convolutions as three fp16 matrix products on two-plane operands, float32 accuracy "
+                      "(k_conv3_same / k_conv3), per-game BatchNorm statistics from the convolution epilogue"}
 
 
 def main():

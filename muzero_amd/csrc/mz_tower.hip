@@ -1595,38 +1595,30 @@ k_merge_conv(const float *__restrict__ blob, long long wm_off, int KTm, int Kt, 
     }
 }
 
-// The same pass at the bf16 matrix rate (v_mfma_f32_16x16x32_bf16: 16 times the rate of the fp32 instruction) with
-// float32 accuracy.  A float32 value splits exactly into three bf16 terms, x = x1 + x2 + x3 (x1 = bf16(x),
-// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significant bits), and a product is, up to terms of relative
-// size 2^-24,   x w = x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1):  six instructions that cover 32 reduction
-// indices where the fp32 form needs eight -- 2.7 times less matrix time.  The packed float32 weights are split in
-// registers as they arrive (same layers as the fp32 form reads), the rows of t once while they are staged (three
-// planes in LDS, a lane's eight values of a pair of k-tiles in one 16-byte piece per plane), x = relu(z + table)
-// in registers: its eight channels per lane are exactly one instruction's operand.
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+// The same pass at the fp16 matrix rate (v_mfma_f32_16x16x32_f16: 16 times the rate of the fp32 instruction) with
+// float32 accuracy.  A float32 value is held as two fp16 terms, hi = fp16(v) and lo = fp16((v - hi) * 2^11)
+// (mz_mlp_device.h: v = hi + lo * 2^-11 to 2^-22 |v|), and a product is, up to the lo * lo term of relative size 2^-22,
+//     2^11 x w = x_hi w_hs + x_hi w_lo + x_lo w_hi      with w_hs = w_hi * 2^11 (an exact exponent shift, made from the
+// w_hi operand in registers):  three instructions into ONE accumulator cover 32 reduction indices where the fp32
+// form needs eight -- 5.3 times less matrix time; the accumulator is scaled back by 2^-11 (exact) when it is read.
+// The packed float32 weights are split once per weight update (mz_packed_split3), the rows of t once while they are
+// staged (two planes in LDS, a lane's eight values of a pair of k-tiles in one 16-byte piece per plane),
+// x = relu(z + table) in registers: its eight channels per lane are exactly one instruction's operand.
+// Operands must stay below 65504 in magnitude (weights below 32): beyond that the results are NaN.
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
-__device__ __forceinline__ unsigned bf16_pair(float a, float b) {  // round to nearest even, a in the low half
-    const __bf16 x = (__bf16)a, y = (__bf16)b;
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+constexpr int kMcPlanes = 2;
+// four values -> their two planes, two words (four fp16) each
+__device__ __forceinline__ void split2w(const f32x4 &v, u32x2 &hi, u32x2 &lo) {
+    f32x2 h, l;
+    split4(v, h, l);
+    hi = __builtin_bit_cast(u32x2, h);
+    lo = __builtin_bit_cast(u32x2, l);
 }
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-// four values -> their three planes, two words (four bf16) each
-__device__ __forceinline__ void split3(const f32x4 &v, u32x2 &p1, u32x2 &p2, u32x2 &p3) {
-    p1.x = bf16_pair(v.x, v.y);
-    p1.y = bf16_pair(v.z, v.w);
-    const float r0 = v.x - bf16_lo(p1.x), r1 = v.y - bf16_hi(p1.x), r2 = v.z - bf16_lo(p1.y), r3 = v.w - bf16_hi(p1.y);
-    p2.x = bf16_pair(r0, r1);
-    p2.y = bf16_pair(r2, r3);
-    p3.x = bf16_pair(r0 - bf16_lo(p2.x), r1 - bf16_hi(p2.x));
-    p3.y = bf16_pair(r2 - bf16_lo(p2.y), r3 - bf16_hi(p2.y));
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(const u32x2 &a, const u32x2 &b) {
-    return __builtin_bit_cast(bf16x8, u32x4{a.x, a.y, b.x, b.y});
-}
-// A packed float32 layer (tiles [column tile][k-tile][lane] of float4, mz_wide_pack) -> its three bf16 planes as
-// matrix-instruction operands: out[((column tile * pairs + pair) * 3 + plane) * 64 + lane] = the lane's four values of
+__device__ __forceinline__ h8 as_h8(const u32x2 &a, const u32x2 &b) { return __builtin_bit_cast(h8, u32x4{a.x, a.y, b.x, b.y}); }
+__device__ __forceinline__ h8 scaled_hi(const h8 &hi) { return hi * (_Float16)kLoScale; }
+// A packed float32 layer (tiles [column tile][k-tile][lane] of float4, mz_wide_pack) -> its two fp16 planes as
+// matrix-instruction operands: out[((column tile * pairs + pair) * 2 + plane) * 64 + lane] = the lane's four values of
 // k-tile 2 pair followed by those of k-tile 2 pair + 1 (zeros past the last tile).
 __global__ void k_packed_split3(const float *__restrict__ w, int KT, int NT, u32x4 *__restrict__ out) {
     const int npairs = (KT + 1) >> 1;
@@ -1635,38 +1627,39 @@ __global__ void k_packed_split3(const float *__restrict__ w, int KT, int NT, u32
     const int lane = (int)(i & 63), pr = (int)((i >> 6) % npairs), nt = (int)((i >> 6) / npairs);
     const f32x4 *src = reinterpret_cast<const f32x4 *>(w) + ((long long)nt * KT + 2 * pr) * 64 + lane;
     const f32x4 a = src[0], b = 2 * pr + 1 < KT ? src[64] : f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x2 pa[3], pb[3];
-    split3(a, pa[0], pa[1], pa[2]);
-    split3(b, pb[0], pb[1], pb[2]);
+    u32x2 pa[kMcPlanes], pb[kMcPlanes];
+    split2w(a, pa[0], pa[1]);
+    split2w(b, pb[0], pb[1]);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) out[(((long long)nt * npairs + pr) * 3 + pl) * 64 + lane] = u32x4{pa[pl].x, pa[pl].y, pb[pl].x, pb[pl].y};
+    for (int pl = 0; pl < kMcPlanes; ++pl)
+        out[(((long long)nt * npairs + pr) * kMcPlanes + pl) * 64 + lane] = u32x4{pa[pl].x, pa[pl].y, pb[pl].x, pb[pl].y};
 }
 
-// Products of operands given as three planes each: the six terms of relative size >= 2^-24, smallest first.
-// Two accumulators at once (alternating, so that no instruction waits for the one before it):
-// acc0 += a0 b, acc1 += a1 b  (shared second operand) or acc0 += a b0, acc1 += a b1 (shared first operand).
-__device__ __forceinline__ void mfma6_shared_b(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x4 &acc0,
-                                               f32x4 &acc1) {
-    constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[ia[i]], b[ib[i]], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ia[i]], b[ib[i]], acc1, 0, 0, 0);
-    }
+// Products of operands given as two planes each (w: the weights, with ws = scaled_hi(w[0]); x: the activations): the
+// three terms, cross terms first.  Two accumulators at once (alternating, so that no instruction waits for the one
+// before it): acc0 += w0 x, acc1 += w1 x  (weights as the first operand) or acc0 += x w0, acc1 += x w1 (as the second).
+__device__ __forceinline__ void mfma3_weights_first(const h8 (&w0)[2], const h8 &w0s, const h8 (&w1)[2], const h8 &w1s,
+                                                    const h8 (&x)[2], f32x4 &acc0, f32x4 &acc1) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[0], x[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[0], x[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[1], x[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[1], x[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0s, x[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1s, x[0], acc1, 0, 0, 0);
 }
-__device__ __forceinline__ void mfma6_shared_a(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], f32x4 &acc0,
-                                               f32x4 &acc1) {
-    constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia[i]], b0[ib[i]], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia[i]], b1[ib[i]], acc1, 0, 0, 0);
-    }
+__device__ __forceinline__ void mfma3_weights_second(const h8 (&x)[2], const h8 (&w0)[2], const h8 &w0s, const h8 (&w1)[2],
+                                                     const h8 &w1s, f32x4 &acc0, f32x4 &acc1) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[1], w0[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[1], w1[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[0], w0[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[0], w1[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[0], w0s, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[0], w1s, acc1, 0, 0, 0);
 }
 
 constexpr int kMcPairs = kMcMaxKT / 2;          // pairs of k-tiles of the merge product
 constexpr int kMcLdT3 = kMcPairs * 16 + 4;      // words per row and plane of the split rows of t (skewed)
-static_assert(3 * kMcLdT3 <= (kMcT / 64) * kMcLdP, "the split rows fit the area of the partial products");
+static_assert(kMcPlanes * kMcLdT3 <= (kMcT / 64) * kMcLdP, "the split rows fit the area of the partial products");
 
 template <int MTR>
 __global__ void __launch_bounds__(kMcT) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -1684,20 +1677,20 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
     lds_i *s_act = to_lds_i(smem + (size_t)(kMcT / 64) * kMcRows * kMcLdP);
     // weights pre-split by mz_packed_split3: [column tile][pair of k-tiles][plane][lane] 16-byte operands
     const int npairs = (KTm + 1) >> 1;
-    const u32x4 *wm = merge3 + ((long long)(pos * (kMcC / 16) + 2 * wave) * npairs) * 3 * 64 + lane;
-    const u32x4 *wg = conv3 + (long long)wave * 3 * 64 + lane;  // pair w of the 256 channels' 8 pairs
+    const u32x4 *wm = merge3 + ((long long)(pos * (kMcC / 16) + 2 * wave) * npairs) * kMcPlanes * 64 + lane;
+    const u32x4 *wg = conv3 + (long long)wave * kMcPlanes * 64 + lane;  // pair w of the 256 channels' 8 pairs
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // the first pair of k-tiles of this wave's merge weights (both column tiles) is on its way while the rows are
     // staged (PF = 2, two pairs ahead, spills registers at every tile size and is slower: measured)
     constexpr int PF = 1;
-    u32x4 wn[PF][2][3];  // [stage][column tile][plane] of the pairs to come
+    u32x4 wn[PF][2][kMcPlanes];  // [stage][column tile][plane] of the pairs to come
 #pragma unroll
     for (int st = 0; st < PF; ++st)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                wn[st][n][pl] = st < npairs ? wm[(((long long)n * npairs + st) * 3 + pl) * 64] : u32x4{0u, 0u, 0u, 0u};
+            for (int pl = 0; pl < kMcPlanes; ++pl)
+                wn[st][n][pl] = st < npairs ? wm[(((long long)n * npairs + st) * kMcPlanes + pl) * 64] : u32x4{0u, 0u, 0u, 0u};
     {
         // TPR threads per row; a thread takes the pieces (four consecutive values) k0, k0 + TPR, ... of its row,
         // splits them and stores each plane's two words into the 16-byte piece of its (pair, lane group)
@@ -1716,10 +1709,10 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const int q = k0 + TPR * j, kt = q >> 2, g4 = q & 3;  // piece -> k-tile, lane group
-                u32x2 p[3];
-                split3(v[j], p[0], p[1], p[2]);
+                u32x2 p[kMcPlanes];
+                split2w(v[j], p[0], p[1]);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < kMcPlanes; ++pl)
                     *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(
                         T3 + ((size_t)pl * kMcRows + r) * kMcLdT3 + ((kt >> 1) * 4 + g4) * 4 + (kt & 1) * 2) = p[pl];
             }
@@ -1730,11 +1723,13 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
         s_act[tid] = a;
     }
     // this wave's convolution weights: channels 32 w .. 32 w + 31 (k-tiles 2 w, 2 w + 1) x both column tiles
-    bf16x8 g3[2][3];
+    h8 g3[2][kMcPlanes], gs[2];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
+    for (int c2 = 0; c2 < 2; ++c2) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) g3[c2][pl] = __builtin_bit_cast(bf16x8, wg[((long long)c2 * (kMcC / 32) * 3 + pl) * 64]);
+        for (int pl = 0; pl < kMcPlanes; ++pl) g3[c2][pl] = __builtin_bit_cast(h8, wg[((long long)c2 * (kMcC / 32) * kMcPlanes + pl) * 64]);
+        gs[c2] = scaled_hi(g3[c2][0]);
+    }
     __syncthreads();
 
     // ---- z for this position, transposed (weights as the A operand): acc[mt][n][i] = z[row 16 mt + m][channel 32 w + 16 n + 4 kq + i]
@@ -1744,25 +1739,31 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[mt][n] = zero4;
     for (int kt = 0, pr = 0; kt < KTm; kt += 2, ++pr) {
-        bf16x8 w3[2][3];  // this pair's weights as operands: [column tile][plane]
+        h8 w3[2][kMcPlanes], ws[2];  // this pair's weights as operands: [column tile][plane], and the scaled hi planes
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                w3[n][pl] = __builtin_bit_cast(bf16x8, wn[0][n][pl]);
+            for (int pl = 0; pl < kMcPlanes; ++pl) {
+                w3[n][pl] = __builtin_bit_cast(h8, wn[0][n][pl]);
                 if (PF > 1) wn[0][n][pl] = wn[PF - 1][n][pl];
-                if (pr + PF < npairs) wn[PF - 1][n][pl] = wm[(((long long)n * npairs + pr + PF) * 3 + pl) * 64];
+                if (pr + PF < npairs) wn[PF - 1][n][pl] = wm[(((long long)n * npairs + pr + PF) * kMcPlanes + pl) * 64];
             }
+            ws[n] = scaled_hi(w3[n][0]);
+        }
 #pragma unroll
         for (int mt = 0; mt < MTR; ++mt) {
-            bf16x8 t3[3];
+            h8 t3[kMcPlanes];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                t3[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(
-                                                        T3 + ((size_t)pl * kMcRows + mt * 16 + m) * kMcLdT3 + (pr * 4 + kq) * 4));
-            mfma6_shared_b(w3[0], w3[1], t3, acc[mt][0], acc[mt][1]);
+            for (int pl = 0; pl < kMcPlanes; ++pl)
+                t3[pl] = __builtin_bit_cast(h8, *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(
+                                                    T3 + ((size_t)pl * kMcRows + mt * 16 + m) * kMcLdT3 + (pr * 4 + kq) * 4));
+            mfma3_weights_first(w3[0], ws[0], w3[1], ws[1], t3, acc[mt][0], acc[mt][1]);
         }
     }
+#pragma unroll
+    for (int mt = 0; mt < MTR; ++mt)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[mt][n] *= kLoUnscale;  // (exact: a power of two)
     // the table values of the first action are requested before the barrier (expansion); rows with their own action
     // read theirs where they are used
     const float *tab = table + (long long)pos * kMcC + 32 * wave + 4 * kq;  // + action * HW * C + 16 n
@@ -1793,14 +1794,14 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[n][i] = fmaxf(acc[mt][n][i] + tv[i], 0.0f);
             }
-            u32x2 pa[3], pb[3];
-            split3(x[0], pa[0], pa[1], pa[2]);
-            split3(x[1], pb[0], pb[1], pb[2]);
-            bf16x8 x3[3];
+            u32x2 pa[kMcPlanes], pb[kMcPlanes];
+            split2w(x[0], pa[0], pa[1]);
+            split2w(x[1], pb[0], pb[1]);
+            h8 x3[kMcPlanes];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) x3[pl] = as_bf16x8(pa[pl], pb[pl]);
+            for (int pl = 0; pl < kMcPlanes; ++pl) x3[pl] = as_h8(pa[pl], pb[pl]);
             y[mt][0] = y[mt][1] = zero4;
-            mfma6_shared_a(x3, g3[0], g3[1], y[mt][0], y[mt][1]);
+            mfma3_weights_second(x3, g3[0], gs[0], g3[1], gs[1], y[mt][0], y[mt][1]);
         }
         // y[mt][c2][i] = partial Y[row 16 mt + 4 kq + i][column 16 c2 + m]
         lds_f *pw = Ps + (size_t)wave * kMcRows * kMcLdP;
@@ -1809,7 +1810,7 @@ k_merge_conv_bf(const u32x4 *__restrict__ merge3, int KTm, int Kt, const u32x4 *
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pw[(mt * 16 + 4 * kq + i) * kMcLdP + 16 * c2 + m] = y[mt][c2][i];
+                for (int i = 0; i < 4; ++i) pw[(mt * 16 + 4 * kq + i) * kMcLdP + 16 * c2 + m] = y[mt][c2][i] * kLoUnscale;
         __syncthreads();
         if (tid < kMcRows * 8) {
             f32x4 sum = *reinterpret_cast<const lds_f4 *>(Ps + rrow * kMcLdP + 4 * rc4);
@@ -2171,7 +2172,7 @@ int mz_merge_conv_forward_split(const mz_packed_layer *h_merge, const uint32_t *
 
 int64_t mz_packed_split3_words(const mz_packed_layer *h_plan) {
     if (!h_plan || h_plan->Kp <= 0 || h_plan->Np <= 0) return mz::fail(MZ_ERR_ARG, "mz_packed_split3_words: NULL or empty layer");
-    return (int64_t)(h_plan->Np / 16) * (((h_plan->Kp / 16) + 1) / 2) * 3 * 64 * 4;
+    return (int64_t)(h_plan->Np / 16) * (((h_plan->Kp / 16) + 1) / 2) * kMcPlanes * 64 * 4;
 }
 
 int mz_packed_split3(const mz_packed_layer *h_plan, const float *blob, uint32_t *out, void *stream) {

@@ -1,10 +1,10 @@
-"""One split-bf16 convolution kernel alone: mz_conv3_same_forward (default) or mz_conv3_forward
+"""One two-plane fp16 convolution kernel alone: mz_conv3_same_forward (default) or mz_conv3_forward
 (--gather) on G images of H x W pixels, C -> N channels, 3 x 3, timed with HIP events.
 
     python tools/bench_conv3_kernel.py [--games 256] [--hw 48] [--cin 128] [--cout 128] [--gather] [--raw]
 
-Prints one JSON line: microseconds per launch and the executed bf16 matrix rate (six products per
-float32 product) against the 2.5 PFLOP/s dense bf16 peak.  MUZERO_HIP_LIB selects another build of
+Prints one JSON line: microseconds per launch and the executed fp16 matrix rate (three products per
+float32 product) against the 2.5 PFLOP/s dense fp16 peak.  MUZERO_HIP_LIB selects another build of
 the library (diagnostic variants)."""
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-BF16_PEAK_TFLOPS = 2500.0
+F16_PEAK_TFLOPS = 2500.0
 
 
 def main():
@@ -77,8 +77,8 @@ def main():
               [round(v) for v in st.mean(dim=(0, 1)).tolist()], file=sys.stderr)
     flop = 2.0 * rows * N * taps * C
     print(json.dumps({"kernel": "gather" if a.gather else ("same+bn" if a.raw else "same"), "games": G, "hw": H, "width": W, "cin": C, "cout": N,
-                      "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6, "bf16_executed_tflops": 6 * flop / us / 1e6,
-                      "bf16_frac_of_peak": 6 * flop / us / 1e6 / BF16_PEAK_TFLOPS, "lib": os.environ.get("MUZERO_HIP_LIB", "default")}))
+                      "us_per_launch": us, "fp32_equivalent_tflops": flop / us / 1e6, "f16_executed_tflops": 3 * flop / us / 1e6,
+                      "f16_frac_of_peak": 3 * flop / us / 1e6 / F16_PEAK_TFLOPS, "lib": os.environ.get("MUZERO_HIP_LIB", "default")}))
 
 
 if __name__ == "__main__":

@@ -51,18 +51,20 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak of an MI355X
 
 def merge_conv_roofline(nets, G, A, D, hw, C, seconds, flop):
     """Roofline entry of k_merge_conv's expansion call.  `flop`: the algorithmic float32 multiply-adds.  In the split
-    form the kernel executes six bf16 products per product (on 128 of the merge layer's reduction indices: pairs
-    of k-tiles) on the bf16 matrix pipe: `achieved` / `peak` / `frac` then refer to that pipe, and
-    `fp32_equivalent_tflops` says what the same result would need of the fp32 pipe (157.3 TFLOP/s peak)."""
+    form the kernel executes three fp16 products per product (operands as two fp16 planes; on 128 of the merge
+    layer's reduction indices: pairs of k-tiles) on the fp16 matrix pipe: `achieved` / `peak` / `frac` then refer
+    to that pipe, and `fp32_equivalent_tflops` says what the same result would need of the fp32 pipe (157.3 TFLOP/s
+    peak)."""
     out = {"bound": "mfma", "kernel": "k_merge_conv [g expansion, search form]", "unit": "TFLOP/s",
            "avg_launch_us": seconds * 1e6, "flop_per_launch": flop, "fp32_equivalent_tflops": flop / seconds / 1e12,
            "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS}
     if getattr(nets, "split_merge_conv", False):
         kp32 = (nets.merge_t_perm.Kp + 31) // 32 * 32
-        executed = 6.0 * (2.0 * G * kp32 * D + 2.0 * G * A * hw * C * 32)
-        out.update({"kernel": "k_merge_conv_bf [g expansion, search form: operands as three bf16 planes, six products]",
+        executed = 3.0 * (2.0 * G * kp32 * D + 2.0 * G * A * hw * C * 32)
+        out.update({"kernel": "k_merge_conv_bf [g expansion, search form: operands as two fp16 planes, three products]",
                     "achieved": executed / seconds / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
-                    "frac": executed / seconds / 1e12 / BF16_MFMA_PEAK_TFLOPS, "executed_bf16_flop_per_launch": executed})
+                    "frac": executed / seconds / 1e12 / BF16_MFMA_PEAK_TFLOPS, "executed_f16_flop_per_launch": executed,
+                    "peak_note": "dense fp16 matrix peak (the same 2500 TFLOP/s as bf16); achieved = executed fp16 flops"})
     else:
         out.update({"achieved": flop / seconds / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                     "frac": flop / seconds / 1e12 / MFMA_F32_PEAK_TFLOPS})
