@@ -373,12 +373,14 @@ int mz_conv_direct_nhwc(const float *x, const float *weight_kmajor, const float 
                         int32_t W, int32_t Cin, int32_t Cout, int32_t KS, int32_t stride, int32_t pad,
                         int32_t activation, float *y, void *stream);
 
-/* The same convolutions at the bf16 matrix rate with float32 accuracy.  A float32 value is the exact
- * sum of three bf16 terms (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)); a product x*w is,
- * up to relative 2^-24, the sum of the six bf16 products x1w1, x1w2, x2w1, x1w3, x2w2, x3w1, which
- * v_mfma_f32_16x16x32_bf16 accumulates in float32 -- 16/6 of the fp32 matrix rate.  Operands are kept
- * in that split form: three bf16 planes (u16 bit patterns), plane p at element offset p * plane_stride.
- *   mz_split3 / mz_unsplit3   float32 <-> planes, element-wise;
+/* The same convolutions at the fp16 matrix rate with float32 accuracy.  A float32 value v is held as two
+ * fp16 terms, hi = fp16(v) and lo = fp16((v - hi) * 2^11) (v = hi + lo * 2^-11 to 2^-22 |v|); a product x*w is,
+ * up to the lo*lo term of relative size 2^-22, 2^-11 (x_hi (w_hi 2^11) + x_hi w_lo + x_lo w_hi): three
+ * v_mfma_f32_16x16x32_f16 into one float32 accumulator -- 16/3 of the fp32 matrix rate.  Operands must stay
+ * below 65504 in magnitude (weights below 32): beyond that the results are NaN, not silently wrong.  Split operands
+ * in memory are TWO planes of fp16 bit patterns (u16), plane p at element offset p * plane_stride (the "3" in the
+ * entry names is historical: it stood for three bf16 planes).
+ *   mz_split3 / mz_unsplit3   float32 <-> planes, element-wise (the planes hold 22 significant bits);
  *   mz_nchw_split3            mz_nchw_to_nhwc and mz_split3 in one pass: the channels-first network input
  *       f32[G][C][P] (the argument of RepresentationNetwork.forward, neural_network.py:83) -> planes [G * P][C];
  *   mz_conv3_forward          nn.Conv2d as in mz_wide_forward_gather: x3 planes [input pixels][C], idx the
@@ -421,9 +423,10 @@ int mz_unsplit3(const uint16_t *x3, int64_t plane_stride, int64_t total, float *
 int mz_conv3_forward(const uint16_t *x3, int64_t x_plane, int32_t C, const int32_t *idx, int32_t taps,
                      const uint16_t *w3, int64_t w_plane, const float *bias, int32_t activation, float *y,
                      uint16_t *y3, int64_t y_plane, int32_t rows, int32_t N, double *block_sums, void *stream);
-/* mz_conv3_forward on float32 input rows x[input pixels][C], split while they are staged: 4 bytes per value instead
- * of the planes' 6 and whole 128-byte lines per gathered chunk (the strided ConvLayers, network_builder.py:33-60,
- * whose input nothing else reads in split form).  Identical bits to mz_split3 + mz_conv3_forward. */
+/* mz_conv3_forward on float32 input rows x[input pixels][C], split while they are staged: whole 128-byte lines per
+ * gathered chunk instead of two 64-byte pieces, and no split copy in memory (the strided ConvLayers,
+ * network_builder.py:33-60, whose input nothing else reads in split form).  Identical bits to mz_split3 +
+ * mz_conv3_forward. */
 int mz_conv3_forward_f32(const float *x, int32_t C, const int32_t *idx, int32_t taps, const uint16_t *w3, int64_t w_plane,
                          const float *bias, int32_t activation, float *y, uint16_t *y3, int64_t y_plane, int32_t rows,
                          int32_t N, double *block_sums, void *stream);
@@ -698,8 +701,8 @@ int mz_merge_conv_forward(const mz_packed_layer *h_merge, const mz_packed_layer 
                           const float *t, int64_t ld_t, const int32_t *t_rows, const float *table,
                           const int32_t *action, int32_t A, int32_t B, int32_t C, int32_t HW, float *Y,
                           void *stream);
-/* The same pass at the bf16 matrix rate with float32 accuracy: every float32 operand is split exactly into three
- * bf16 terms and a product evaluated as the six bf16 products of relative size >= 2^-24 in float32 accumulators
+/* The same pass at the fp16 matrix rate with float32 accuracy: every float32 operand is held as two fp16 terms
+ * (hi, lo * 2^11, as the convolutions above) and a product evaluated as three fp16 products in one float32 accumulator
  * (results equal mz_merge_conv_forward's to within 1e-6 of their scale, tests/test_gpu_towers.py; no
  * counterpart in the reference, which evaluates these layers in float32).  merge3 / conv3: the two layers' weights
  * as split operands, written once per weight update by mz_packed_split3 from the packed float32 layers

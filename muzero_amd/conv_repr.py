@@ -8,9 +8,9 @@ adaptive average pool -- on channels-last activations:
 * a convolution is ONE matrix product on the matrix cores (rows = output pixels of all games,
   reduction = (tap, input channel), A operand gathered through a pixel index table, bias and
   activation in the epilogue).  Layers with input channels a multiple of 64 and output channels a
-  multiple of 128 -- all the heavy ones -- run at the bf16 matrix rate with float32 accuracy
-  (`mz_conv3_forward`: every float32 operand is the exact sum of three bf16 terms, six bf16 products
-  per float32 product, float32 accumulation; activations stay in that split form between layers);
+  multiple of 128 -- all the heavy ones -- run at the fp16 matrix rate with float32 accuracy
+  (`mz_conv3_forward`: every float32 operand is held as two fp16 terms, three fp16 products per float32
+  product into one float32 accumulator; the kernels split float32 activations while they stage them);
   other layers with 64-multiple input channels use the fp32 matrix instruction
   (`mz_wide_forward_gather`), the rest (few input channels) the direct kernel.
   Stride-1 "same" convolutions among them (the ResBlock convolutions) stage the contiguous pixel
@@ -19,7 +19,7 @@ adaptive average pool -- on channels-last activations:
   `fast_convolutions=False` keeps everything on the fp32 instruction;
 * every BatchNorm2d normalises with the statistics of ONE game, because the reference calls h with
   batch size 1 and never leaves train mode (src/training_data_generator.py:117, main.py:39 only
-  disables grad): `mz_bn_stats` per (game, channel) -- or, after a split-bf16 convolution whose games
+  disables grad): `mz_bn_stats` per (game, channel) -- or, after a split-product convolution whose games
   are whole 64-pixel blocks, `mz_bn_stats_from_sums` on the block sums the convolution's epilogue left,
   without another pass over its output (`fused_statistics=False` keeps the separate pass) --
   and `mz_bn_apply` with the residual sum and the activation of the block fused in; inside a block
@@ -77,8 +77,8 @@ class _Conv:
         # the matrix product pads the output channels to 16: still far cheaper than one lane per output value
         # once the reduction is long
         self.matrix = self.cin % 64 == 0
-        self.fast = self.cin % 64 == 0 and self.cout % 128 == 0 and self.k <= 4   # split-bf16 product (mz_conv3_forward)
-        self.w3 = None        # i16[3][cout * k * k * cin]: the split k-major weight
+        self.fast = self.cin % 64 == 0 and self.cout % 128 == 0 and self.k <= 4   # split-fp16 product (mz_conv3_forward)
+        self.w3 = None        # i16[2][cout * k * k * cin]: the split k-major weight (fp16 hi and lo planes)
         self.plan = None      # _hip.PackedLayer (matrix form)
         self.wk = None        # f32[cout][k][k][cin]
         self.bias = None
@@ -107,7 +107,7 @@ class ConvRepresentation:
                  fused_input_bn: bool = True, fused_block_output: bool = True, f32_gather: bool = True):
         self.src = repr_net
         # the strided convolutions gather float32 rows and split them while staging (mz_conv3_forward_f32): their
-        # producers then write 4 bytes per value instead of three bf16 planes; identical bits either way
+        # producers then write the float32 value only, no split planes; identical bits either way
         self.f32_gather = f32_gather
         self.fused_input_bn = fused_input_bn
         # a ResBlock's bn2 + skip sum + activation applied while the NEXT block's conv1 stages its input (which also
@@ -259,7 +259,7 @@ class ConvRepresentation:
         return t
 
     # ---- layers -------------------------------------------------------------------------------
-    # An activation is held as float32 [G, H, W, C] (`f`), as three bf16 planes i16[3, G*H*W*C] (`s`), or
+    # An activation is held as float32 [G, H, W, C] (`f`), as two fp16 planes i16[2, G*H*W*C] (`s`), or
     # both; whichever form a consumer lacks is made on demand.
     class _Act:
         __slots__ = ("f", "s", "n", "sums")
@@ -289,7 +289,7 @@ class ConvRepresentation:
 
     def _conv(self, a, G, H, W, cv: _Conv, name: str, split_out: bool = False, sums: bool = False, pre=None, block=None):
         """a: input activation [G, H, W, cin] -> (output activation, Ho, Wo).  The output is float32
-        unless `split_out` and the layer runs on the split-bf16 product (then split only).
+        unless `split_out` and the layer runs on the split-fp16 product (then split only).
         `sums`: where the kernel can, also leave the column sums of every 64-row block in `out.sums`
         (the BatchNorm statistics that follow then need no pass over the output).
         `pre` = (scale, shift, activation): `a` is the raw float32 output of the previous convolution and

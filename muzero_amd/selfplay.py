@@ -203,7 +203,7 @@ class SelfPlayEngine:
 
         `root_form`: with a representation network that ends in a 1x1 convolution of a few channels, a
         residual-tower search starts from those channels' pooled values: h's final convolution is composed
-        into the first layers of g and f, and the root expansion runs on the bf16-split merge kernel.  Its
+        into the first layers of g and f, and the root expansion runs on the split (two fp16 planes) merge kernel.  Its
         network outputs agree with the reference-ordered float32 evaluation to 1e-5 of their scale, a bound
         and not bit parity: a selection or a greedy action that two candidates tie for to that precision
         may fall the other way.  False keeps the roots as full latents through the plain kernels.

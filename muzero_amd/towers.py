@@ -82,7 +82,7 @@ class TowerNetworks:
         # a few values as g's outputs are, and the root expansion can run in the bottleneck form too (`root_form`)
         self.root_final = root_final
         self.fuse_merge_conv = fuse_merge_conv  # False keeps fc_merge and the tower of g as separate kernels
-        # the fused pass on operands split into three bf16 terms each: float32 accuracy at the bf16 matrix rate
+        # the fused pass on operands split into two fp16 terms each: float32 accuracy at the fp16 matrix rate
         # (MZ_MC_SPLIT=0: float32 matrix instructions)
         self.split_merge_conv = os.environ.get("MZ_MC_SPLIT", "1") != "0"
         # source rows from which the fused form is used (default: always; 256 trees 1.33 -> 1.41 M sims/s, the
@@ -336,7 +336,7 @@ class TowerNetworks:
                 _hip.check(lib.mz_wide_pack(C.byref(src), C.byref(pl), ptr(self.blob), _stream()), "mz_wide_pack")
             else:
                 _hip.check(lib.mz_mlp_pack(C.byref(src), C.byref(pl), ptr(self.blob), _stream()), "mz_mlp_pack")
-        # the fused fc_merge + first-convolution pass at the bf16 matrix rate: its layers as three bf16 planes
+        # the fused fc_merge + first-convolution pass at the fp16 matrix rate: its layers as two fp16 planes
         self.split3 = {}
         if self.fused_g and self.split_merge_conv:
             for name in ("merge_t_perm", "conv_g", "merge_root_perm"):

@@ -57,7 +57,7 @@ def _close(got, want, tol=1e-5):
     np.testing.assert_allclose(got.double().cpu().numpy(), want, rtol=tol, atol=tol * float(np.abs(want).max()))
 
 
-@pytest.mark.parametrize("fast", [True, False], ids=["split-bf16", "fp32-only"])
+@pytest.mark.parametrize("fast", [True, False], ids=["split-fp16", "fp32-only"])
 @pytest.mark.parametrize("case", ["direct-small", "matrix-64", "mixed-strides", "avgpool-tanh", "pointwise-pooled", "wide-128"])
 def test_conv_representation_matches_torch_per_game(case, fast):
     from muzero_amd.conv_repr import ConvRepresentation
@@ -73,7 +73,7 @@ def test_conv_representation_matches_torch_per_game(case, fast):
     elif case == "avgpool-tanh":    # average pooling layer, sigmoid / tanh activations, non-square-divisible adaptive pool
         h = _net((2, 14, 14), (6, 3, 3), 1, [_cv(8, 3, 1, 1, act="sigmoid"), _pool(2, 2, "avg"), _rb(6, act="tanh")], [])
         G, obs = 4, (2, 14, 14)
-    elif case == "wide-128":        # 128 / 256-channel layers: the split-bf16 product everywhere (3x3, 2x2 stride 2, 1x1 skip, tanh)
+    elif case == "wide-128":        # 128 / 256-channel layers: the split-fp16 product everywhere (3x3, 2x2 stride 2, 1x1 skip, tanh)
         h = _net((2, 16, 16), (256, 2, 2), 31, [_cv(128, 2, 2, 0), _rb(128), _rb(256, act="tanh"), _cv(256, 3, 1, 1, act="sigmoid"),
                                                  _rb(256, k=3, s=2, p=1)], [])
         G, obs = 3, (2, 16, 16)
@@ -205,7 +205,7 @@ def _shipped_h():
                 [_rb(3)], seed=3)
 
 
-@pytest.mark.parametrize("fast", [True, False], ids=["split-bf16", "fp32-only"])
+@pytest.mark.parametrize("fast", [True, False], ids=["split-fp16", "fp32-only"])
 def test_shipped_representation_network_256_games(fast):
     """The shipped CarRacing h (32-frame history of 3x96x96 -> latent [256, 6, 6]) for 256 games in one
     call against the torch module called once per game on the GPU (float32, MIOpen)."""

@@ -1051,9 +1051,9 @@ def test_root_form_advances_running_statistics_like_the_plain_form():
 
 
 @pytest.mark.parametrize("rows", [5, 300, 4096])
-def test_merge_conv_on_bf16_planes_equals_the_fp32_form(rows):
-    """mz_merge_conv_forward_split (every float32 operand as three bf16 terms, six bf16 products per product in
-    float32 accumulators) against mz_merge_conv_forward (fp32 matrix instructions) on the shipped shape: the
+def test_merge_conv_on_split_planes_equals_the_fp32_form(rows):
+    """mz_merge_conv_forward_split (every float32 operand as two fp16 terms, three fp16 products per product in
+    one float32 accumulator) against mz_merge_conv_forward (fp32 matrix instructions) on the shipped shape: the
     products Y agree to 1e-6 of their scale, for the expansion (all actions) and for one action per row, ragged row
     counts and gathered rows; and against a float64 evaluation both are equally close."""
     import ctypes as C
@@ -1118,7 +1118,7 @@ def nets_latent_from_t(nets, g, t64):
 @pytest.mark.parametrize("G", [256, 4096])
 def test_tower_search_in_the_benchmarked_form(G):
     """The tower search exactly as bench.py times it (bench.py: tower_search): roots given as the bottleneck values
-    of h's final convolution (`root_t`), no stored latents, fc_merge fused with the first convolution on bf16 planes,
+    of h's final convolution (`root_t`), no stored latents, fc_merge fused with the first convolution on split planes,
     50 simulations, at 256 and at 4096 trees:
       (i)   launch by launch with tracing: the search's own network outputs replayed through the CPU tree oracle give
             EVERY tree bit for bit; the whole-search graph replay leaves the same pool;
