@@ -477,3 +477,30 @@ def test_staged_convolution_applies_the_previous_batchnorm_bit_for_bit():
                                                 N, None, None), "mz_conv3_same_bn_forward")
         torch.cuda.synchronize()
         assert torch.equal(got, want), (G, H, W, Cin, N)
+
+
+def test_operands_beyond_the_fp16_range_are_loud():
+    """The split-product kernels hold an operand as two fp16 terms: a value beyond 65504 has no such form.  The result
+    is then non-finite -- visible -- and never a wrong finite number; values just inside the range are exact to the
+    usual tolerance."""
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    G, H, W, Cin, N = 1, 8, 8, 64, 128
+    rows = G * H * W
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    w = torch.randn(N * 9 * Cin, device="cuda", generator=gen) * 0.05
+    w3 = torch.empty((2, w.numel()), dtype=torch.int16, device="cuda")
+    _hip.check(lib.mz_split3(ptr(w), w.numel(), ptr(w3), w3.shape[1], None), "mz_split3")
+    for peak, finite in ((6.0e4, True), (1.0e5, False)):
+        x = torch.rand(rows * Cin, device="cuda", generator=gen)
+        x[5 * Cin + 3] = peak
+        y = torch.empty(rows * N, device="cuda")
+        _hip.check(lib.mz_conv3_same_bn_forward(ptr(x), None, None, 0, Cin, G, H, W, 3, ptr(w3), w3.shape[1], None, 0, ptr(y), None, 0,
+                                                N, None, None), "mz_conv3_same_bn_forward")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y).all()) == finite
+        if finite:
+            ref = torch.nn.functional.conv2d(x.view(G, H, W, Cin).permute(0, 3, 1, 2).double().cpu(),
+                                             w.view(N, 3, 3, Cin).permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1)
+            _close(y, ref)
