@@ -341,7 +341,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
         for (int dy = -pad; dy <= pad; ++dy)
             for (int dx = -pad; dx <= pad; ++dx, ++tap) {
                 const bool in = row < rows && h + dy >= 0 && h + dy < H && w + dx >= 0 && w + dx < W;
-                dst[tap * (4 * 16 * 4)] = (unsigned short)(in ? r + reach + dy * W + dx : cap);
+                dst[tap * (4 * 16 * 4)] = (unsigned short)lds_off(in ? r + reach + dy * W + dx : cap, 0);  // (below 64 Ki: cap <= 640)
             }
     }
     if (tid < 4 * kPA) *reinterpret_cast<u32x4 *>(s_halo + (tid >> 2) * kHaloPlane + cap * kARow + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -459,15 +459,21 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
             *reinterpret_cast<u32x4 *>(s_halo + kHaloPlane + lds_off(slot, pc)) = lo;
         }
     };
-    auto fetch_b = [&](int s) {
-        const int chunk = s / taps, tap = s - chunk * taps;
-        const int kk = tap * C + chunk * kTK + pc * 8;
+    // the weights of consecutive steps, one call per step (tap innermost); the last step's are requested again
+    // past the end (harmless: a step is one straight-line block)
+    const unsigned short *wrow = w3 + (long long)(n0 + rb) * K + pc * 8;
+    int f_tap = 0, f_chunk = 0;
+    auto fetch_b_next = [&]() {
+        const int kk = f_tap * C + f_chunk * kTK;  // (wave-uniform)
 #pragma unroll
-        for (int p = 0; p < kPW; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(w3 + p * w_plane + (long long)(n0 + rb) * K + kk);
+        for (int p = 0; p < kPW; ++p) gb[p] = *reinterpret_cast<const u32x4 *>(wrow + p * w_plane + kk);
+        if (f_tap + 1 < taps) ++f_tap;
+        else if (f_chunk + 1 < chunks) f_tap = 0, ++f_chunk;
     };
+    const int b_off = lds_off(rb, pc);
     auto stash_b = [&](int stage) {
 #pragma unroll
-        for (int p = 0; p < kPW; ++p) *reinterpret_cast<u32x4 *>(s_b + stage * kBStage + p * (kTN * kARow) + lds_off(rb, pc)) = gb[p];
+        for (int p = 0; p < kPW; ++p) *reinterpret_cast<u32x4 *>(s_b + stage * kBStage + p * (kTN * kARow) + b_off) = gb[p];
     };
 
     f32x4 acc[4][4];
@@ -477,14 +483,14 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     fetch_halo(0);
-    fetch_b(0);
+    fetch_b_next();
     if constexpr (RAW) __syncthreads();  // the scale / shift rows are in place
     for_each_index(std::make_integer_sequence<int, 2 * NJ>{}, [&](auto k_tag) __attribute__((always_inline)) { convert_piece(0, k_tag); });
     write_halo();
     stash_b(0);
-    fetch_b(min(1, steps - 1));
+    fetch_b_next();
     stash_b(1);
-    fetch_b(min(2, steps - 1));  // stored by step 0
+    fetch_b_next();  // (the weights of step 2) stored by step 0
     __syncthreads();
     // The step loop is software-pipelined through the operand registers: every LDS read of step s + 1 is issued
     // during the matrix instructions of step s, into the register whose operand has just been multiplied for the
@@ -504,10 +510,11 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
     int bo[4], ao[4], an[4];  // LDS offsets of the weight operands, of the pixel operands read in this step, in the next
 #pragma unroll
     for (int t = 0; t < 4; ++t) bo[t] = lds_off(wn * 64 + t * 16 + m, kg);
+    // the table holds the byte offset of a slot's piece 0; piece kg of the same row is that XOR 16 kg (lds_off)
     auto a_offsets = [&](int tap, int (&dst)[4]) {
         const uint2 sl = *reinterpret_cast<const uint2 *>(s_slot + ((tap * 4 + wm) * 16 + m) * 4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dst[t] = lds_off((int)((t < 2 ? sl.x : sl.y) >> (16 * (t & 1))) & 0xffff, kg);
+        for (int t = 0; t < 4; ++t) dst[t] = ((int)((t < 2 ? sl.x : sl.y) >> (16 * (t & 1))) & 0xffff) ^ (kg << 4);
     };
     auto read_a = [&](int plane, int t) { return *reinterpret_cast<const h8 *>(s_halo + plane * kHaloPlane + ao[t]); };
     auto read_b = [&](int plane, int stage, int t) {
@@ -554,7 +561,7 @@ k_conv3_same(const unsigned short *__restrict__ x3, long long x_plane, const flo
                     // s + 2, the request for those of step s + 3
                     if (!(MZ_CONV3_SKIP & 8)) {
                         stash_b(st2);
-                        fetch_b(min(s + 3, steps - 1));
+                        fetch_b_next();  // (step s + 3)
                     }
                     // the next chunk's pixel range: in flight behind the taps of this chunk.  Requested BEHIND the
                     // weights: loads return in order, and these come from memory -- in front they would hold the weights back
