@@ -57,68 +57,52 @@ using namespace mzs;
 namespace {
 
 
-struct SeqLds {
-    int ld_d, ld_p, ld_q, ld_v, ld_l, tab_rows;
-    // byte offsets.  xi: split image of the current input latents (leaf, drawn child, rollout latent in turn);
-    // z / zs: merge pre-activations of the leaf / of the drawn child (fp32 rows); h1: policy layer 1 of leaf
-    // (tile 0) and child (tile 1), split image; h2: policy layer 2 of leaf and child, likewise; r: split images
-    // of a pass's row tiles, over h1 | h2 (dead by then); hv: value layer 1 (split image); lg: logits / policies
-    // of the 32 rows; dote / dotv: partial sums of the folded layers; bias*: padded biases; dw*: the folded
-    // one-output layers' weights by k.  After the last round everything from `xi` up to `b_p0` is one arena for the
-    // children's rewards: ew holds every column tile of reward 1 (as packed: two fp16 planes per k-chunk)
-    size_t ew;
-    size_t xi, z, zs, tab, h1, h2, r, hv, lg, dote, dotv, b_p0, b_m, b_p1, b_v0, b_v1, b_r0, dw_v, dw_r, b_p2, prior, rew, roll, ints, path,
-        tabs, total;
+// LDS layout.  Every offset is a compile-time constant of the instantiation (k-chunk counts): buffers whose size
+// depends on run-time values -- action count, head widths -- are laid out for the largest values the kernel accepts
+// (8 actions, 16 column tiles per layer, 8 in value 2 / reward 1), so the kernel addresses LDS with literals instead
+// of two dozen run-time bases held in (spilled) scalar registers; only the square-root / logarithm tables, whose
+// length is a launch parameter, follow at the end.
+//   xi: split image of the current input latents (leaf, drawn child, rollout latent in turn); z / zs: merge
+//   pre-activations of the leaf / of the drawn child (fp32 rows); h1: policy layer 1 of leaf (tile 0) and child
+//   (tile 1), split image; h2: policy layer 2 of leaf and child, likewise; hv: value layer 1 (split image); lg:
+//   logits / policies of the 32 rows; dote / dotv: partial sums of the folded layers; b_*: padded biases; dw_*: the
+//   folded one-output layers' weights by k.  After the last round everything from `xi` up to `dote` is one arena for
+//   the children's rewards: ew holds every column tile of reward 1 (as packed: two fp16 planes per k-chunk).
+constexpr int kSeqMaxA = 8, kSeqMaxTiles = 2 * kWaves, kSeqMaxFoldTiles = kWaves;
+template <int KCD, int KCP, int KCV>
+struct SeqLayout {
+    static constexpr int ld_d = KCD * 32 + 4, ld_p = KCP * 32 + 4, ld_q = KCP * 32 + 4, ld_v = KCV * 32 + 4, ld_l = 32 + 4;
+    static constexpr size_t a16(size_t v) { return (v + 15) & ~(size_t)15; }
+    static constexpr size_t tile_d = sizeof(float) * kTrees * ld_d;
+    static constexpr size_t tab = sizeof(float) * kLdsReserve;
+    static constexpr size_t xi = a16(tab + sizeof(float) * kSeqMaxA * ld_d);  // row tile 0: leaf (later the rollout latent), row tile 1: drawn child
+    static constexpr size_t ew = xi;
+    static constexpr size_t z = a16(xi + 2 * tile_d);
+    static constexpr size_t zs = a16(z + tile_d);
+    static constexpr size_t h1 = a16(zs + tile_d);
+    static constexpr size_t h2 = a16(h1 + sizeof(float) * 2 * kTrees * ld_p);
+    static constexpr size_t hv = a16(h2 + sizeof(float) * 2 * kTrees * ld_q);
+    static constexpr size_t lg = a16(hv + sizeof(float) * kTrees * ld_v);
+    static constexpr size_t dote = a16(lg + sizeof(float) * 2 * kTrees * ld_l);
+    static constexpr size_t ew_bytes = sizeof(float) * (size_t)(16 * kSeqMaxFoldTiles) * (KCD * 32);  // reward 1 at its widest
+    static_assert(ew + ew_bytes <= dote, "the arena of the phase after the rounds fits in front of the small buffers");
+    static constexpr size_t dotv = a16(dote + sizeof(float) * 4 * kSeqMaxFoldTiles * kTrees);
+    static constexpr size_t b_p0 = a16(dotv + sizeof(float) * 4 * kSeqMaxFoldTiles * kTrees);
+    static constexpr size_t b_m = b_p0 + sizeof(float) * 16 * kSeqMaxTiles;
+    static constexpr size_t b_p1 = b_m + sizeof(float) * 16 * kSeqMaxTiles;
+    static constexpr size_t b_v0 = b_p1 + sizeof(float) * 16 * kSeqMaxTiles;
+    static constexpr size_t b_v1 = b_v0 + sizeof(float) * 16 * kSeqMaxTiles;           // + the one-output layer's bias
+    static constexpr size_t b_r0 = b_v1 + sizeof(float) * (16 * kSeqMaxFoldTiles + 4);
+    static constexpr size_t dw_v = b_r0 + sizeof(float) * (16 * kSeqMaxFoldTiles + 4);
+    static constexpr size_t dw_r = dw_v + sizeof(float) * 16 * kSeqMaxFoldTiles;
+    static constexpr size_t b_p2 = dw_r + sizeof(float) * 16 * kSeqMaxFoldTiles;
+    static constexpr size_t prior = b_p2 + sizeof(float) * 16;
+    static constexpr size_t roll = prior + sizeof(float) * kTrees * kSeqMaxA;
+    static constexpr size_t ints = roll + sizeof(float) * kTrees * 2;
+    static constexpr size_t path = ints + sizeof(int) * kTrees * 8;
+    static constexpr size_t tabs = a16(path + sizeof(int) * kTrees * kPathCap);
+    static constexpr size_t total(int tab_len) { return tabs + sizeof(double) * 2 * tab_len; }
 };
-
-__host__ __device__ inline SeqLds seq_layout(const mz_packed_nets &P, int tab_len) {
-    SeqLds L;
-    const int A = P.A;
-    L.ld_d = lds_stride(P.D);
-    L.ld_p = lds_stride(P.policy.layer[0].N);
-    L.ld_q = lds_stride(P.policy.layer[1].N);
-    L.ld_v = lds_stride(P.value.layer[0].N);
-    L.ld_l = lds_stride(A);
-    L.tab_rows = A;
-    size_t off = sizeof(float) * kLdsReserve;
-    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
-    const size_t tile_d = sizeof(float) * kTrees * L.ld_d;
-    L.tab = take(sizeof(float) * L.tab_rows * L.ld_d);
-    const size_t arena = off;
-    L.xi = take(2 * tile_d);  // row tile 0: leaf (later the rollout latent), row tile 1: drawn child
-    L.z = take(tile_d);
-    L.zs = take(tile_d);
-    L.h1 = take(sizeof(float) * 2 * kTrees * L.ld_p);
-    L.h2 = take(sizeof(float) * 2 * kTrees * L.ld_q);
-    L.r = L.h1;
-    L.hv = take(sizeof(float) * kTrees * L.ld_v);
-    L.lg = take(sizeof(float) * 2 * kTrees * L.ld_l);
-    L.dote = take(sizeof(float) * dot_floats(P.reward.layer[0].Np >> 4, kTrees));
-    L.dotv = take(sizeof(float) * dot_floats(P.value.layer[1].Np >> 4, kTrees));
-    {   // the arena of the phase after the rounds
-        size_t eo = arena;
-        auto etake = [&](size_t bytes) { size_t o = eo; eo = align16(eo + bytes); return o; };
-        L.ew = etake(sizeof(float) * (size_t)P.reward.layer[0].Np * P.reward.layer[0].Kp);
-        if (off < eo) off = eo;
-    }
-    L.b_p0 = take(sizeof(float) * P.policy.layer[0].Np);
-    L.b_m = take(sizeof(float) * P.merge.layer[0].Np);
-    L.b_p1 = take(sizeof(float) * P.policy.layer[1].Np);
-    L.b_v0 = take(sizeof(float) * P.value.layer[0].Np);
-    L.b_v1 = take(sizeof(float) * (P.value.layer[1].Np + 4));   // + the one-output layer's bias
-    L.b_r0 = take(sizeof(float) * (P.reward.layer[0].Np + 4));
-    L.dw_v = take(sizeof(float) * P.value.layer[1].Np);
-    L.dw_r = take(sizeof(float) * P.reward.layer[0].Np);
-    L.b_p2 = take(sizeof(float) * P.policy.layer[2].Np);
-    L.prior = take(sizeof(float) * kTrees * A);
-    L.rew = take(sizeof(float) * kTrees * (A + 1));
-    L.roll = take(sizeof(float) * kTrees * 2);
-    L.ints = take(sizeof(int) * kTrees * 8);
-    L.path = take(sizeof(int) * kTrees * kPathCap);
-    L.tabs = take(sizeof(double) * 2 * tab_len);
-    L.total = off;
-    return L;
-}
 
 // One ring slot: a whole column tile of a matrix layer (up to KMAX k-chunks x two planes of 16 bytes per lane).
 template <int KMAX>
@@ -268,36 +252,37 @@ __device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int 
 // STORE: the pool keeps every node's latent (written from the root rows and in the phase after the rounds)
 template <int KCD, int KCP, int KCV, bool STORE>
 __global__ void __launch_bounds__(kThreads)
-k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q, SeqLds L,
+k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q,
              double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
              int32_t *__restrict__ visits) {
     constexpr int KMAX = KCD > KCP ? (KCD > KCV ? KCD : KCV) : (KCP > KCV ? KCP : KCV);
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    lds_f *XI = to_lds(smem_raw + L.xi);
-    lds_f *Z = to_lds(smem_raw + L.z);
-    lds_f *Zs = to_lds(smem_raw + L.zs);
-    lds_f *Tab = to_lds(smem_raw + L.tab);
-    lds_f *H1 = to_lds(smem_raw + L.h1);
-    lds_f *H2 = to_lds(smem_raw + L.h2);
-    lds_f *Hv = to_lds(smem_raw + L.hv);
-    lds_f *Lg = to_lds(smem_raw + L.lg);
-    lds_f *DotE = to_lds(smem_raw + L.dote);
-    lds_f *DotV = to_lds(smem_raw + L.dotv);
-    lds_f *Bp0 = to_lds(smem_raw + L.b_p0), *Bm = to_lds(smem_raw + L.b_m), *Bp1 = to_lds(smem_raw + L.b_p1);
-    lds_f *Bv0 = to_lds(smem_raw + L.b_v0), *Bv1 = to_lds(smem_raw + L.b_v1), *Br0 = to_lds(smem_raw + L.b_r0);
-    lds_f *DwV = to_lds(smem_raw + L.dw_v), *DwR = to_lds(smem_raw + L.dw_r);
-    lds_f *Bp2 = to_lds(smem_raw + L.b_p2);
-    lds_f *s_prior = to_lds(smem_raw + L.prior);
-    lds_f *s_roll = to_lds(smem_raw + L.roll);
-    lds_i *s_leaf = to_lds_i(smem_raw + L.ints);
+    using L = SeqLayout<KCD, KCP, KCV>;
+    lds_f *XI = to_lds(smem_raw + L::xi);
+    lds_f *Z = to_lds(smem_raw + L::z);
+    lds_f *Zs = to_lds(smem_raw + L::zs);
+    lds_f *Tab = to_lds(smem_raw + L::tab);
+    lds_f *H1 = to_lds(smem_raw + L::h1);
+    lds_f *H2 = to_lds(smem_raw + L::h2);
+    lds_f *Hv = to_lds(smem_raw + L::hv);
+    lds_f *Lg = to_lds(smem_raw + L::lg);
+    lds_f *DotE = to_lds(smem_raw + L::dote);
+    lds_f *DotV = to_lds(smem_raw + L::dotv);
+    lds_f *Bp0 = to_lds(smem_raw + L::b_p0), *Bm = to_lds(smem_raw + L::b_m), *Bp1 = to_lds(smem_raw + L::b_p1);
+    lds_f *Bv0 = to_lds(smem_raw + L::b_v0), *Bv1 = to_lds(smem_raw + L::b_v1), *Br0 = to_lds(smem_raw + L::b_r0);
+    lds_f *DwV = to_lds(smem_raw + L::dw_v), *DwR = to_lds(smem_raw + L::dw_r);
+    lds_f *Bp2 = to_lds(smem_raw + L::b_p2);
+    lds_f *s_prior = to_lds(smem_raw + L::prior);
+    lds_f *s_roll = to_lds(smem_raw + L::roll);
+    lds_i *s_leaf = to_lds_i(smem_raw + L::ints);
     lds_i *s_child = s_leaf + kTrees;
     lds_i *s_act = s_child + kTrees;    // action of the drawn child
     lds_i *s_act2 = s_act + kTrees;     // greedy action of the rollout step
     lds_i *s_leaf_tp = s_act2 + kTrees;
     lds_i *s_depth = s_leaf_tp + kTrees;
     lds_i *s_root = s_depth + kTrees;
-    int *s_path = reinterpret_cast<int *>(smem_raw + L.path);
-    double *s_tab = reinterpret_cast<double *>(smem_raw + L.tabs);
+    int *s_path = reinterpret_cast<int *>(smem_raw + L::path);
+    double *s_tab = reinterpret_cast<double *>(smem_raw + L::tabs);
 
     __shared__ unsigned long long s_stamp[32];
     unsigned long long t_prev = 0;
@@ -312,7 +297,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     }
 
     const int A = Pk.A, D = Pk.D, S = q.S;
-    const int ld_d = L.ld_d, ld_p = L.ld_p, ld_q = L.ld_q, ld_v = L.ld_v, ld_l = L.ld_l;
+    constexpr int ld_d = L::ld_d, ld_p = L::ld_p, ld_q = L::ld_q, ld_v = L::ld_v, ld_l = L::ld_l;
     const int wave = uni(threadIdx.x >> 6);
     int tid = threadIdx.x, lane = tid & 63;  // (re-derived every round: see the round loop)
     const int g0 = blockIdx.x * kTrees;
@@ -331,7 +316,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         s_tab[i] = q.sqrt_tab[i];
         s_tab[q.tab_len + i] = q.log_tab[i];
     }
-    for (int i = tid; i < L.tab_rows * ld_d; i += kThreads) {
+    for (int i = tid; i < A * ld_d; i += kThreads) {
         const int a = i / ld_d, c = i - a * ld_d;
         Tab[i] = (a < A && c < Pk.Dp) ? blob[Pk.action_table_off + (size_t)a * Pk.Dp + c] : 0.0f;
     }
@@ -770,7 +755,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
-        lds_f *EW = to_lds(smem_raw + L.ew);
+        lds_f *EW = to_lds(smem_raw + L::ew);
         const float b2 = Br0[Lr0.Np];
         __syncthreads();  // the rounds' buffers are dead from here on
         {
@@ -887,15 +872,15 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 }
 
 template <int KCD, int KCP, int KCV, bool STORE>
-int launch_seq(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params &q, const SeqLds &L,
+int launch_seq(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params &q, size_t lds_total,
                double *policy, float *policy32, double *value, int32_t *visits, hipStream_t st) {
     auto kernel = k_search_seq<KCD, KCP, KCV, STORE>;
-    if (L.total > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
-        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_search_seq: cannot enable %zu bytes of LDS: %s", L.total, hipGetErrorString(e));
+    if (lds_total > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
+        if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_search_seq: cannot enable %zu bytes of LDS: %s", lds_total, hipGetErrorString(e));
     }
     const int blocks = (pool->G + kTrees - 1) / kTrees;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), L.total, st, *pool, *plan, blob, q, L, policy, policy32, value, visits);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_total, st, *pool, *plan, blob, q, policy, policy32, value, visits);
     return mz::check_launch("k_search_seq");
 }
 
@@ -925,16 +910,23 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
     if (P.policy.layer[0].Kp != P.merge.layer[0].Kp || P.value.layer[0].Kp != P.merge.layer[0].Kp ||
         P.reward.layer[0].Kp != P.merge.layer[0].Kp)
         return 0;
-    const SeqLds L = seq_layout(P, prm->tab_len);
-    if (L.total > 160 * 1024) return 0;
+    // the strides of the compile-time layout are those of the packed layers (a layer's padded input width is the
+    // padded output width of the one before it)
+    if (lds_stride(P.D) != kcd * 32 + 4 || lds_stride(P.policy.layer[0].N) != kcp * 32 + 4 || lds_stride(P.policy.layer[1].N) != kcp * 32 + 4 ||
+        lds_stride(P.value.layer[0].N) != kcv * 32 + 4 || P.A > kSeqMaxA || prm->tab_len < 0)
+        return 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool store = pool->latent != nullptr;
 #define MZ_SEQ_LAUNCH(A_, B_, C_)                                                                                          \
-    rc = store ? launch_seq<A_, B_, C_, true>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st)             \
-               : launch_seq<A_, B_, C_, false>(pool, plan, blob, *prm, L, policy, policy32, value, visits, st)
-    if (kcd == 6 && kcp == 8 && kcv == 8) MZ_SEQ_LAUNCH(6, 8, 8);
-    else if (kcd == 2 && kcp == 4 && kcv == 4) MZ_SEQ_LAUNCH(2, 4, 4);
+    {                                                                                                                      \
+        const size_t lds_total = SeqLayout<A_, B_, C_>::total(prm->tab_len);                                               \
+        if (lds_total > 160 * 1024) return 0;                                                                              \
+        rc = store ? launch_seq<A_, B_, C_, true>(pool, plan, blob, *prm, lds_total, policy, policy32, value, visits, st)  \
+                   : launch_seq<A_, B_, C_, false>(pool, plan, blob, *prm, lds_total, policy, policy32, value, visits, st);\
+    }
+    if (kcd == 6 && kcp == 8 && kcv == 8) MZ_SEQ_LAUNCH(6, 8, 8)
+    else if (kcd == 2 && kcp == 4 && kcv == 4) MZ_SEQ_LAUNCH(2, 4, 4)
     else return 0;
 #undef MZ_SEQ_LAUNCH
     return rc == MZ_OK ? 1 : rc;
