@@ -1,5 +1,5 @@
 """Turns the counter passes of tools/r2_profiles.sh (gpurun_out/r2p/{fetch,write,sq}) into the two summaries the
-bench line and DESIGN.md cite: profiles/<prefix>_search_pmc_traffic.json (HBM bytes per launch of the search
+bench line cites: profiles/<prefix>_search_pmc_traffic.json (HBM bytes per launch of the search
 kernel: FETCH_SIZE doubled as gfx950 needs for wide coalesced reads, WRITE_SIZE as read) and
 profiles/<prefix>_search_pmc_sq.json (instruction and cycle counters, averaged over the launches seen).
 
