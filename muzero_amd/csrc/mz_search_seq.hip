@@ -745,9 +745,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 
     // ---- rewards of every expansion's children (src/search/expansion.py:29-33) --------------------------------
     // Row-stationary and barrier-free: reward 1's weights (all column tiles) are copied into LDS once; a wave takes
-    // units of up to four children of one expansion, reads its lanes' share of the expansion's merge row from z_pool
-    // once, forms the operand of two children at a time IN REGISTERS (a lane's eight k of row lane & 15 are exactly its
-    // piece of the B operand: no LDS round trip for the activations), multiplies them with every column tile, and folds
+    // pairs of children of one expansion, reads its lanes' share of the expansion's merge row from z_pool (requested
+    // while the previous pair is multiplied), forms the operand of the pair IN REGISTERS (a lane's eight k of row
+    // lane & 15 are exactly its piece of the B operand: no LDS round trip for the activations), multiplies it with
+    // every column tile, and folds
     // the one-output layer as it goes: the four quarter sums of a tile sit in the lanes 16 apart and are added in
     // ascending order through lane exchanges -- finish_dot's order.  Same per-accumulator instruction sequence and
     // epilogue arithmetic as the rounds.
@@ -763,12 +764,15 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             for (int i = tid; i < nr0 * KCD * 128; i += kThreads) *reinterpret_cast<lds_f4 *>(EW + i * 4) = src[i];
         }
         __syncthreads();
-        const int uph = (A + 3) >> 2, units = (S + 1) * uph;
+        // Work items: up to four children of one expansion, multiplied as pairs (2 p, 2 p + 1) -- a last single child
+        // on its own, at half the cost of a pair -- UP = ceil(A / 4) items per expansion.  Items are dealt in blocks of
+        // eight, a wave's position in the block rotating from block to block, so that every wave gets its share of the
+        // cheaper items (with seven actions: four children, then three).
+        const int UP = (A + 3) >> 2, items = (S + 1) * UP;
         const int j = lane & 15, rq = lane >> 4;
-        for (int u = wave; u < units; u += kWaves) {
-            const int ex = u / uph, a0 = (u - ex * uph) * 4;
-            // this lane's part of the expansion's merge row: k = 32 c + 8 rq .. + 7 of tree j
-            f32x4 z0[KCD], z1[KCD];
+        // this lane's part of an expansion's merge row: k = 32 c + 8 rq .. + 7 of tree j
+        f32x4 z0[KCD], z1[KCD];
+        auto load_z = [&](int ex) {
 #pragma unroll
             for (int c = 0; c < KCD; ++c) {
                 const int k0 = 32 * c + 8 * rq;
@@ -786,13 +790,19 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                     }
                 }
             }
-            for (int sp = 0; sp < 2; ++sp) {
-                const int a_first = a0 + 2 * sp;
-                if (a_first >= A) break;
-                h8 xh[2][KCD], xl[2][KCD];
+        };
+        auto item_of = [&](int blk) { return blk * kWaves + ((wave - blk) & (kWaves - 1)); };
+        if (item_of(0) < items) load_z(item_of(0) / UP);
+        for (int blk = 0;; ++blk) {
+            const int v = item_of(blk);
+            if (v >= items) break;
+            const int ex = v / UP, a0 = (v - ex * UP) * 4;
+            auto pass = [&](auto mt_tag, int a_first, bool last) {
+                constexpr int MT = decltype(mt_tag)::value;
+                h8 xh[MT][KCD], xl[MT][KCD];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int a = min(a_first + mt, A - 1);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int a = a_first + mt;
 #pragma unroll
                     for (int c = 0; c < KCD; ++c) {
                         const int k0 = 32 * c + 8 * rq;
@@ -803,7 +813,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                             v0 = f32x4{fmaxf(z0[c].x + b0.x, 0.f), fmaxf(z0[c].y + b0.y, 0.f), fmaxf(z0[c].z + b0.z, 0.f), fmaxf(z0[c].w + b0.w, 0.f)};
                             v1 = f32x4{fmaxf(z1[c].x + b1.x, 0.f), fmaxf(z1[c].y + b1.y, 0.f), fmaxf(z1[c].z + b1.z, 0.f), fmaxf(z1[c].w + b1.w, 0.f)};
                         }
-                        if (STORE && a_first + mt < A && j < trees && k0 < D) {
+                        if (STORE && j < trees && k0 < D) {
                             // every node's latent stored (Node.latent_state, src/search/expansion.py:30-33): this lane's eight values
                             float *dst = p.latent + ((size_t)(g0 + j) * p.cap + 1 + ex * A + a) * D + k0;
                             if ((D & 3) == 0) {
@@ -821,16 +831,22 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                         xl[mt][c] = __builtin_bit_cast(h8, lo);
                     }
                 }
-                float sum[2] = {0.0f, 0.0f};
+                // the item's last operands are formed: the next item's merge row can be on its way during the products
+                const int vn = item_of(blk + 1);
+                if (last && vn < items) load_z(vn / UP);
+                float sum[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sum[mt] = 0.0f;
                 for (int nt = 0; nt < nr0; ++nt) {
-                    f32x4 hi[2], lo[2];
-                    hi[0] = hi[1] = lo[0] = lo[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 hi[MT], lo[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) hi[mt] = lo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     const lds_f *wt = EW + (size_t)nt * KCD * 512 + lane * 4;
 #pragma unroll
                     for (int c = 0; c < KCD; ++c) {
                         const h8 wh = __builtin_bit_cast(h8, lds4(wt + (2 * c) * 256)), wl = __builtin_bit_cast(h8, lds4(wt + (2 * c + 1) * 256));
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
+                        for (int mt = 0; mt < MT; ++mt) {
                             hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[mt][c], hi[mt], 0, 0, 0);
                             lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[mt][c], lo[mt], 0, 0, 0);
                             lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[mt][c], lo[mt], 0, 0, 0);
@@ -838,7 +854,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                     }
                     const f32x4 bb = lds4(Br0 + nt * 16 + 4 * rq), w2 = lds4(DwR + nt * 16 + 4 * rq);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt) {
                         const f32x4 v = epi_value<true>(hi[mt], lo[mt], bb);
                         float part = __fmul_rn(v.x, w2.x);
                         part += __fmul_rn(v.y, w2.y);
@@ -849,11 +865,14 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                     }
                 }
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int a = a_first + mt;
-                    if (rq == 0 && a < A && j < trees)
-                        p.node[(size_t)(g0 + j) * p.cap + 1 + ex * A + a].reward = activate(sum[mt] + b2, Lr1.act);
-                }
+                for (int mt = 0; mt < MT; ++mt)
+                    if (rq == 0 && j < trees)
+                        p.node[(size_t)(g0 + j) * p.cap + 1 + ex * A + a_first + mt].reward = activate(sum[mt] + b2, Lr1.act);
+            };
+            for (int a_first = a0; a_first < min(a0 + 4, A); a_first += 2) {
+                const bool last = a_first + 2 >= min(a0 + 4, A);
+                if (a_first + 1 < A) pass(std::integral_constant<int, 2>{}, a_first, last);
+                else pass(std::integral_constant<int, 1>{}, a_first, last);
             }
         }
         MZ_STAMP(9)  // the children's rewards
