@@ -331,6 +331,24 @@ int mz_repr_pointwise(const float *x, const float *weight, const float *bias, in
 int mz_pick_action(const float *policy, const int8_t *explore, const int32_t *random_action,
                    int32_t G, int32_t A, int32_t *action, void *stream);
 
+/* The random inputs of one lock-step move of G games, drawn on the device in one launch (the reference draws them game
+ * after game from Python's and torch's global generators): rand_child i32[G][draws_per_game], the child every
+ * simulation starts from (src/search/mcts.py:64-66 with expansion.py:35: uniform over the A children; the root
+ * expansion's slot is drawn too); eta f32[G][A], the root's Dirichlet(alpha) noise (mcts.py:85-94); explore i8[G] =
+ * uniform < *epsilon and random_action i32[G] ~ p_random (f32[A], NULL: uniform), the coin and the action of
+ * _select_action (src/training_data_generator.py:148-163).  Counter-based generator (Philox4x32-10): the streams are
+ * a function of (seed, move number, game) only.  state: device i64[2], zero before the first call -- the move
+ * number, advanced by the launch itself (so a recorded launch draws fresh numbers at every replay), and a work
+ * counter; epsilon: device f32[1].  Same distributions as the reference's draws, not the same streams. */
+int mz_move_draws(uint64_t seed, int64_t *state, const float *epsilon, const float *p_random, float alpha, int32_t G,
+                  int32_t A, int32_t draws_per_game, int32_t *rand_child, float *eta, int8_t *explore,
+                  int32_t *random_action, void *stream);
+
+/* End of a lock-step move for G games: step_in_episode[g] += 1; ended[g] = done[g] or the counter reached max_steps
+ * (the episode loop of src/training_data_generator.py:107-142: `for step in range(max_steps_per_episode)` with
+ * `if done: break`); the counter of an ended game returns to 0. */
+int mz_episode_end(const int8_t *done, int32_t *step_in_episode, int32_t max_steps, int32_t G, int8_t *ended, void *stream);
+
 /* Host-only: h_out[j] = gamma^(j-1) for j = 0..w+1 with the C library's pow (the factors
  * _compute_z_targets uses, src/training.py:236-240). */
 int mz_gamma_powers(double gamma, int32_t w, double *h_out);

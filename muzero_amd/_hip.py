@@ -131,6 +131,8 @@ _SIGS = {
                                            _P, _P]),
     "mz_repr_pointwise": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mz_pick_action": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "mz_episode_end": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "mz_move_draws": (C.c_int, [C.c_uint64, _P, _P, _P, C.c_float, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "mz_gamma_powers": (C.c_int, [C.c_double, C.c_int32, _P]),
     "mz_z_targets": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "mz_wide_plan": (C.c_int64, [C.POINTER(Dense), C.c_int64, C.POINTER(PackedLayer)]),

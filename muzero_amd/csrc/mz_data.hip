@@ -96,6 +96,124 @@ __global__ void k_z_targets(const double *__restrict__ R, const double *__restri
 
 inline int grid_for(long long total, int block) { return (int)std::min<long long>((total + block - 1) / block, 65535); }
 
+
+// ---- the random inputs of one lock-step move, drawn on the device in one launch --------------------------------
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): a counter-based generator, so every
+// game reads its own stream (key = seed, counter = move number, game, block) with no state but the move counter.
+struct Philox {
+    uint32_t k0, k1, c0, c1, c2;
+    __device__ void block(uint32_t index, uint32_t (&out)[4]) const {
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = index, a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t h0 = __umulhi(0xD2511F53u, x0), l0 = 0xD2511F53u * x0;
+            const uint32_t h1 = __umulhi(0xCD9E8D57u, x2), l1 = 0xCD9E8D57u * x2;
+            x0 = h1 ^ x1 ^ a, x1 = l1, x2 = h0 ^ x3 ^ b, x3 = l0;
+            a += 0x9E3779B9u, b += 0xBB67AE85u;
+        }
+        out[0] = x0, out[1] = x1, out[2] = x2, out[3] = x3;
+    }
+};
+// sequential 32-bit words of one game's stream
+struct WordStream {
+    const Philox &g;
+    uint32_t index, buf[4];
+    int have;
+    __device__ WordStream(const Philox &gen, uint32_t first_block) : g(gen), index(first_block), have(0) {}
+    __device__ uint32_t next() {
+        if (have == 0) g.block(index++, buf), have = 4;
+        return buf[4 - have--];
+    }
+    __device__ float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }            // [0, 1)
+    __device__ float uniform_open() { return ((float)(next() >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0, 1)
+    __device__ float normal() {  // Box-Muller
+        const float u1 = uniform_open(), u2 = uniform();
+        return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    }
+    // Gamma(alpha, 1), alpha > 0: Marsaglia & Tsang (2000); alpha < 1 through Gamma(alpha + 1) * U^(1 / alpha)
+    __device__ float gamma(float alpha) {
+        const float boost = alpha < 1.0f ? powf(uniform_open(), 1.0f / alpha) : 1.0f;
+        const float a = alpha < 1.0f ? alpha + 1.0f : alpha;
+        const float d = a - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+        for (int tries = 0; tries < 64; ++tries) {
+            const float x = normal(), t = 1.0f + c * x;
+            if (t <= 0.0f) continue;
+            const float v = t * t * t, u = uniform_open();
+            if (u < 1.0f - 0.0331f * x * x * x * x || logf(u) < 0.5f * x * x + d * (1.0f - v + logf(v))) return d * v * boost;
+        }
+        return d * boost;  // (never reached in practice: the acceptance rate is above 0.95)
+    }
+};
+
+// state i64[2]: the move counter (read by every workgroup, advanced by the last one to finish) and the arrival
+// ticket.  One lane per game.
+__global__ void __launch_bounds__(256)
+k_move_draws(unsigned long long seed, long long *__restrict__ state, const float *__restrict__ eps, const float *__restrict__ p_random,
+             float alpha, int G, int A, int S1, int32_t *__restrict__ rand_child, float *__restrict__ eta,
+             int8_t *__restrict__ explore, int32_t *__restrict__ random_action) {
+    const unsigned long long move = (unsigned long long)*reinterpret_cast<volatile long long *>(state);
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) {
+        const Philox gen{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)move, (uint32_t)(move >> 32), (uint32_t)g};
+        {   // the child each simulation starts from (src/search/mcts.py:64-66 with expansion.py:35): uniform over the actions
+            WordStream w(gen, 0);
+            for (int i = 0; i < S1; ++i) rand_child[(size_t)g * S1 + i] = (int32_t)__umulhi(w.next(), (uint32_t)A);
+        }
+        {   // exploration coin and action of _select_action (src/training_data_generator.py:148-163)
+            WordStream w(gen, 0x40000000u);
+            explore[g] = w.uniform() < eps[0] ? 1 : 0;
+            int a = A - 1;
+            if (p_random) {
+                const float u = w.uniform();
+                float cum = 0.0f;
+                for (int i = 0; i < A; ++i) {
+                    cum += p_random[i];
+                    if (u < cum) {
+                        a = i;
+                        break;
+                    }
+                }
+            } else {
+                a = (int)__umulhi(w.next(), (uint32_t)A);
+            }
+            random_action[g] = a;
+        }
+        {   // Dirichlet(alpha) noise of the root (src/search/mcts.py:85-94): normalised Gamma(alpha, 1) draws
+            WordStream w(gen, 0x80000000u);
+            float sum = 0.0f;
+            for (int i = 0; i < A; ++i) {
+                const float v = fmaxf(w.gamma(alpha), 1e-30f);
+                eta[(size_t)g * A + i] = v;
+                sum += v;
+            }
+            for (int i = 0; i < A; ++i) eta[(size_t)g * A + i] /= sum;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long *>(state + 1), 1ULL);
+        if (ticket == (unsigned long long)gridDim.x - 1) {  // every workgroup has read the counter: the next launch sees the next move
+            state[1] = 0;
+            state[0] = (long long)(move + 1);
+        }
+    }
+}
+
+
+// end of a lock-step move: the step counters advance; a game ends when its environment says so or at the step limit
+// (src/training_data_generator.py:107-142: `for step in range(max_steps_per_episode)` / `if done: break`), and the
+// counter of an ended game returns to 0 for its next episode
+__global__ void k_episode_end(const int8_t *__restrict__ done, int32_t *__restrict__ step, int max_steps, int G,
+                              int8_t *__restrict__ ended) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int t = step[g] + 1;
+    const bool e = done[g] != 0 || t >= max_steps;
+    ended[g] = e ? 1 : 0;
+    step[g] = e ? 0 : t;
+}
+
 }  // namespace
 
 extern "C" {
@@ -129,6 +247,23 @@ int mz_pick_action(const float *policy, const int8_t *explore, const int32_t *ra
     hipLaunchKernelGGL(k_pick_action, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, policy, explore,
                        random_action, G, A, action);
     return mz::check_launch("k_pick_action");
+}
+
+int mz_move_draws(uint64_t seed, int64_t *state, const float *epsilon, const float *p_random, float alpha, int32_t G, int32_t A,
+                  int32_t draws_per_game, int32_t *rand_child, float *eta, int8_t *explore, int32_t *random_action, void *stream) {
+    if (!state || !epsilon || !rand_child || !eta || !explore || !random_action || G <= 0 || A <= 0 || draws_per_game <= 0)
+        return mz::fail(MZ_ERR_ARG, "mz_move_draws: NULL argument or non-positive dimension");
+    if (!(alpha > 0.0f)) return mz::fail(MZ_ERR_ARG, "mz_move_draws: the Dirichlet parameter must be positive");
+    hipLaunchKernelGGL(k_move_draws, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed,
+                       reinterpret_cast<long long *>(state), epsilon, p_random, alpha, G, A, draws_per_game, rand_child, eta, explore,
+                       random_action);
+    return mz::check_launch("k_move_draws");
+}
+
+int mz_episode_end(const int8_t *done, int32_t *step_in_episode, int32_t max_steps, int32_t G, int8_t *ended, void *stream) {
+    if (!done || !step_in_episode || !ended || G <= 0) return mz::fail(MZ_ERR_ARG, "mz_episode_end: NULL argument or non-positive dimension");
+    hipLaunchKernelGGL(k_episode_end, dim3((G + 255) / 256), dim3(256), 0, (hipStream_t)stream, done, step_in_episode, max_steps, G, ended);
+    return mz::check_launch("k_episode_end");
 }
 
 int mz_gamma_powers(double gamma, int32_t w, double *h_out) {

@@ -132,7 +132,8 @@ class MoveStreams:
     """The random inputs of one lock-step move of G games: child draws i32[G, S+1], Dirichlet noise f32[G, A],
     exploration coin i8[G] and the uniform action i32[G] (src/training_data_generator.py:107-142 draws them
     from three global generators, game after game).  One numpy Generator on the host (reproducible against
-    a CPU replay), or torch's generator on the device (`device_rng`: the whole move stays on the GPU)."""
+    a CPU replay), or one kernel on the device (`device_rng`: `mz_move_draws`, a counter-based generator keyed by
+    (seed, move number, game) -- the whole move stays on the GPU and costs one launch for all four streams)."""
 
     def __init__(self, G: int, A: int, S: int, config, device, seed: int = 0, device_rng: bool = False):
         self.G, self.A, self.S, self.cfg, self.device = G, A, S, config, torch.device(device)
@@ -140,22 +141,30 @@ class MoveStreams:
         self.rng = np.random.default_rng(seed)
         self.device_rng = device_rng
         if device_rng:
-            self.gen = torch.Generator(device=self.device)
-            self.gen.manual_seed(seed)
-            self._alpha = torch.full((G, A), float(self.alpha), device=self.device)
+            dev = self.device
+            self.seed = int(seed) & (2 ** 64 - 1)
+            self._state = torch.zeros(2, dtype=torch.int64, device=dev)   # move number, work counter (advanced by the kernel)
             p = config.random_action_probability
-            p = np.full(A, 1.0 / A) if p is None else np.asarray(p)
-            self._p_random = torch.as_tensor(p.astype(np.float32)).to(self.device)
+            self._p_random = None if p is None else torch.as_tensor(np.asarray(p, np.float32)).to(dev)
+            self._eps = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._rand = torch.empty((G, S + 1), dtype=torch.int32, device=dev)
+            self._eta = torch.empty((G, A), dtype=torch.float32, device=dev)
+            self._explore = torch.empty(G, dtype=torch.int8, device=dev)
+            self._rnd = torch.empty(G, dtype=torch.int32, device=dev)
 
     def draw(self, eps: float):
         G, A, S, dev = self.G, self.A, self.S, self.device
         if self.device_rng:
-            rand = torch.randint(0, A, (G, S + 1), device=dev, dtype=torch.int32, generator=self.gen)
-            # Dirichlet(alpha) = normalised Gamma(alpha, 1) draws
-            gam = torch._standard_gamma(self._alpha, generator=self.gen).clamp_min_(1e-30)
-            eta = (gam / gam.sum(dim=1, keepdim=True)).contiguous()
-            explore = (torch.rand(G, device=dev, generator=self.gen) < eps).to(torch.int8)
-            rnd = torch.multinomial(self._p_random, G, replacement=True, generator=self.gen).to(torch.int32)
+            # (the four outputs are this object's own buffers, overwritten by the next draw)
+            if torch.is_tensor(eps):
+                eps_t = eps if eps.dtype == torch.float32 and eps.numel() == 1 else eps.to(torch.float32).reshape(1)
+            else:
+                self._eps.fill_(float(eps))
+                eps_t = self._eps
+            rand, eta, explore, rnd = self._rand, self._eta, self._explore, self._rnd
+            _hip.check(_hip.lib().mz_move_draws(self.seed, ptr(self._state), ptr(eps_t), ptr(self._p_random), float(self.alpha), G, A,
+                                                S + 1, ptr(rand), ptr(eta), ptr(explore), ptr(rnd),
+                                                torch.cuda.current_stream().cuda_stream), "mz_move_draws")
         else:
             rand = torch.from_numpy(self.rng.integers(0, A, size=(G, S + 1), dtype=np.int32)).to(dev)
             eta = torch.from_numpy(self.rng.dirichlet(np.full(A, self.alpha), size=G).astype(np.float32)).to(dev)
@@ -313,8 +322,7 @@ class SelfPlayEngine:
         if self._moves_played >= 2:
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
-            graph.register_generator_state(self.streams.gen)
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph):  # (the draws' move counter lives on the device: every replay draws fresh numbers)
                 self._move_out = self._move(self._eps)  # recorded, not executed: the games stay where they are
             self._move_graph, self._move_seen = graph, seen
         return out
@@ -322,6 +330,13 @@ class SelfPlayEngine:
     def _move(self, eps):
         obs, res = self.launch(self.streams.draw(eps))
         reward, done = self.env.step(self.action)
+        if done.is_cuda and done.dtype == torch.int8 and self.step_in_episode.dtype == torch.int32:
+            ended = torch.empty(self.G, dtype=torch.int8, device=done.device)
+            _hip.check(_hip.lib().mz_episode_end(ptr(done), ptr(self.step_in_episode), int(self.cfg.max_steps_per_episode), self.G,
+                                                 ptr(ended), _stream()), "mz_episode_end")
+            out = (obs, res.policy32, res.value, self.action.clone(), reward, ended)
+            self.env.reset(ended)
+            return out
         self.step_in_episode += 1
         ended = (done.bool() | (self.step_in_episode >= self.cfg.max_steps_per_episode)).to(torch.int8)
         out = (obs, res.policy32, res.value, self.action.clone(), reward, ended)

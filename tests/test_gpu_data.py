@@ -85,3 +85,82 @@ def test_pick_action_first_argmax_and_exploration():
     want = np.where(explore == 1, rnd, torch.from_numpy(pol).argmax(dim=1).numpy())
     assert np.array_equal(out.cpu().numpy(), want)
     assert (want[::3][explore[::3] == 0] == 2).all()
+
+
+def test_move_draws_distributions_and_streams():
+    """mz_move_draws: the four random inputs of a move from one launch.  Same distributions as the reference's
+    draws (src/search/mcts.py:64-66 with expansion.py:35: uniform child; mcts.py:85-94: Dirichlet(alpha);
+    src/training_data_generator.py:148-163: coin against epsilon, action ~ random_action_probability), streams
+    a function of (seed, move number, game): reproducible, advancing by themselves, independent of the batch size."""
+    import numpy as np
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    lib = _hip.lib()
+    G, A, S1, alpha = 20000, 7, 51, 0.3
+    dev = "cuda"
+    p_rand = torch.tensor([0.05, 0.1, 0.15, 0.2, 0.25, 0.15, 0.1], device=dev)
+
+    def draw(state, eps, n=G, p=p_rand, seed=1234):
+        e = torch.tensor([eps], dtype=torch.float32, device=dev)
+        out = (torch.empty((n, S1), dtype=torch.int32, device=dev), torch.empty((n, A), device=dev),
+               torch.empty(n, dtype=torch.int8, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+        _hip.check(lib.mz_move_draws(seed, ptr(state), ptr(e), ptr(p), alpha, n, A, S1, *[ptr(t) for t in out], None), "mz_move_draws")
+        torch.cuda.synchronize()
+        return out
+
+    state = torch.zeros(2, dtype=torch.int64, device=dev)
+    rand, eta, explore, rnd = draw(state, 0.25)
+    assert state.tolist() == [1, 0]
+    # uniform children: every action within 4 sigma of G * S1 / A
+    counts = torch.bincount(rand.reshape(-1).long(), minlength=A).double().cpu().numpy()
+    n = G * S1
+    assert counts.sum() == n and np.abs(counts - n / A).max() < 4 * np.sqrt(n / A)
+    assert int(rand.min()) >= 0 and int(rand.max()) < A
+    # Dirichlet(alpha): rows on the simplex, component mean 1/A, variance (1/A)(1 - 1/A) / (A alpha + 1)
+    e64 = eta.double().cpu().numpy()
+    np.testing.assert_allclose(e64.sum(1), 1.0, atol=1e-5)
+    assert (e64 >= 0).all()
+    var = (1 / A) * (1 - 1 / A) / (A * alpha + 1)
+    assert np.abs(e64.mean(0) - 1 / A).max() < 5 * np.sqrt(var / G)
+    np.testing.assert_allclose(e64.var(0), var, rtol=0.06)
+    # a sparse prior: the share of components below 1e-3 equals the Beta(alpha, (A - 1) alpha) mass there
+    from scipy import stats
+    want = stats.beta(alpha, (A - 1) * alpha).cdf(1e-3)
+    assert abs((e64 < 1e-3).mean() - want) < 0.01
+    # coin and random action
+    assert abs(float(explore.float().mean()) - 0.25) < 4 * np.sqrt(0.25 * 0.75 / G)
+    pc = torch.bincount(rnd.long(), minlength=A).double().cpu().numpy() / G
+    assert np.abs(pc - p_rand.cpu().numpy()).max() < 4 * np.sqrt(0.25 / G)
+    # the next call draws the next move; a fresh state with the same seed repeats the first; another seed differs
+    rand2, eta2, _, _ = draw(state, 0.25)
+    assert state.tolist() == [2, 0] and not torch.equal(rand2, rand) and not torch.equal(eta2, eta)
+    again = draw(torch.zeros(2, dtype=torch.int64, device=dev), 0.25)
+    assert all(torch.equal(a, b) for a, b in zip(again, (rand, eta, explore, rnd)))
+    other = draw(torch.zeros(2, dtype=torch.int64, device=dev), 0.25, seed=99)
+    assert not torch.equal(other[0], rand)
+    # a game's stream does not depend on how many games are drawn with it; uniform action when no table is given
+    few = draw(torch.zeros(2, dtype=torch.int64, device=dev), 0.25, n=300)
+    assert torch.equal(few[0], rand[:300]) and torch.equal(few[1], eta[:300])
+    uni = draw(torch.zeros(2, dtype=torch.int64, device=dev), 1.0, p=None)
+    assert bool(uni[2].all())
+    pu = torch.bincount(uni[3].long(), minlength=A).double().cpu().numpy() / G
+    assert np.abs(pu - 1 / A).max() < 4 * np.sqrt((1 / A) / G)
+
+
+def test_episode_end_counts_steps_and_ends_games():
+    """mz_episode_end against the torch expressions it replaces (the episode loop of
+    src/training_data_generator.py:107-142: a game ends when its environment says so or at the step limit)."""
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    G, limit = 1000, 42
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    step = torch.randint(0, limit, (G,), device="cuda", generator=gen, dtype=torch.int32)
+    done = (torch.rand(G, device="cuda", generator=gen) < 0.2).to(torch.int8)
+    want_step = step + 1
+    want_end = (done.bool() | (want_step >= limit)).to(torch.int8)
+    want_step = want_step.masked_fill(want_end.bool(), 0)
+    ended = torch.full((G,), 7, dtype=torch.int8, device="cuda")
+    _hip.check(_hip.lib().mz_episode_end(ptr(done), ptr(step), limit, G, ptr(ended), None), "mz_episode_end")
+    torch.cuda.synchronize()
+    assert torch.equal(ended, want_end) and torch.equal(step, want_step)
+    assert int(want_end.sum()) > 0 and int((want_step == 0).sum()) >= int(want_end.sum())
