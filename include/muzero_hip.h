@@ -302,6 +302,14 @@ int mz_c4_step(const mz_c4_state *state, const int32_t *action, float *reward, i
 /* ConnectFour.get_state + get_to_play, connect_four.py:26-30,53-57: obs f32[G][2][6][7]
  * (plane 0 = player to move, row 0 = top), to_play i8[G] in {+1,-1} (may be NULL). */
 int mz_c4_observe(const mz_c4_state *state, float *obs, int8_t *to_play, void *stream);
+/* The end of a lock-step self-play move in one launch (src/training_data_generator.py:107-142 for every game):
+ * mz_pick_action on policy f32[G][A] / explore / random_action, mz_c4_step with that action, mz_episode_end on
+ * step_in_episode with max_steps, and mz_c4_reset of the games that ended -- the results of those four calls in a
+ * row.  action i32[G] and action_copy (optional, i32[G]: a second copy for the caller's record of the move) receive
+ * the action, reward f32[G] and ended i8[G] as mz_c4_step / mz_episode_end leave them. */
+int mz_c4_move_end(const mz_c4_state *state, const float *policy, int32_t A, const int8_t *explore,
+                   const int32_t *random_action, int32_t *step_in_episode, int32_t max_steps, int32_t *action,
+                   int32_t *action_copy, float *reward, int8_t *ended, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Data side of self-play and of the learner's targets.

@@ -125,6 +125,7 @@ _SIGS = {
     "mz_c4_reset": (C.c_int, [C.POINTER(C4State), _P, _P]),
     "mz_c4_step": (C.c_int, [C.POINTER(C4State), _P, _P, _P, _P]),
     "mz_c4_observe": (C.c_int, [C.POINTER(C4State), _P, _P, _P]),
+    "mz_c4_move_end": (C.c_int, [C.POINTER(C4State), _P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "mz_search_run": (C.c_int, [C.POINTER(Pool), C.POINTER(PackedNets), _P, C.POINTER(SearchParams), _P, _P, _P, _P,
                                 _P]),
     "mz_history_push_assemble": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

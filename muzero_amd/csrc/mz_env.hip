@@ -28,21 +28,17 @@ __global__ void k_c4_reset(mz_c4_state s, const int8_t *__restrict__ mask) {
     s.done[g] = 0;
 }
 
-// One adapter-level step per game: drop a piece, decide win / draw / illegal move, pass the
+// One adapter-level step of game g: drop a piece, decide win / draw / illegal move, pass the
 // turn, and report what the player who is now to move sees (reward, done).
-__global__ void k_c4_step(mz_c4_state s, const int32_t *__restrict__ action, float *__restrict__ reward,
-                          int8_t *__restrict__ done_out) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= s.G) return;
+__device__ __forceinline__ void c4_step(const mz_c4_state &s, int g, int col, float &reward, int8_t &done_out) {
     if (s.done[g]) {
-        reward[g] = 0.0f;
-        done_out[g] = 1;
+        reward = 0.0f;
+        done_out = 1;
         return;
     }
     const int mover = s.to_move[g];
     unsigned long long own = s.pieces[2 * (size_t)g + mover];
     const unsigned long long opp = s.pieces[2 * (size_t)g + 1 - mover];
-    const int col = action[g];
     float r = 0.0f;
     int8_t done = 0;
     int8_t next_mover = (int8_t)(1 - mover);
@@ -66,8 +62,55 @@ __global__ void k_c4_step(mz_c4_state s, const int32_t *__restrict__ action, flo
     }
     s.to_move[g] = next_mover;
     s.done[g] = done;
+    reward = r;
+    done_out = done;
+}
+
+__global__ void k_c4_step(mz_c4_state s, const int32_t *__restrict__ action, float *__restrict__ reward,
+                          int8_t *__restrict__ done_out) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.G) return;
+    float r;
+    int8_t d;
+    c4_step(s, g, action[g], r, d);
     reward[g] = r;
-    done_out[g] = done;
+    done_out[g] = d;
+}
+
+// The end of a self-play move in one launch, one lane per game: the action pick of k_pick_action (first maximum of
+// the policy, or the drawn action when the coin says so), the step above, the episode bookkeeping of k_episode_end
+// and the restart of an ended game (k_c4_reset) -- the same results as those four kernels in a row.
+__global__ void k_c4_move_end(mz_c4_state s, const float *__restrict__ policy, int A, const int8_t *__restrict__ explore,
+                              const int32_t *__restrict__ random_action, int32_t *__restrict__ step_in_episode, int max_steps,
+                              int32_t *__restrict__ action_out, int32_t *__restrict__ action_copy, float *__restrict__ reward,
+                              int8_t *__restrict__ ended) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= s.G) return;
+    int a;
+    if (explore && explore[g]) {
+        a = random_action[g];
+    } else {
+        const float *p = policy + (size_t)g * A;
+        a = 0;
+        for (int i = 1; i < A; ++i)
+            if (p[i] > p[a]) a = i;
+    }
+    action_out[g] = a;
+    if (action_copy) action_copy[g] = a;
+    float r;
+    int8_t d;
+    c4_step(s, g, a, r, d);
+    reward[g] = r;
+    const int t = step_in_episode[g] + 1;
+    const bool e = d != 0 || t >= max_steps;
+    ended[g] = e ? 1 : 0;
+    step_in_episode[g] = e ? 0 : t;
+    if (e) {
+        s.pieces[2 * (size_t)g] = 0ull;
+        s.pieces[2 * (size_t)g + 1] = 0ull;
+        s.to_move[g] = 0;
+        s.done[g] = 0;
+    }
 }
 
 // obs f32[G][2][6][7]: plane 0 = pieces of the player to move, plane 1 = the opponent's,
@@ -106,6 +149,17 @@ int mz_c4_step(const mz_c4_state *state, const int32_t *action, float *reward, i
     hipLaunchKernelGGL(k_c4_step, dim3((state->G + 255) / 256), dim3(256), 0, (hipStream_t)stream, *state, action,
                        reward, done);
     return mz::check_launch("k_c4_step");
+}
+
+int mz_c4_move_end(const mz_c4_state *state, const float *policy, int32_t A, const int8_t *explore, const int32_t *random_action,
+                   int32_t *step_in_episode, int32_t max_steps, int32_t *action, int32_t *action_copy, float *reward,
+                   int8_t *ended, void *stream) {
+    MZ_TRY(check_state(state));
+    if (!policy || A <= 0 || (explore && !random_action) || !step_in_episode || !action || !reward || !ended)
+        return mz::fail(MZ_ERR_ARG, "mz_c4_move_end: NULL argument or non-positive action count");
+    hipLaunchKernelGGL(k_c4_move_end, dim3((state->G + 255) / 256), dim3(256), 0, (hipStream_t)stream, *state, policy, A, explore,
+                       random_action, step_in_episode, max_steps, action, action_copy, reward, ended);
+    return mz::check_launch("k_c4_move_end");
 }
 
 int mz_c4_observe(const mz_c4_state *state, float *obs, int8_t *to_play, void *stream) {

@@ -45,6 +45,22 @@ class BatchedConnectFour:
         _hip.check(_hip.lib().mz_c4_step(C.byref(self.c), ptr(action), ptr(reward), ptr(done), _stream()), "mz_c4_step")
         return reward, done
 
+    def move_end(self, policy32: torch.Tensor, explore, random_action, step_in_episode: torch.Tensor, max_steps: int,
+                 action: torch.Tensor):
+        """Action pick, step, episode bookkeeping and the restart of ended games for all G games in one launch
+        (mz_c4_move_end: what pick_action, step, mz_episode_end and reset do in a row).  `action` i32[G] receives the
+        actions; returns (a fresh copy of the actions, reward f32[G], ended i8[G])."""
+        G, A = policy32.shape
+        assert G == self.G and policy32.dtype == torch.float32 and policy32.is_contiguous()
+        assert step_in_episode.dtype == torch.int32 and action.dtype == torch.int32
+        played = torch.empty(G, dtype=torch.int32, device=self.device)
+        reward = torch.empty(G, dtype=torch.float32, device=self.device)
+        ended = torch.empty(G, dtype=torch.int8, device=self.device)
+        _hip.check(_hip.lib().mz_c4_move_end(C.byref(self.c), ptr(policy32), A, ptr(explore), ptr(random_action), ptr(step_in_episode),
+                                             int(max_steps), ptr(action), ptr(played), ptr(reward), ptr(ended), _stream()),
+                   "mz_c4_move_end")
+        return played, reward, ended
+
     def observe(self, obs: torch.Tensor | None = None, to_play: torch.Tensor | None = None):
         obs = obs if obs is not None else torch.empty((self.G, 2, 6, 7), dtype=torch.float32, device=self.device)
         to_play = to_play if to_play is not None else torch.empty(self.G, dtype=torch.int8, device=self.device)

@@ -281,10 +281,10 @@ class SelfPlayEngine:
         c = self.cfg
         return max(c.epsilon * (c.epsilon_decay ** training_steps), c.min_epsilon)
 
-    def launch(self, draws):
-        """The device side of one move, up to the action pick (left in `self.action`): nothing here waits for
-        the GPU.  `draws`: this engine's games' (rand, eta, explore, rnd) of MoveStreams.draw.  Returns
-        (obs, SearchResult)."""
+    def launch(self, draws, pick: bool = True):
+        """The device side of one move, up to the action pick (left in `self.action`; `pick=False`: left to the
+        caller): nothing here waits for the GPU.  `draws`: this engine's games' (rand, eta, explore, rnd) of
+        MoveStreams.draw.  Returns (obs, SearchResult)."""
         G = self.G
         rand, eta, explore, rnd = draws
         obs, to_play = self.env.observe()
@@ -298,7 +298,8 @@ class SelfPlayEngine:
             if self._root_versions() != getattr(self.nets, "root_seen", None):
                 self.nets.refresh()  # the composed root weights hold a copy of the final convolution's (it records what it read)
         res = self.mcts.run(latent if root_t is None else None, to_play, eta, rand, root_t=root_t)
-        pick_action(res.policy32, explore, rnd, self.action)
+        if pick:
+            pick_action(res.policy32, explore, rnd, self.action)
         return obs, res
 
     def move(self, training_steps: int = 0):
@@ -328,6 +329,13 @@ class SelfPlayEngine:
         return out
 
     def _move(self, eps):
+        if hasattr(self.env, "move_end") and self.step_in_episode.dtype == torch.int32:
+            # the device environment ends the move in one launch: pick, step, episode bookkeeping, restarts
+            draws = self.streams.draw(eps)
+            obs, res = self.launch(draws, pick=False)
+            played, reward, ended = self.env.move_end(res.policy32, draws[2], draws[3], self.step_in_episode,
+                                                      int(self.cfg.max_steps_per_episode), self.action)
+            return obs, res.policy32, res.value, played, reward, ended
         obs, res = self.launch(self.streams.draw(eps))
         reward, done = self.env.step(self.action)
         if done.is_cuda and done.dtype == torch.int8 and self.step_in_episode.dtype == torch.int32:

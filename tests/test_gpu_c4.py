@@ -80,3 +80,42 @@ def test_position_counts_match_published_table():
         live = uniq[uniq[:, 3] == 0]
         pieces, to_move = live[:, :2].contiguous(), live[:, 2].to(torch.int8).contiguous()
     assert counts == want
+
+
+def test_move_end_equals_pick_step_bookkeeping_and_reset():
+    """mz_c4_move_end against the four calls it stands for -- mz_pick_action, mz_c4_step, mz_episode_end,
+    mz_c4_reset (src/training_data_generator.py:107-163 for every game) -- over 60 moves of 600 games from the same
+    draws: actions, rewards, ended flags, step counters and board states stay identical."""
+    import torch
+    from muzero_amd import _hip
+    from muzero_amd._hip import ptr
+    from muzero_amd.environments.connect_four import BatchedConnectFour
+    from muzero_amd.selfplay import pick_action
+    G, A, limit = 600, 7, 30
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    a_env, b_env = BatchedConnectFour(G), BatchedConnectFour(G)
+    a_env.reset(), b_env.reset()
+    step_a = torch.zeros(G, dtype=torch.int32, device="cuda")
+    step_b = torch.zeros(G, dtype=torch.int32, device="cuda")
+    act_a = torch.zeros(G, dtype=torch.int32, device="cuda")
+    act_b = torch.zeros(G, dtype=torch.int32, device="cuda")
+    ends = 0
+    for _ in range(60):
+        policy = torch.rand(G, A, device="cuda", generator=gen)
+        policy[::7, 3] = policy[::7, 5] = 2.0  # ties: the first maximum wins
+        explore = (torch.rand(G, device="cuda", generator=gen) < 0.3).to(torch.int8)
+        rnd = torch.randint(0, A, (G,), device="cuda", generator=gen, dtype=torch.int32)
+        # the four separate calls
+        pick_action(policy, explore, rnd, act_a)
+        reward_a, done_a = a_env.step(act_a)
+        ended_a = torch.empty(G, dtype=torch.int8, device="cuda")
+        _hip.check(_hip.lib().mz_episode_end(ptr(done_a), ptr(step_a), limit, G, ptr(ended_a), None), "mz_episode_end")
+        a_env.reset(ended_a)
+        # the one call
+        played, reward_b, ended_b = b_env.move_end(policy, explore, rnd, step_b, limit, act_b)
+        torch.cuda.synchronize()
+        assert torch.equal(act_a, act_b) and torch.equal(played, act_b)
+        assert torch.equal(reward_a, reward_b) and torch.equal(ended_a, ended_b) and torch.equal(step_a, step_b)
+        assert torch.equal(a_env.pieces, b_env.pieces) and torch.equal(a_env.to_move, b_env.to_move) and torch.equal(a_env.done, b_env.done)
+        ends += int(ended_b.sum())
+    assert ends > G  # games ended (wins, full columns, the step limit) and restarted along the way
