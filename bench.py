@@ -327,7 +327,7 @@ def main():
                     help="keep every node's latent in the pool (the drop-in MCTS.run's form) instead of one merge row per "
                          "expansion (self-play's form; bit-identical trees)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--selfplay-moves", type=int, default=16, help="timed self-play moves per game (0 = skip)")
+    ap.add_argument("--selfplay-moves", type=int, default=64, help="timed self-play moves per game (0 = skip)")
     ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="after the K timed steps, keep stepping for this long (a sustained-rate figure; longer than a "
                          "5-second utilisation sampler's period)")
