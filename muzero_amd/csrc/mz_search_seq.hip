@@ -377,9 +377,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     // Runs a step: `n` tiles of KC chunks for this wave through the ring.  On entry slot 0 and slot 1 hold the
     // step's first two tiles (requested ahead by the caller, a whole inter-step phase earlier: prefetch2); the
     // step requests tile j + 2 as soon as tile j has been multiplied.  ptr(j): address of the wave's j-th tile
-    // (j clamped by the callee); work(slot, j): multiply and store it.  Inside the loop every path issues its
-    // fetches unconditionally, so that the waits in front of the matrix instructions count the loads in flight
-    // behind the tile they need instead of draining the queue.  MULTI = false: at most two tiles per wave.
+    // (j clamped by the callee); work(slot, j): multiply and store it.  Inside the loop the fetches are issued
+    // unconditionally -- but for the one past an odd share -- so that the waits in front of the matrix instructions
+    // count the loads in flight behind the tile they need instead of draining the queue.  MULTI = false: at most
+    // two tiles per wave.
     auto run_step = [&](auto kc_tag, auto multi_tag, int n, auto &&ptr, auto &&work, auto &&after_first) {
         constexpr int KC = decltype(kc_tag)::value;
         constexpr bool MULTI = decltype(multi_tag)::value;
@@ -389,7 +390,9 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                 work(s0, j);
                 fetch_tile<KC>(s0, ptr(j + 2), lane);
                 work(s1, j + 1);
-                fetch_tile<KC>(s1, ptr(j + 3), lane);  // (an odd share repeats its last tile here)
+                // (an odd share has no fourth tile: fetching its last one again, to keep the loads in flight countable,
+                // cost more on the compute unit's L2 port than the drained queue costs the waves with an even share)
+                if (j + 3 < n) fetch_tile<KC>(s1, ptr(j + 3), lane);
             }
         }
         if (j < n) work(s0, j);
