@@ -406,6 +406,11 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         else if (kcn == KCP) fetch_tile<KCP>(s0, tile0, lane), fetch_tile<KCP>(s1, tile1, lane);
         else fetch_tile<KCV>(s0, tile0, lane), fetch_tile<KCV>(s1, tile1, lane);
     };
+    // the merge layer's tiles of this wave: one or two (a wave with one does not request it twice)
+    auto prefetch_merge = [&] {
+        fetch_tile<KCD>(s0, m_tile0, lane);
+        if (m_n > 1) fetch_tile<KCD>(s1, m_tile1, lane);
+    };
     using MultiPair = std::true_type;
     using OnePair = std::false_type;
 
@@ -492,7 +497,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             // barrier makes everybody wait for the issuing waves: the six waves that do not select request the first
             // tiles of the leaf's merge HERE, beside the selection (a latency chain of dependent record reads); the
             // two selecting waves follow in the leaf-latent phase
-            if (wave >= 2) prefetch2(m_tile0, m_tile1, KCD);
+            if (wave >= 2) prefetch_merge();
             if (tid < kTrees * lpt) {
                 const int t = tid / lpt, a = tid % lpt;
                 int leaf = 0, dep = 0;
@@ -541,7 +546,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                 // unit's L2 port needs to take them, so the waves that were idle during records, backup and selection
                 // requested theirs there; the two selecting waves do it here, behind the rows (loads return in order:
                 // in front of the rows they would hold them back)
-                if (wave < 2) prefetch2(m_tile0, m_tile1, KCD);
+                if (wave < 2) prefetch_merge();
                 if (live) {
                     const lds_f *tr = Tab + a * ld_d + k0;
                     v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
@@ -560,7 +565,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         }
 
         // ---- merge of the leaf; the drawn child's latent; policy 1 of both | merge of the child -----------------
-        if (!sim) prefetch2(m_tile0, m_tile1, KCD);  // (root expansion: nothing to hide it behind)
+        if (!sim) prefetch_merge();  // (root expansion: nothing to hide it behind)
         merge_leaf();
         prefetch2(p0_tile0, p0_tile1, KCD);  // in flight through the barrier, the row store and the forming of the child
         __syncthreads();
