@@ -448,7 +448,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                          epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Zs, ld_d, lane);
                      }
                  },
-                 nothing);
+                 [&] { fetch_tile<KCP>(s0, p1_tile0, lane); });  // policy 2's first tile: beside this wave's last tile
     };
     // split image of sixteen rows relu(zsrc[t] + table[action of tree t]) -> dst (a 16-row tile); act_fixed >= 0:
     // the same action for every tree (the children of one action), else the trees' own actions `sel`
@@ -590,7 +590,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             MZ_STAMP(16)  // child latent
         }
         policy1_and_child_merge(sim);
-        prefetch2(p1_tile0, p1_tile1, KCP);
+        fetch_tile<KCP>(s1, p1_tile1, lane);
         __syncthreads();
         MZ_STAMP(18)  // policy 1 (leaf + child) | merge (child)
 
@@ -682,24 +682,24 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                          mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
                          epi_split<1, true>(hi, lo, t, lds4(Bv0 + t * 16 + 4 * (lane >> 4)), Hv, 16 * ld_v, KCV, nv0, lane);
                      },
-                     nothing);
-            fetch_tile<KCV>(s0, v1_tile, lane);  // value 2 and
-            fetch_tile<KCD>(s1, r0_tile, lane);  // reward 1: in flight through the barrier
-            __syncthreads();
-            MZ_STAMP(7)  // value 1
-            // ---- value 2 (slot 0) | reward 1 of the rollout latent (slot 1) ----------------------------------
-            if (wave < nv1) {
-                f32x4 hi[1], lo[1];
-                mma_tile<KCV, 1>(s0, Hv + lane * 4, 0, hi, lo);
-                epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
-            }
+                     [&] { fetch_tile<KCD>(s0, r0_tile, lane); });  // reward 1's tile: beside this wave's second tile
+            fetch_tile<KCV>(s1, v1_tile, lane);  // value 2's tile: in flight through reward 1 and the barrier
+            // reward 1 of the rollout latent (its input is the one value 1 has just read)
             if (wave < nr0) {
                 f32x4 hi[1], lo[1];
-                mma_tile<KCD, 1>(s1, XI + lane * 4, 0, hi, lo);
+                mma_tile<KCD, 1>(s0, XI + lane * 4, 0, hi, lo);
                 epi_dot<1, true>(hi, lo, wave, lds4(Br0 + wave * 16 + 4 * (lane >> 4)), lds4(DwR + wave * 16 + 4 * (lane >> 4)), DotE, lane);
             }
             __syncthreads();
-            MZ_STAMP(8)  // value 2 | reward 1
+            MZ_STAMP(7)  // value 1 | reward 1
+            // ---- value 2 ------------------------------------------------------------------------------------
+            if (wave < nv1) {
+                f32x4 hi[1], lo[1];
+                mma_tile<KCV, 1>(s1, Hv + lane * 4, 0, hi, lo);
+                epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
+            }
+            __syncthreads();
+            MZ_STAMP(8)  // value 2
             if (tid < kTrees) {  // value of the rollout latent (as finish_dot)
                 s_roll[tid * 2 + 1] = activate(ordered_sum(DotV + tid, kTrees, 4 * nv1) + Bv1[Lv1.Np], Lv2.act);
             } else if (tid >= 64 && tid < 64 + kTrees) {
