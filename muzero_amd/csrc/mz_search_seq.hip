@@ -406,10 +406,11 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         else if (kcn == KCP) fetch_tile<KCP>(s0, tile0, lane), fetch_tile<KCP>(s1, tile1, lane);
         else fetch_tile<KCV>(s0, tile0, lane), fetch_tile<KCV>(s1, tile1, lane);
     };
-    // the merge layer's tiles of this wave: one or two (a wave with one does not request it twice)
+    // the merge layer's tiles of this wave: one or two (a wave with one does not request it twice: its free slot
+    // takes policy 1's second tile already, a whole latency phase before that step)
     auto prefetch_merge = [&] {
         fetch_tile<KCD>(s0, m_tile0, lane);
-        if (m_n > 1) fetch_tile<KCD>(s1, m_tile1, lane);
+        fetch_tile<KCD>(s1, m_n > 1 ? m_tile1 : p0_tile1, lane);
     };
     using MultiPair = std::true_type;
     using OnePair = std::false_type;
@@ -424,7 +425,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                      mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
                      epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Z, ld_d, lane);
                  },
-                 nothing);
+                 [&] { fetch_tile<KCD>(s0, p0_tile0, lane); });  // policy 1's first tile: beside a second merge tile
     };
     // policy 1 of leaf AND drawn child as one pass over two row tiles (its weights are read once per round) -> H1
     // (split image, two row tiles); with `child`, the merge of the drawn child (row tile 1) -> Zs behind it
@@ -567,7 +568,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         // ---- merge of the leaf; the drawn child's latent; policy 1 of both | merge of the child -----------------
         if (!sim) prefetch_merge();  // (root expansion: nothing to hide it behind)
         merge_leaf();
-        prefetch2(p0_tile0, p0_tile1, KCD);  // in flight through the barrier, the row store and the forming of the child
+        if (m_n > 1) fetch_tile<KCD>(s1, p0_tile1, lane);  // in flight through the barrier, the row store and the forming of the child
         __syncthreads();
         MZ_STAMP(3)  // merge (leaf)
         // the leaf's merge row is all that is kept of its children's latents
