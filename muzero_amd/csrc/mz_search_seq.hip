@@ -381,7 +381,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     // unconditionally -- but for the one past an odd share -- so that the waits in front of the matrix instructions
     // count the loads in flight behind the tile they need instead of draining the queue.  MULTI = false: at most
     // two tiles per wave.
-    auto run_step = [&](auto kc_tag, auto multi_tag, int n, auto &&ptr, auto &&work, auto &&after_first) {
+    auto run_step = [&](auto kc_tag, auto multi_tag, int n, auto &&ptr, auto &&work, auto &&after_first, auto &&odd_share) {
         constexpr int KC = decltype(kc_tag)::value;
         constexpr bool MULTI = decltype(multi_tag)::value;
         int j = 0;
@@ -393,6 +393,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                 // (an odd share has no fourth tile: fetching its last one again, to keep the loads in flight countable,
                 // cost more on the compute unit's L2 port than the drained queue costs the waves with an even share)
                 if (j + 3 < n) fetch_tile<KC>(s1, ptr(j + 3), lane);
+                else if (j + 3 == n) odd_share();  // slot 1 is free for good: the caller's request for the next step
             }
         }
         if (j < n) work(s0, j);
@@ -425,7 +426,8 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                      mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
                      epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Z, ld_d, lane);
                  },
-                 [&] { fetch_tile<KCD>(s0, p0_tile0, lane); });  // policy 1's first tile: beside a second merge tile
+                 [&] { fetch_tile<KCD>(s0, p0_tile0, lane); },  // policy 1's first tile: beside a second merge tile
+                 nothing);
     };
     // policy 1 of leaf AND drawn child as one pass over two row tiles (its weights are read once per round) -> H1
     // (split image, two row tiles); with `child`, the merge of the drawn child (row tile 1) -> Zs behind it
@@ -449,7 +451,9 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                          epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Zs, ld_d, lane);
                      }
                  },
-                 [&] { fetch_tile<KCP>(s0, p1_tile0, lane); });  // policy 2's first tile: beside this wave's last tile
+                 [&] { fetch_tile<KCP>(s0, p1_tile0, lane); },   // policy 2's first tile: beside this wave's last tile
+                 [&] { fetch_tile<KCP>(s1, p1_tile1, lane); });  // its second: as early as an odd share frees slot 1
+        if (!(n >= 3 && (n & 1))) fetch_tile<KCP>(s1, p1_tile1, lane);
     };
     // split image of sixteen rows relu(zsrc[t] + table[action of tree t]) -> dst (a 16-row tile); act_fixed >= 0:
     // the same action for every tree (the children of one action), else the trees' own actions `sel`
@@ -591,7 +595,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             MZ_STAMP(16)  // child latent
         }
         policy1_and_child_merge(sim);
-        fetch_tile<KCP>(s1, p1_tile1, lane);
         __syncthreads();
         MZ_STAMP(18)  // policy 1 (leaf + child) | merge (child)
 
@@ -607,7 +610,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             // policy 3 is one column tile: the first wave multiplies it, and requests it as soon as its slot 0 is free
             run_step(std::integral_constant<int, KCP>{}, OnePair{}, p1_n, ptr, work, [&] {
                 if (wave == 0) fetch_tile<KCP>(s0, tile_of(Lp2, KCP, 0), lane);
-            });
+            }, nothing);
             // value 1's first tiles: in flight through policy 3, the softmax phase and the forming of the rollout latent
         }
         __syncthreads();
@@ -683,7 +686,8 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                          mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
                          epi_split<1, true>(hi, lo, t, lds4(Bv0 + t * 16 + 4 * (lane >> 4)), Hv, 16 * ld_v, KCV, nv0, lane);
                      },
-                     [&] { fetch_tile<KCD>(s0, r0_tile, lane); });  // reward 1's tile: beside this wave's second tile
+                     [&] { fetch_tile<KCD>(s0, r0_tile, lane); },  // reward 1's tile: beside this wave's second tile
+                     nothing);
             fetch_tile<KCV>(s1, v1_tile, lane);  // value 2's tile: in flight through reward 1 and the barrier
             // reward 1 of the rollout latent (its input is the one value 1 has just read)
             if (wave < nr0) {
