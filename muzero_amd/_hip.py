@@ -186,6 +186,7 @@ _SIGS = {
     "mz_packed_split3_words": (C.c_int64, [C.POINTER(PackedLayer)]),
     "mz_packed_split3": (C.c_int, [C.POINTER(PackedLayer), _P, _P, _P]),
     "mz_tower_thin_min_calls": (C.c_int, [C.c_int32]),
+    "mz_search_seq_three_slots": (C.c_int, [C.c_int32]),
     "mz_tower_tail_forward": (C.c_int, [C.POINTER(Tower), _P, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P, _P]),
     "mz_tower_stats_floats": (C.c_int64, [C.POINTER(Tower), C.c_int32]),
     "mz_tower_forward_stats": (C.c_int, [C.POINTER(Tower), _P, C.c_int64, _P, _P, C.c_int64, _P, _P, C.c_int64, _P,

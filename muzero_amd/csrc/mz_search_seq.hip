@@ -120,14 +120,25 @@ __device__ __forceinline__ void fetch_tile(Slot<KMAX> &s, const float *tile, int
     }
 }
 
+// Ends the life of a slot's contents for the register allocator (no instruction): a slot filled under one condition
+// and used under another would otherwise count as live from its last use all the way round the loop to the next fill.
+template <int KMAX>
+__device__ __forceinline__ void forget(Slot<KMAX> &s) {
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        asm volatile("" : "=v"(s.w[c][0]));
+        asm volatile("" : "=v"(s.w[c][1]));
+    }
+}
+
 // acc = tile x rows, the rows' split image at img (this lane's 16 bytes of chunk 0 of row tile 0), row tiles
 // x_tile floats apart.  Same instruction sequence per accumulator as stream_tiles.
-template <int KC, int MT, int KMAX>
+template <int KC, int MT, int AHEAD = (MT == 1 ? 2 : 1), int KMAX>
 __device__ __forceinline__ void mma_tile(const Slot<KMAX> &s, const lds_f *img, int x_tile, f32x4 (&hi)[MT], f32x4 (&lo)[MT]) {
     // The rows' operands are read from LDS kAhead chunks ahead of the matrix instructions that use them, with
     // scheduling fences between the groups: left to itself the compiler issues each chunk's reads right in front of
     // its products and every chunk pays an LDS round trip.
-    constexpr int kAhead = MT == 1 ? 2 : 1, kBuf = kAhead + 1;
+    constexpr int kAhead = AHEAD, kBuf = kAhead + 1;
     h8 ah[kBuf][MT], al[kBuf][MT];
     auto read = [&](int c) {
 #pragma unroll
@@ -249,8 +260,15 @@ __device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int 
     count = max(0, min(groups * 2, total - first));
 }
 
-// STORE: the pool keeps every node's latent (written from the root rows and in the phase after the rounds)
-template <int KCD, int KCP, int KCV, bool STORE>
+// STORE: the pool keeps every node's latent (written from the root rows and in the phase after the rounds).
+// FULL: every wave has two column tiles in policy 1, policy 2 and value 1, one in value 2 and reward 1 and one or
+// two in the merge (16 / 16 / 16 / 8 / 8 / 8-16 column tiles): the ring gets a third slot of the merge's width, and
+// the schedule of a round is written out for exactly these shares --
+//   * a wave's first merge tile stays in its slot from the leaf's merge to the drawn child's (the same weights:
+//     requested once per round instead of twice),
+//   * policy 1's tiles are both on their way during the selection, reward 1's tile during the softmax phase
+//     (beside value 1's two): no request for them inside a matrix step.
+template <int KCD, int KCP, int KCV, bool STORE, bool FULL>
 __global__ void __launch_bounds__(kThreads)
 k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q,
              double *__restrict__ policy, float *__restrict__ policy32, double *__restrict__ value,
@@ -373,6 +391,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     const float *r0_tile = tile_of(Lr0, KCD, min(wave, nr0 - 1));
 
     Slot<KMAX> s0, s1;
+    Slot<KCD> sx;  // FULL only
 
     // Runs a step: `n` tiles of KC chunks for this wave through the ring.  On entry slot 0 and slot 1 hold the
     // step's first two tiles (requested ahead by the caller, a whole inter-step phase earlier: prefetch2); the
@@ -412,20 +431,45 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     auto prefetch_merge = [&] {
         fetch_tile<KCD>(s0, m_tile0, lane);
         fetch_tile<KCD>(s1, m_n > 1 ? m_tile1 : p0_tile1, lane);
+        if constexpr (FULL) fetch_tile<KCD>(sx, p0_tile0, lane);
     };
     using MultiPair = std::true_type;
     using OnePair = std::false_type;
 
     lds_f *XC = XI + kTrees * ld_d;  // the drawn child's image
+    // one column tile t of: the merge of sixteen rows (image at img) -> fp32 rows at dst; policy 1 of leaf AND drawn
+    // child (two row tiles) -> H1 (split image); value 1 of the rollout latent -> Hv (split image); value 2 and
+    // reward 1 with their folded one-output layers -> partial sums
+    constexpr int kAhead1 = 2;
+    auto work_merge = [&](auto &s, const lds_f *img, int t, lds_f *dst) {
+        f32x4 hi[1], lo[1];
+        mma_tile<KCD, 1, kAhead1>(s, img + lane * 4, 0, hi, lo);
+        epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), dst, ld_d, lane);
+    };
+    auto work_policy1 = [&](auto &s, int t) {
+        f32x4 hi[2], lo[2];
+        mma_tile<KCD, 2>(s, XI + lane * 4, 16 * ld_d, hi, lo);
+        epi_split<2, true>(hi, lo, t, lds4(Bp0 + t * 16 + 4 * (lane >> 4)), H1, 16 * ld_p, KCP, np0, lane);
+    };
+    auto work_value1 = [&](auto &s, int t) {
+        f32x4 hi[1], lo[1];
+        mma_tile<KCD, 1, kAhead1>(s, XI + lane * 4, 0, hi, lo);
+        epi_split<1, true>(hi, lo, t, lds4(Bv0 + t * 16 + 4 * (lane >> 4)), Hv, 16 * ld_v, KCV, nv0, lane);
+    };
+    auto work_value2 = [&](auto &s) {
+        f32x4 hi[1], lo[1];
+        mma_tile<KCV, 1, kAhead1>(s, Hv + lane * 4, 0, hi, lo);
+        epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
+    };
+    auto work_reward1 = [&](auto &s) {
+        f32x4 hi[1], lo[1];
+        mma_tile<KCD, 1, kAhead1>(s, XI + lane * 4, 0, hi, lo);
+        epi_dot<1, true>(hi, lo, wave, lds4(Br0 + wave * 16 + 4 * (lane >> 4)), lds4(DwR + wave * 16 + 4 * (lane >> 4)), DotE, lane);
+    };
     // merge of the leaf (image in XI) -> Z (fp32 rows): at most two tiles per wave, both prefetched
     auto merge_leaf = [&] {
         run_step(std::integral_constant<int, KCD>{}, OnePair{}, m_n, m_tile,
-                 [&](Slot<KMAX> &s, int j) {
-                     const int t = wave + kWaves * j;
-                     f32x4 hi[1], lo[1];
-                     mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
-                     epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Z, ld_d, lane);
-                 },
+                 [&](Slot<KMAX> &s, int j) { work_merge(s, XI, wave + kWaves * j, Z); },
                  [&] { fetch_tile<KCD>(s0, p0_tile0, lane); },  // policy 1's first tile: beside a second merge tile
                  nothing);
     };
@@ -439,17 +483,8 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                      return j < p0_n ? tile_of(Lp0, KCD, min(p0_first + j, np0 - 1)) : m_tile(j - p0_n);
                  },
                  [&](Slot<KMAX> &s, int j) {
-                     if (j < p0_n) {
-                         const int t = p0_first + j;
-                         f32x4 hi[2], lo[2];
-                         mma_tile<KCD, 2>(s, XI + lane * 4, 16 * ld_d, hi, lo);
-                         epi_split<2, true>(hi, lo, t, lds4(Bp0 + t * 16 + 4 * (lane >> 4)), H1, 16 * ld_p, KCP, np0, lane);
-                     } else {
-                         const int t = wave + kWaves * (j - p0_n);
-                         f32x4 hi[1], lo[1];
-                         mma_tile<KCD, 1>(s, XC + lane * 4, 0, hi, lo);
-                         epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), Zs, ld_d, lane);
-                     }
+                     if (j < p0_n) work_policy1(s, p0_first + j);
+                     else work_merge(s, XC, wave + kWaves * (j - p0_n), Zs);
                  },
                  [&] { fetch_tile<KCP>(s0, p1_tile0, lane); },   // policy 2's first tile: beside this wave's last tile
                  [&] { fetch_tile<KCP>(s1, p1_tile1, lane); });  // its second: as early as an odd share frees slot 1
@@ -480,6 +515,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     for (int e = 0; e <= S; ++e) {
         const int base = 1 + e * A;
         const bool sim = e > 0;
+        if constexpr (FULL) forget(sx);
         // Thread-dependent addresses are re-derived every round from an opaque copy of the thread index: hoisted out
         // of the loop they stay live through the whole kernel, spill, and every reload from scratch waits for ALL
         // outstanding loads -- the ring's tiles in flight included.
@@ -571,8 +607,16 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 
         // ---- merge of the leaf; the drawn child's latent; policy 1 of both | merge of the child -----------------
         if (!sim) prefetch_merge();  // (root expansion: nothing to hide it behind)
-        merge_leaf();
-        if (m_n > 1) fetch_tile<KCD>(s1, p0_tile1, lane);  // in flight through the barrier, the row store and the forming of the child
+        if constexpr (FULL) {
+            work_merge(s0, XI, wave, Z);  // (slot 0 keeps the tile for the drawn child's merge)
+            if (m_n > 1) {
+                work_merge(s1, XI, wave + kWaves, Z);
+                fetch_tile<KCD>(s1, p0_tile1, lane);  // in flight through the barrier, the row store and the forming of the child
+            }
+        } else {
+            merge_leaf();
+            if (m_n > 1) fetch_tile<KCD>(s1, p0_tile1, lane);  // in flight through the barrier, the row store and the forming of the child
+        }
         __syncthreads();
         MZ_STAMP(3)  // merge (leaf)
         // the leaf's merge row is all that is kept of its children's latents
@@ -594,7 +638,20 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             __syncthreads();
             MZ_STAMP(16)  // child latent
         }
-        policy1_and_child_merge(sim);
+        if constexpr (FULL) {
+            // slot x: policy 1's first tile; slot 0: the merge tile the leaf used; slot 1: policy 1's second tile.
+            // Policy 2's tiles are requested as the slots fall free, a second merge tile behind the first product.
+            work_policy1(sx, p0_first);
+            if (sim && m_n > 1) fetch_tile<KCD>(sx, m_tile1, lane);
+            work_policy1(s1, p0_first + 1);
+            fetch_tile<KCP>(s1, p1_tile1, lane);
+            if (sim) work_merge(s0, XC, wave, Zs);
+            fetch_tile<KCP>(s0, p1_tile0, lane);
+            if (sim && m_n > 1) work_merge(sx, XC, wave + kWaves, Zs);
+            forget(sx);
+        } else {
+            policy1_and_child_merge(sim);
+        }
         __syncthreads();
         MZ_STAMP(18)  // policy 1 (leaf + child) | merge (child)
 
@@ -678,31 +735,18 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
             __syncthreads();
             MZ_STAMP(6)  // rollout latent
-            // ---- value 1 of the rollout latent -> Hv (split image) -------------------------------------------
+            // ---- value 1 of the rollout latent -> Hv (split image) | reward 1 of the rollout latent ---------------
             run_step(std::integral_constant<int, KCD>{}, OnePair{}, v0_n, [&](int j) { return tile_of(Lv0, KCD, min(v0_first + j, nv0 - 1)); },
-                     [&](Slot<KMAX> &s, int j) {
-                         const int t = v0_first + j;
-                         f32x4 hi[1], lo[1];
-                         mma_tile<KCD, 1>(s, XI + lane * 4, 0, hi, lo);
-                         epi_split<1, true>(hi, lo, t, lds4(Bv0 + t * 16 + 4 * (lane >> 4)), Hv, 16 * ld_v, KCV, nv0, lane);
-                     },
+                     [&](Slot<KMAX> &s, int j) { work_value1(s, v0_first + j); },
                      [&] { fetch_tile<KCD>(s0, r0_tile, lane); },  // reward 1's tile: beside this wave's second tile
                      nothing);
             fetch_tile<KCV>(s1, v1_tile, lane);  // value 2's tile: in flight through reward 1 and the barrier
             // reward 1 of the rollout latent (its input is the one value 1 has just read)
-            if (wave < nr0) {
-                f32x4 hi[1], lo[1];
-                mma_tile<KCD, 1>(s0, XI + lane * 4, 0, hi, lo);
-                epi_dot<1, true>(hi, lo, wave, lds4(Br0 + wave * 16 + 4 * (lane >> 4)), lds4(DwR + wave * 16 + 4 * (lane >> 4)), DotE, lane);
-            }
+            if (wave < nr0) work_reward1(s0);
             __syncthreads();
             MZ_STAMP(7)  // value 1 | reward 1
             // ---- value 2 ------------------------------------------------------------------------------------
-            if (wave < nv1) {
-                f32x4 hi[1], lo[1];
-                mma_tile<KCV, 1>(s1, Hv + lane * 4, 0, hi, lo);
-                epi_dot<1, true>(hi, lo, wave, lds4(Bv1 + wave * 16 + 4 * (lane >> 4)), lds4(DwV + wave * 16 + 4 * (lane >> 4)), DotV, lane);
-            }
+            if (wave < nv1) work_value2(s1);
             __syncthreads();
             MZ_STAMP(8)  // value 2
             if (tid < kTrees) {  // value of the rollout latent (as finish_dot)
@@ -903,10 +947,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 #undef MZ_STAMP
 }
 
-template <int KCD, int KCP, int KCV, bool STORE>
+template <int KCD, int KCP, int KCV, bool STORE, bool FULL>
 int launch_seq(const mz_pool *pool, const mz_packed_nets *plan, const float *blob, const mz_search_params &q, size_t lds_total,
                double *policy, float *policy32, double *value, int32_t *visits, hipStream_t st) {
-    auto kernel = k_search_seq<KCD, KCP, KCV, STORE>;
+    auto kernel = k_search_seq<KCD, KCP, KCV, STORE, FULL>;
     if (lds_total > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
         if (e != hipSuccess) return mz::fail(MZ_ERR_HIP, "k_search_seq: cannot enable %zu bytes of LDS: %s", lds_total, hipGetErrorString(e));
@@ -916,7 +960,21 @@ int launch_seq(const mz_pool *pool, const mz_packed_nets *plan, const float *blo
     return mz::check_launch("k_search_seq");
 }
 
+// The written-out schedule with a third ring slot (FULL) is taken wherever the layer widths allow it; the knob
+// (environment variable at load time, mz_search_seq_three_slots at run time) lets the general schedule run on the
+// same searches.
+int g_three_slots = [] {
+    const char *e = getenv("MZ_SEARCH_SEQ_THREE_SLOTS");
+    return e ? atoi(e) : 1;
+}();
+
 }  // namespace
+
+extern "C" int mz_search_seq_three_slots(int32_t new_value) {
+    const int old = g_three_slots;
+    if (new_value >= 0) g_three_slots = new_value;
+    return old;
+}
 
 // The sequential-program form of mz_search_run for the searches it covers: returns 1 after launching it,
 // 0 when the search needs k_search, a negative code on a failed launch.  Arguments are validated by the caller.
@@ -950,15 +1008,20 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool store = pool->latent != nullptr;
-#define MZ_SEQ_LAUNCH(A_, B_, C_)                                                                                          \
-    {                                                                                                                      \
-        const size_t lds_total = SeqLayout<A_, B_, C_>::total(prm->tab_len);                                               \
-        if (lds_total > 160 * 1024) return 0;                                                                              \
-        rc = store ? launch_seq<A_, B_, C_, true>(pool, plan, blob, *prm, lds_total, policy, policy32, value, visits, st)  \
-                   : launch_seq<A_, B_, C_, false>(pool, plan, blob, *prm, lds_total, policy, policy32, value, visits, st);\
+    // every wave with two tiles in policy 1, policy 2 and value 1, one in value 2 and reward 1, one or two in the merge
+    const bool full = g_three_slots && (P.policy.layer[0].Np >> 4) == 2 * kWaves && (P.policy.layer[1].Np >> 4) == 2 * kWaves &&
+                      (P.value.layer[0].Np >> 4) == 2 * kWaves && (P.value.layer[1].Np >> 4) == kWaves &&
+                      (P.reward.layer[0].Np >> 4) == kWaves && (P.merge.layer[0].Np >> 4) >= kWaves;
+#define MZ_SEQ_LAUNCH(A_, B_, C_, F_)                                                                                          \
+    {                                                                                                                          \
+        const size_t lds_total = SeqLayout<A_, B_, C_>::total(prm->tab_len);                                                   \
+        if (lds_total > 160 * 1024) return 0;                                                                                  \
+        rc = store ? launch_seq<A_, B_, C_, true, F_>(pool, plan, blob, *prm, lds_total, policy, policy32, value, visits, st)  \
+                   : launch_seq<A_, B_, C_, false, F_>(pool, plan, blob, *prm, lds_total, policy, policy32, value, visits, st);\
     }
-    if (kcd == 6 && kcp == 8 && kcv == 8) MZ_SEQ_LAUNCH(6, 8, 8)
-    else if (kcd == 2 && kcp == 4 && kcv == 4) MZ_SEQ_LAUNCH(2, 4, 4)
+    if (kcd == 6 && kcp == 8 && kcv == 8 && full) MZ_SEQ_LAUNCH(6, 8, 8, true)
+    else if (kcd == 6 && kcp == 8 && kcv == 8) MZ_SEQ_LAUNCH(6, 8, 8, false)
+    else if (kcd == 2 && kcp == 4 && kcv == 4) MZ_SEQ_LAUNCH(2, 4, 4, false)
     else return 0;
 #undef MZ_SEQ_LAUNCH
     return rc == MZ_OK ? 1 : rc;

@@ -12,7 +12,7 @@ NAMES = {0: "staging", 1: "select", 2: "leaf gather", 3: "policy1|merge (all wav
 # the sequential-program kernel (implicit child latents) stamps its own steps
 SEQ_NAMES = {0: "staging", 1: "select + draw", 2: "leaf latent", 3: "merge (leaf)", 16: "child latent",
              18: "policy 1 (leaf + child) | merge (child)", 4: "policy 2 (leaf + child)", 5: "priors", 19: "policy 3 (narrow)",
-             6: "rollout latent", 7: "value 1", 8: "value 2 | reward 1", 9: "after the rounds: rewards of all children",
+             6: "rollout latent", 7: "value 1 | reward 1", 8: "value 2", 9: "after the rounds: rewards of all children",
              11: "child records, backup"}
 
 
@@ -35,7 +35,7 @@ def main():
     mcts.run(latent, to_play, eta, rand)
     torch.cuda.synchronize()
     st = mcts.stamps.cpu().numpy()
-    tot = st[:16].sum()
+    tot = st[:32].sum()
     for k in sorted(NAMES):
         v = st[k]
         print(f"{NAMES[k]:28s} {v:12d} cycles  {100*v/tot:5.1f}%   {v/(S+1):9.0f} /round")
