@@ -605,8 +605,9 @@ int mz_search_run(const mz_pool *pool, const mz_packed_nets *plan, const float *
 
 /* Schedule choice of the sequential-program kernel behind mz_search_run: where every wavefront of a
  * workgroup has a full share of every layer's column tiles (policy and value hidden widths 241-256,
- * value 2 / reward 1 widths 113-128, latents of 113-256 values -- the benchmark configuration), a
- * schedule written out for those shares runs, with a third register slot for weight tiles; 0 makes such
+ * value 2 / reward 1 widths 113-128, latents of 113-176 values -- the benchmark configuration), a
+ * schedule written out for those shares runs, with a third register slot for weight tiles and the merge
+ * tiles beyond one per wavefront resident in LDS; 0 makes such
  * searches take the general schedule.  Default 1.  Sets the choice unless new_value < 0; returns the
  * previous one.  Both leave bit-identical pools and results; no counterpart in the reference, a
  * cross-checking knob only. */

@@ -63,9 +63,9 @@ namespace {
 // of two dozen run-time bases held in (spilled) scalar registers; only the square-root / logarithm tables, whose
 // length is a launch parameter, follow at the end.
 //   xi: split image of the current input latents (leaf, drawn child, rollout latent in turn); z / zs: merge
-//   pre-activations of the leaf / of the drawn child (fp32 rows); h1: policy layer 1 of leaf (tile 0) and child
-//   (tile 1), split image; h2: policy layer 2 of leaf and child, likewise; hv: value layer 1 (split image); lg:
-//   logits / policies of the 32 rows; dote / dotv: partial sums of the folded layers; b_*: padded biases; dw_*: the
+//   pre-activations of the leaf / of the drawn child (fp32 rows, one buffer: their lives do not overlap); h1: policy
+//   layer 1 of leaf (tile 0) and child (tile 1), split image -- and, once policy 2 has read it, hv: value layer 1
+//   (split image) and lg: logits / policies of the 32 rows; h2: policy layer 2 of leaf and child; res: resident merge tiles; dote / dotv: partial sums of the folded layers; b_*: padded biases; dw_*: the
 //   folded one-output layers' weights by k.  After the last round everything from `xi` up to `dote` is one arena for
 //   the children's rewards: ew holds every column tile of reward 1 (as packed: two fp16 planes per k-chunk).
 constexpr int kSeqMaxA = 8, kSeqMaxTiles = 2 * kWaves, kSeqMaxFoldTiles = kWaves;
@@ -78,12 +78,18 @@ struct SeqLayout {
     static constexpr size_t xi = a16(tab + sizeof(float) * kSeqMaxA * ld_d);  // row tile 0: leaf (later the rollout latent), row tile 1: drawn child
     static constexpr size_t ew = xi;
     static constexpr size_t z = a16(xi + 2 * tile_d);
-    static constexpr size_t zs = a16(z + tile_d);
-    static constexpr size_t h1 = a16(zs + tile_d);
-    static constexpr size_t h2 = a16(h1 + sizeof(float) * 2 * kTrees * ld_p);
-    static constexpr size_t hv = a16(h2 + sizeof(float) * 2 * kTrees * ld_q);
+    static constexpr size_t zs = z;    // (the leaf's rows are stored and the child formed before the child's merge writes here)
+    static constexpr size_t h1 = a16(z + tile_d);
+    static constexpr size_t h1_bytes = sizeof(float) * 2 * kTrees * ld_p;
+    static constexpr size_t h2 = a16(h1 + h1_bytes);
+    static constexpr size_t hv = h1;   // (policy 1's rows are dead once policy 2 has read them)
     static constexpr size_t lg = a16(hv + sizeof(float) * kTrees * ld_v);
-    static constexpr size_t dote = a16(lg + sizeof(float) * 2 * kTrees * ld_l);
+    static_assert(lg + sizeof(float) * 2 * kTrees * ld_l <= h1 + h1_bytes, "value 1's rows and the logits share policy 1's buffer");
+    // merge column tiles beyond one per wave (as packed), resident for the whole search: a wave's second merge tile is
+    // read from here, twice a round, instead of from L2
+    static constexpr int res_tiles = 3;
+    static constexpr size_t res = a16(h2 + sizeof(float) * 2 * kTrees * ld_q);
+    static constexpr size_t dote = a16(res + sizeof(float) * (size_t)res_tiles * KCD * 512);
     static constexpr size_t ew_bytes = sizeof(float) * (size_t)(16 * kSeqMaxFoldTiles) * (KCD * 32);  // reward 1 at its widest
     static_assert(ew + ew_bytes <= dote, "the arena of the phase after the rounds fits in front of the small buffers");
     static constexpr size_t dotv = a16(dote + sizeof(float) * 4 * kSeqMaxFoldTiles * kTrees);
@@ -162,6 +168,39 @@ __device__ __forceinline__ void mma_tile(const Slot<KMAX> &s, const lds_f *img, 
             hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[c % kBuf][mt], hi[mt], 0, 0, 0);
             lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[c % kBuf][mt], lo[mt], 0, 0, 0);
             lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[c % kBuf][mt], lo[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The same with the tile's weights read from LDS (a tile as packed, this lane's 16 bytes of chunk 0 at wt).
+template <int KC, int MT>
+__device__ __forceinline__ void mma_tile_lds(const lds_f *wt, const lds_f *img, int x_tile, f32x4 (&hi)[MT], f32x4 (&lo)[MT]) {
+    constexpr int kAhead = 2, kBuf = kAhead + 1;
+    h8 ah[kBuf][MT], al[kBuf][MT], wh[kBuf], wl[kBuf];
+    auto read = [&](int c) {
+        wh[c % kBuf] = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(wt + (2 * c) * 256));
+        wl[c % kBuf] = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(wt + (2 * c + 1) * 256));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const lds_f *p = img + mt * x_tile + c * kChunkFloats;
+            ah[c % kBuf][mt] = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p));
+            al[c % kBuf][mt] = __builtin_bit_cast(h8, *reinterpret_cast<const lds_f4 *>(p + KC * kChunkFloats));
+        }
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) hi[mt] = lo[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < kAhead && c < KC; ++c) read(c);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        if (c + kAhead < KC) read(c + kAhead);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            hi[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c % kBuf], ah[c % kBuf][mt], hi[mt], 0, 0, 0);
+            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c % kBuf], al[c % kBuf][mt], lo[mt], 0, 0, 0);
+            lo[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c % kBuf], ah[c % kBuf][mt], lo[mt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -265,9 +304,9 @@ __device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int 
 // two in the merge (16 / 16 / 16 / 8 / 8 / 8-16 column tiles): the ring gets a third slot of the merge's width, and
 // the schedule of a round is written out for exactly these shares --
 //   * a wave's first merge tile stays in its slot from the leaf's merge to the drawn child's (the same weights:
-//     requested once per round instead of twice),
-//   * policy 1's tiles are both on their way during the selection, reward 1's tile during the softmax phase
-//     (beside value 1's two): no request for them inside a matrix step.
+//     requested once per round instead of twice), the merge tiles beyond eight are resident in LDS,
+//   * policy 1's tiles are both on their way during the selection, policy 2's first tile is requested behind
+//     policy 1's first product.
 template <int KCD, int KCP, int KCV, bool STORE, bool FULL>
 __global__ void __launch_bounds__(kThreads)
 k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_search_params q,
@@ -369,6 +408,11 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         s_act[tid] = 0;
         s_act2[tid] = 0;
     }
+    lds_f *RES = to_lds(smem_raw + L::res);
+    if constexpr (FULL) {
+        const glb_f4 *src = (const glb_f4 *)tile_of(Lm0, KCD, kWaves);
+        for (int i = tid; i < (nm0 - kWaves) * KCD * 128; i += kThreads) *reinterpret_cast<lds_f4 *>(RES + i * 4) = src[i];
+    }
     __syncthreads();
     rows_to_split(Z, ld_d, XI, ld_d, 1, KCD, ld_d, whole_workgroup());
     for (int i = tid; i < kTrees * ld_d; i += kThreads) XI[kTrees * ld_d + i] = 0.0f;  // (no drawn child in the root expansion)
@@ -430,8 +474,12 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     // takes policy 1's second tile already, a whole latency phase before that step)
     auto prefetch_merge = [&] {
         fetch_tile<KCD>(s0, m_tile0, lane);
-        fetch_tile<KCD>(s1, m_n > 1 ? m_tile1 : p0_tile1, lane);
-        if constexpr (FULL) fetch_tile<KCD>(sx, p0_tile0, lane);
+        if constexpr (FULL) {
+            fetch_tile<KCD>(s1, p0_tile1, lane);
+            fetch_tile<KCD>(sx, p0_tile0, lane);
+        } else {
+            fetch_tile<KCD>(s1, m_n > 1 ? m_tile1 : p0_tile1, lane);
+        }
     };
     using MultiPair = std::true_type;
     using OnePair = std::false_type;
@@ -444,6 +492,12 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     auto work_merge = [&](auto &s, const lds_f *img, int t, lds_f *dst) {
         f32x4 hi[1], lo[1];
         mma_tile<KCD, 1, kAhead1>(s, img + lane * 4, 0, hi, lo);
+        epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), dst, ld_d, lane);
+    };
+    auto work_merge_resident = [&](const lds_f *img, lds_f *dst) {  // this wave's second merge tile
+        const int t = wave + kWaves;
+        f32x4 hi[1], lo[1];
+        mma_tile_lds<KCD, 1>(RES + wave * (KCD * 512) + lane * 4, img + lane * 4, 0, hi, lo);
         epi_rows<1, false>(hi, lo, t, lds4(Bm + t * 16 + 4 * (lane >> 4)), dst, ld_d, lane);
     };
     auto work_policy1 = [&](auto &s, int t) {
@@ -609,10 +663,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         if (!sim) prefetch_merge();  // (root expansion: nothing to hide it behind)
         if constexpr (FULL) {
             work_merge(s0, XI, wave, Z);  // (slot 0 keeps the tile for the drawn child's merge)
-            if (m_n > 1) {
-                work_merge(s1, XI, wave + kWaves, Z);
-                fetch_tile<KCD>(s1, p0_tile1, lane);  // in flight through the barrier, the row store and the forming of the child
-            }
+            if (m_n > 1) work_merge_resident(XI, Z);
         } else {
             merge_leaf();
             if (m_n > 1) fetch_tile<KCD>(s1, p0_tile1, lane);  // in flight through the barrier, the row store and the forming of the child
@@ -639,16 +690,15 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             MZ_STAMP(16)  // child latent
         }
         if constexpr (FULL) {
-            // slot x: policy 1's first tile; slot 0: the merge tile the leaf used; slot 1: policy 1's second tile.
-            // Policy 2's tiles are requested as the slots fall free, a second merge tile behind the first product.
+            // slot x: policy 1's first tile; slot 1: its second; slot 0: the merge tile the leaf used.  Policy 2's
+            // tiles are requested as slots 1 and 0 fall free
             work_policy1(sx, p0_first);
-            if (sim && m_n > 1) fetch_tile<KCD>(sx, m_tile1, lane);
+            forget(sx);
             work_policy1(s1, p0_first + 1);
             fetch_tile<KCP>(s1, p1_tile1, lane);
             if (sim) work_merge(s0, XC, wave, Zs);
             fetch_tile<KCP>(s0, p1_tile0, lane);
-            if (sim && m_n > 1) work_merge(sx, XC, wave + kWaves, Zs);
-            forget(sx);
+            if (sim && m_n > 1) work_merge_resident(XC, Zs);
         } else {
             policy1_and_child_merge(sim);
         }
@@ -1011,7 +1061,8 @@ int mz_search_seq_try(const mz_pool *pool, const mz_packed_nets *plan, const flo
     // every wave with two tiles in policy 1, policy 2 and value 1, one in value 2 and reward 1, one or two in the merge
     const bool full = g_three_slots && (P.policy.layer[0].Np >> 4) == 2 * kWaves && (P.policy.layer[1].Np >> 4) == 2 * kWaves &&
                       (P.value.layer[0].Np >> 4) == 2 * kWaves && (P.value.layer[1].Np >> 4) == kWaves &&
-                      (P.reward.layer[0].Np >> 4) == kWaves && (P.merge.layer[0].Np >> 4) >= kWaves;
+                      (P.reward.layer[0].Np >> 4) == kWaves && (P.merge.layer[0].Np >> 4) >= kWaves &&
+                      (P.merge.layer[0].Np >> 4) <= kWaves + 3;  // (SeqLayout::res_tiles resident merge tiles)
 #define MZ_SEQ_LAUNCH(A_, B_, C_, F_)                                                                                          \
     {                                                                                                                          \
         const size_t lds_total = SeqLayout<A_, B_, C_>::total(prm->tab_len);                                                   \
