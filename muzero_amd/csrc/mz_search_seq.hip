@@ -290,6 +290,18 @@ __device__ __forceinline__ float ordered_sum(const lds_f *p, int stride, int n) 
     return s;
 }
 
+// The same for a length known at compile time (constant offsets, no index arithmetic).
+template <int N>
+__device__ __forceinline__ float ordered_sum_n(const lds_f *p, int stride) {
+    float v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[i * stride];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s += v[i];
+    return s;
+}
+
 // This wave's share of `total` column tiles, dealt in pairs (as dense_group_body): first tile and count.
 __device__ __forceinline__ void deal_pairs(int total, int wave, int &first, int &count) {
     const int units = (total + 1) >> 1;
@@ -570,6 +582,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         const int base = 1 + e * A;
         const bool sim = e > 0;
         if constexpr (FULL) forget(sx);
+        mzt::NodeStat path_stat = {0.0, 0, 0};  // backup lanes: statistics of this lane's node on the selected path
         // Thread-dependent addresses are re-derived every round from an opaque copy of the thread index: hoisted out
         // of the loop they stay live through the whole kernel, spill, and every reload from scratch waits for ALL
         // outstanding loads -- the ring's tiles in flight included.
@@ -642,6 +655,14 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                 // requested theirs there; the two selecting waves do it here, behind the rows (loads return in order:
                 // in front of the rows they would hold them back)
                 if (wave < 2) prefetch_merge();
+                // The backup of this round will add to the statistics of the nodes on the path just selected: nothing
+                // writes them before that, so the backup lanes read them now and the backup itself waits for no load
+                if (tid >= kThreads / 2 && tid < kThreads / 2 + kTrees * kPathCap) {
+                    const int bt = (tid - kThreads / 2) / kPathCap, bi = (tid - kThreads / 2) % kPathCap;
+                    const int dl = s_depth[bt];
+                    if (bt < trees && dl + 1 <= kPathCap - 1 && bi >= 1 && bi <= dl + 1)
+                        path_stat = mzt::load_stat(p, (size_t)(g0 + bt) * p.cap + s_path[bt * kPathCap + (dl - (bi - 1))]);
+                }
                 if (live) {
                     const lds_f *tr = Tab + a * ld_d + k0;
                     v0 = f32x4{fmaxf(z[0] + tr[0], 0.f), fmaxf(z[1] + tr[1], 0.f), fmaxf(z[2] + tr[2], 0.f), fmaxf(z[3] + tr[3], 0.f)};
@@ -779,6 +800,22 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             __syncthreads();
         }
         MZ_STAMP(5)  // policy 3, softmax, priors, greedy action
+        // ---- child records ---------------------------------------------------------------------------
+        // (by the last two waves, which have no share in the forming of the rollout latent that follows: nothing reads
+        // these records before the next round's selection, and the backup only writes to them)
+        for (int i = tid - (kThreads - 128); i >= 0 && i < trees * A; i += 128) {
+            const int t = i / A, a = i - t * A;
+            const size_t o = (size_t)(g0 + t) * p.cap;
+            float pr = s_prior[t * A + a];
+            if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
+            // (the reward follows after the rounds; the statistics of the drawn child come from the backup, which
+            // knows what a new record holds, unless the path is longer than the backup lanes cover)
+            if (sim && a == s_act[t] && s_depth[t] + 1 <= kPathCap - 1)
+                mzt::store_edge(p, o + base + a, mzt::NodeEdge{(double)pr, 0.0f, -1});
+            else
+                mzt::write_child(p, o, base, a, s_leaf[t], pr, 0.0f, (int8_t)s_leaf_tp[t]);
+            if (a == 0) p.node[o + s_leaf[t]].first_child = base;
+        }
         if (sim) {
             if (wave < 4) prefetch2(v0_tile0, v0_tile1, KCD);
             // ---- rollout latent ---------------------------------------------------------------------------
@@ -800,23 +837,16 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             __syncthreads();
             MZ_STAMP(8)  // value 2
             if (tid < kTrees) {  // value of the rollout latent (as finish_dot)
-                s_roll[tid * 2 + 1] = activate(ordered_sum(DotV + tid, kTrees, 4 * nv1) + Bv1[Lv1.Np], Lv2.act);
+                const float sum = FULL ? ordered_sum_n<4 * kWaves>(DotV + tid, kTrees) : ordered_sum(DotV + tid, kTrees, 4 * nv1);
+                s_roll[tid * 2 + 1] = activate(sum + Bv1[Lv1.Np], Lv2.act);
             } else if (tid >= 64 && tid < 64 + kTrees) {
                 const int t = tid - 64;
-                s_roll[t * 2] = activate(ordered_sum(DotE + t, kTrees, 4 * nr0) + Br0[Lr0.Np], Lr1.act);
+                const float sum = FULL ? ordered_sum_n<4 * kWaves>(DotE + t, kTrees) : ordered_sum(DotE + t, kTrees, 4 * nr0);
+                s_roll[t * 2] = activate(sum + Br0[Lr0.Np], Lr1.act);
             }
         }
 
-        // ---- child records ---------------------------------------------------------------------------
-        for (int i = tid; i < trees * A; i += kThreads) {
-            const int t = i / A, a = i - t * A;
-            const size_t o = (size_t)(g0 + t) * p.cap;
-            float pr = s_prior[t * A + a];
-            if (e == 0) pr = mzt::noisy_prior((double)pr, q.eta[(size_t)(g0 + t) * A + a], q.noise_frac);
-            mzt::write_child(p, o, base, a, s_leaf[t], pr, 0.0f, (int8_t)s_leaf_tp[t]);  // (the reward follows after the rounds)
-            if (a == 0) p.node[o + s_leaf[t]].first_child = base;
-        }
-        __syncthreads();  // the drawn child's record exists before the backup updates it (and s_roll is complete)
+        __syncthreads();  // s_roll is complete (and the records of a root expansion exist before the first selection)
         if (!sim) continue;
         // ---- backup: the recorded path is updated by independent lanes (see k_search) --------------------------
         if (tid >= kThreads / 2 && tid < kThreads / 2 + kTrees * kPathCap) {
@@ -835,7 +865,8 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                         const int node = (i == 0) ? s_child[t] : s_path[t * kPathCap + (dl - (i - 1))];
                         const bool same = s_root[t] == 0 || (i >= 1 && ((i - 1) & 1) == 0);
                         const size_t c = o + node;
-                        mzt::NodeStat st = mzt::load_stat(p, c);
+                        mzt::NodeStat st = path_stat;
+                        if (i == 0) st = mzt::NodeStat{0.0, 0, MZ_LINK(s_leaf[t], (int8_t)(-s_leaf_tp[t]))};  // a new record (write_child)
                         st.visit += 1;
                         const double add = same ? ret : -ret;
                         st.value_sum = st.value_sum + add;

@@ -13,7 +13,7 @@ NAMES = {0: "staging", 1: "select", 2: "leaf gather", 3: "policy1|merge (all wav
 SEQ_NAMES = {0: "staging", 1: "select + draw", 2: "leaf latent", 3: "merge (leaf)", 16: "child latent",
              18: "policy 1 (leaf + child) | merge (child)", 4: "policy 2 (leaf + child)", 5: "priors", 19: "policy 3 (narrow)",
              6: "rollout latent", 7: "value 1 | reward 1", 8: "value 2", 9: "after the rounds: rewards of all children",
-             11: "child records, backup"}
+             11: "rollout sums, backup"}
 
 
 def main():
