@@ -746,6 +746,9 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
 
         // ---- policy 3 (narrow), softmax; priors of the leaf, greedy action of the child ----------------------
         {
+            // value 1's first tiles: waves 1-3 request them beside policy 3 (they idle while the first wave multiplies;
+            // more waves would hold up the barrier behind it), waves 4-7 beside the softmax phase, the first wave after it
+            if (sim && wave >= 1 && wave < 4) prefetch2(v0_tile0, v0_tile1, KCD);
             if (wave == 0) {  // policy 3 of the 32 rows -> logits (fp32 rows; the layer's own softmax follows)
                 f32x4 hi[2], lo[2];
                 mma_tile<KCP, 2>(s0, H2 + lane * 4, 16 * ld_q, hi, lo);
@@ -753,7 +756,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             }
             __syncthreads();
             MZ_STAMP(19)  // policy 3
-            // value 1's first tiles: waves 4-7 request them beside the softmax phase (waves 0-3), which follow afterwards
             if (sim && wave >= 4) prefetch2(v0_tile0, v0_tile1, KCD);
             // softmax_rows' arithmetic for A <= 8 (row maximum; sum over the columns in ascending order) with eight lanes
             // per row, all 32 rows at once, the lanes of a row exchanging values through DPP moves instead of LDS round
@@ -817,7 +819,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             if (a == 0) p.node[o + s_leaf[t]].first_child = base;
         }
         if (sim) {
-            if (wave < 4) prefetch2(v0_tile0, v0_tile1, KCD);
+            if (wave == 0) prefetch2(v0_tile0, v0_tile1, KCD);
             // ---- rollout latent ---------------------------------------------------------------------------
             for (int i = tid; i < KCD * 64; i += kThreads) form_item(i, Zs, -1, s_act2, XI);
             __syncthreads();
