@@ -715,10 +715,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             // tiles are requested as slots 1 and 0 fall free
             work_policy1(sx, p0_first);
             forget(sx);
-            work_policy1(s1, p0_first + 1);
-            fetch_tile<KCP>(s1, p1_tile1, lane);
             if (sim) work_merge(s0, XC, wave, Zs);
             fetch_tile<KCP>(s0, p1_tile0, lane);
+            work_policy1(s1, p0_first + 1);
+            fetch_tile<KCP>(s1, p1_tile1, lane);
             if (sim && m_n > 1) work_merge_resident(XC, Zs);
         } else {
             policy1_and_child_merge(sim);
@@ -737,11 +737,10 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             auto ptr = [&](int j) { return tile_of(Lp1, KCP, min(p1_first + j, np1 - 1)); };
             // policy 3 is one column tile: the first wave multiplies it, and requests it as soon as its slot 0 is free
             if constexpr (FULL) {
-                // (slot 1's tile was requested first, behind policy 1's second product: it is multiplied first, while
-                // slot 0's is still on its way)
-                work(s1, 1);
-                if (wave == 0) fetch_tile<KCP>(s1, tile_of(Lp2, KCP, 0), lane);
+                // (in the order the tiles were requested)
                 work(s0, 0);
+                if (wave == 0) fetch_tile<KCP>(s0, tile_of(Lp2, KCP, 0), lane);
+                work(s1, 1);
             } else {
                 run_step(std::integral_constant<int, KCP>{}, OnePair{}, p1_n, ptr, work, [&] {
                     if (wave == 0) fetch_tile<KCP>(s0, tile_of(Lp2, KCP, 0), lane);
@@ -759,7 +758,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             if (sim && wave >= 1 && wave < 4) prefetch2(v0_tile0, v0_tile1, KCD);
             if (wave == 0) {  // policy 3 of the 32 rows -> logits (fp32 rows; the layer's own softmax follows)
                 f32x4 hi[2], lo[2];
-                mma_tile<KCP, 2>(FULL ? s1 : s0, H2 + lane * 4, 16 * ld_q, hi, lo);
+                mma_tile<KCP, 2>(s0, H2 + lane * 4, 16 * ld_q, hi, lo);
                 epi_rows<2, false>(hi, lo, 0, lds4(Bp2 + 4 * (lane >> 4)), Lg, ld_l, lane);
             }
             __syncthreads();
