@@ -832,17 +832,29 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             __syncthreads();
             MZ_STAMP(6)  // rollout latent
             // ---- value 1 of the rollout latent -> Hv (split image) | reward 1 of the rollout latent ---------------
-            run_step(std::integral_constant<int, KCD>{}, OnePair{}, v0_n, [&](int j) { return tile_of(Lv0, KCD, min(v0_first + j, nv0 - 1)); },
-                     [&](Slot<KMAX> &s, int j) { work_value1(s, v0_first + j); },
-                     [&] { fetch_tile<KCD>(s0, r0_tile, lane); },  // reward 1's tile: beside this wave's second tile
-                     nothing);
-            fetch_tile<KCV>(s1, v1_tile, lane);  // value 2's tile: in flight through reward 1 and the barrier
-            // reward 1 of the rollout latent (its input is the one value 1 has just read)
-            if (wave < nr0) work_reward1(s0);
+            if constexpr (FULL) {
+                // the third slot takes reward 1's tile at once, slot 0 value 2's tile behind the first product
+                forget(sx);
+                fetch_tile<KCD>(sx, r0_tile, lane);
+                work_value1(s0, v0_first);
+                fetch_tile<KCV>(s0, v1_tile, lane);
+                work_value1(s1, v0_first + 1);
+                work_reward1(sx);
+                forget(sx);
+            } else {
+                run_step(std::integral_constant<int, KCD>{}, OnePair{}, v0_n, [&](int j) { return tile_of(Lv0, KCD, min(v0_first + j, nv0 - 1)); },
+                         [&](Slot<KMAX> &s, int j) { work_value1(s, v0_first + j); },
+                         [&] { fetch_tile<KCD>(s0, r0_tile, lane); },  // reward 1's tile: beside this wave's second tile
+                         nothing);
+                fetch_tile<KCV>(s1, v1_tile, lane);  // value 2's tile: in flight through reward 1 and the barrier
+                // reward 1 of the rollout latent (its input is the one value 1 has just read)
+                if (wave < nr0) work_reward1(s0);
+            }
             __syncthreads();
             MZ_STAMP(7)  // value 1 | reward 1
             // ---- value 2 ------------------------------------------------------------------------------------
-            if (wave < nv1) work_value2(s1);
+            if constexpr (FULL) work_value2(s0);
+            else if (wave < nv1) work_value2(s1);
             __syncthreads();
             MZ_STAMP(8)  // value 2
             if (tid < kTrees) {  // value of the rollout latent (as finish_dot)
