@@ -379,3 +379,45 @@ def test_implicit_child_latents_leave_identical_trees(which, G, S, depth):
         np.testing.assert_allclose(kids.numpy(), want.numpy(), rtol=1e-5, atol=2e-6)
     with pytest.raises(NotImplementedError):
         b.run(*args, fused=False)
+
+
+@pytest.mark.parametrize("which,G,S", [("c4", 100, 50), ("c4", 4100, 5), ("ragged", 35, 12)])
+@pytest.mark.parametrize("keep", [False, True])
+def test_written_out_schedule_equals_the_general_one(which, G, S, keep):
+    """Where every wavefront has a full share of every layer's column tiles the one-launch search runs a schedule
+    written out for those shares (a third register slot for weight tiles, a merge tile kept from the leaf's merge
+    to the drawn child's, further merge tiles resident in LDS); mz_search_seq_three_slots(0) makes the same
+    searches take the general schedule.  Pools and results are identical bit for bit, with and without stored
+    latents (src/search/mcts.py:44-74 either way)."""
+    from muzero_amd import _hip
+    from muzero_amd.engine import BatchedMCTS, PackedNetworks
+    if which == "c4":
+        _, g, f = _c4_nets(5)
+        D = 168
+    else:
+        g, f = _custom_nets((1, 10, 17), 6, [128], [256, 128], [256, 256], ("relu",))
+        D = 170
+    A = g.num_actions
+    nets = PackedNetworks(g, f)
+    lat, eta, rand, to_play = _inputs(G, A, S, D, seed=7 * G + S)
+    args = [torch.from_numpy(x).cuda() for x in (lat, to_play, eta, rand)]
+    lib = _hip.lib()
+    runs = []
+    old = lib.mz_search_seq_three_slots(-1)
+    assert old == 1
+    try:
+        for choice in (1, 0):
+            lib.mz_search_seq_three_slots(choice)
+            m = BatchedMCTS(nets, G, S, 1, discount=0.997, noise_frac=0.25, keep_latents=keep)
+            res = m.run(*args)
+            torch.cuda.synchronize()
+            runs.append((m, res))
+    finally:
+        lib.mz_search_seq_three_slots(old)
+    (a, ra), (b, rb) = runs
+    names = ["visit", "value_sum", "prior", "reward", "parent", "first_child", "to_play", "n_nodes"] + (["latent"] if keep else [])
+    for name in names:
+        assert torch.equal(getattr(a.pool, name), getattr(b.pool, name)), name
+    assert torch.equal(a.z_pool, b.z_pool)
+    assert torch.equal(ra.policy, rb.policy) and torch.equal(ra.value, rb.value) and torch.equal(ra.visits, rb.visits)
+    assert torch.equal(ra.policy32, rb.policy32)
