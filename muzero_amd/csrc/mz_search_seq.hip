@@ -2,7 +2,7 @@
 // arithmetic as k_search (mz_search.hip) for the network shape the benchmark configuration and
 // the reference's config.yaml heads have, organised around the resource that bounds that kernel.
 //
-// A 16-tree workgroup reads ~1.3 MB of packed weights per simulation round for 16 rows of work.
+// A 16-tree workgroup reads ~1 MB of packed weights per simulation round for 16 rows of work.
 // They come from L2 (the whole model is 1 MB) into registers at no more than ~60 bytes per clock
 // and compute unit; a wave that issues a tile's loads is held for as long as the port needs to
 // take them, every matrix step would start with a round trip to L2, and between the matrix steps
@@ -14,9 +14,12 @@
 //   policy 1 for leaf AND child as one 32-row pass | merge(drawn child)
 //   policy 2 for leaf AND child as one 32-row pass      (their weights are read once, not twice)
 //   policy 3 for the 32 rows (one column tile: one wave), softmax; priors of the leaf, greedy action of the child
-//   value 1 (rollout latent)
-//   value 2 | reward 1 of the rollout latent
-//   child records, backup
+//   value 1 (rollout latent) | reward 1 of the rollout latent
+//   value 2
+//   rollout sums, backup                                (the leaf's child records are written beside the rollout latent)
+//
+// Where every wave has a full share of every layer's column tiles (the benchmark's widths) the round runs a
+// schedule written out for those shares, with a third register slot (template parameter FULL below).
 //
 // The rewards of the A children of every expansion (src/search/expansion.py:29-33) are outputs only --
 // no selection, rollout or backup reads a node's reward -- so they are not computed inside the rounds:
