@@ -114,16 +114,19 @@ __device__ __forceinline__ int select_leaf(const mz_pool &p, size_t o, int a, co
         }
         double score = -__builtin_inf();
         if (child_lane) {
+            // (both quotients formed side by side, in one block: two dependent float64 divisions in a row are the
+            // longest stretch of a level; the mean value is only used where the child has been visited)
+            const double q = w / (double)(n > 0 ? n : 1);
             double pb = s_tab[n_parent] / (double)(n + 1);
             pb = pb * s_tab[tab_len + n];
             if (node == 0 && root_f32) {
                 float ps = (float)pb * (float)pr;
                 float sc = ps;
-                if (n > 0) sc = (float)(w / (double)n) + ps;
+                if (n > 0) sc = (float)q + ps;
                 score = (double)sc;
             } else {
                 double ps = pb * pr;
-                score = (n > 0) ? (w / (double)n + ps) : (0.0 + ps);
+                score = (n > 0) ? (q + ps) : (0.0 + ps);
             }
         }
         const double best = group_max<LPT>(score);
