@@ -20,7 +20,7 @@ def main():
     from muzero_amd.engine import BatchedMCTS, PackedNetworks
     global NAMES
     cfg, h, g, f = bench.build_networks()
-    G, S = 4096, 50
+    G, S = int(os.environ.get("MZ_STAGE_GAMES", "4096")), 50  # (256 games: the whole pool fits in L2)
     nets = PackedNetworks(g, f)
     stored = "--store-latents" in sys.argv
     if not stored and os.environ.get("MZ_SEARCH_SEQ", "1") != "0":
