@@ -584,7 +584,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
     for (int e = 0; e <= S; ++e) {
         const int base = 1 + e * A;
         const bool sim = e > 0;
-        if constexpr (FULL) forget(sx);
         mzt::NodeStat path_stat = {0.0, 0, 0};  // backup lanes: statistics of this lane's node on the selected path
         // Thread-dependent addresses are re-derived every round from an opaque copy of the thread index: hoisted out
         // of the loop they stay live through the whole kernel, spill, and every reload from scratch waits for ALL
@@ -607,7 +606,7 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
             // Issuing a tile's loads occupies a wave for as long as the compute unit's L2 port needs to take them, and a
             // barrier makes everybody wait for the issuing waves: the six waves that do not select request the first
             // tiles of the leaf's merge HERE, beside the selection (a latency chain of dependent record reads); the
-            // two selecting waves follow in the leaf-latent phase
+            // two selecting waves have requested theirs at the end of the round before
             if (wave >= 2) prefetch_merge();
             if (tid < kTrees * lpt) {
                 const int t = tid / lpt, a = tid % lpt;
@@ -653,11 +652,6 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
                         for (int j = 0; j < 8; ++j) z[j] = k0 + j < D ? zr[j] : 0.0f;
                     }
                 }
-                // The tiles of the leaf's merge.  Issuing a tile's loads occupies the wave for as long as the compute
-                // unit's L2 port needs to take them, so the waves that were idle during records, backup and selection
-                // requested theirs there; the two selecting waves do it here, behind the rows (loads return in order:
-                // in front of the rows they would hold them back)
-                if (wave < 2) prefetch_merge();
                 // The backup of this round will add to the statistics of the nodes on the path just selected: nothing
                 // writes them before that, so the backup lanes read them now and the backup itself waits for no load
                 if (tid >= kThreads / 2 && tid < kThreads / 2 + kTrees * kPathCap) {
@@ -871,6 +865,12 @@ k_search_seq(mz_pool p, mz_packed_nets Pk, const float *__restrict__ blob, mz_se
         }
 
         __syncthreads();  // s_roll is complete (and the records of a root expansion exist before the first selection)
+        // The two selecting waves request the next round's first tiles HERE, where they idle beside the backup: issued
+        // in the leaf-latent phase, their 72 KB stood in the port's queue in front of the other waves' loads of the
+        // leaf's rows.  (Their first record reads of the selection return behind these tiles: the backup covers most of it.)
+        forget(s0), forget(s1);  // (every slot is free here)
+        if constexpr (FULL) forget(sx);
+        if (wave < 2 && e < S) prefetch_merge();
         if (!sim) continue;
         // ---- backup: the recorded path is updated by independent lanes (see k_search) --------------------------
         if (tid >= kThreads / 2 && tid < kThreads / 2 + kTrees * kPathCap) {
